@@ -1,0 +1,101 @@
+"""Pins the CPU oracle (oracle/) to every fixed output the reference's own tests hold
+(SURVEY.md §8c): whisk.rs:355-361, :363-368, :381-402, :416-456, plus the published Merlin
+vector and Keccak (via hashlib's SHA3).  CPU only."""
+import hashlib
+import os
+import struct
+
+P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+def test_keccak_against_hashlib_sha3(orc):
+    # SHA3-256 of a short message = one Keccak-f[1600] call on the padded block (rate 136)
+    msg = b"curdleproofs oracle keccak check"
+    st = bytearray(200)
+    st[: len(msg)] = msg
+    st[len(msg)] ^= 0x06
+    st[135] ^= 0x80
+    out = orc.keccak_f1600(bytes(st))
+    assert out[:32] == hashlib.sha3_256(msg).digest()
+
+
+def test_merlin_published_vector(orc):
+    assert orc.merlin_test_vector().hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+def test_stdrng_checkpoints(orc):
+    rng = orc.rng(0)
+    assert rng.key().hex() == "ecf273f981b5cd4587f0467306ad6cadd0d0a3e33317e767f29bea72d78a7dfe"
+    assert [rng.u32() for _ in range(4)] == [0xCD2C6F7F, 0xBB2A3FB2, 0x8E27697B, 0xC6017C94]
+
+
+def test_fr_rand_is_montgomery_limbs(orc):
+    # SURVEY §8c checkpoint: first Fr::rand of StdRng(0), canonical LE bytes
+    fr = orc.rng(0).fr(1)
+    assert orc.fr_to_canonical_bytes(fr).hex() == "7a497eeda6d8ed1f38c9324427a251a98a215f13d93c3a138a727b5c27019269"
+
+
+def test_fr_bytes_roundtrip_kat(orc, whisk_kat):
+    # whisk.rs:355-361 serde_fr_rand
+    k_bytes = bytes.fromhex(whisk_kat["fr_le_bytes"])
+    k = orc.fr_from_le_bytes_mod_order(k_bytes)
+    assert orc.fr_to_canonical_bytes(k) == k_bytes
+    assert orc.fr_from_canonical_bytes(k_bytes) == k
+
+
+def test_g1_generator_roundtrip_kat(orc, whisk_kat):
+    # whisk.rs:363-368 serde_g1_roundtrip
+    gen = bytes.fromhex(whisk_kat["g1_generator_compressed"])
+    p = orc.g1_decompress(gen)
+    assert p == orc.g1_generator()
+    assert orc.g1_compress(p) == gen
+    assert orc.g1_on_curve(p) and orc.g1_in_subgroup(p)
+
+
+def test_field_arithmetic_against_python_ints(orc):
+    # independent check of the Montgomery code with Python big ints
+    rnd = os.urandom
+    for mod, nbytes, mul, inv in ((P, 48, orc.fp_mul, orc.fp_inv), (R, 32, orc.fr_mul, orc.fr_inv)):
+        Rm = 1 << (8 * nbytes)
+        a = [int.from_bytes(rnd(nbytes), "little") % mod for _ in range(16)] + [0, 1, mod - 1]
+        b = [int.from_bytes(rnd(nbytes), "little") % mod for _ in range(16)] + [mod - 1, mod - 1, mod - 1]
+        ab = b"".join(x.to_bytes(nbytes, "little") for x in a)
+        bb = b"".join(x.to_bytes(nbytes, "little") for x in b)
+        got = mul(ab, bb)
+        Rinv = pow(Rm, -1, mod)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert int.from_bytes(got[i * nbytes:(i + 1) * nbytes], "little") == x * y * Rinv % mod
+        gi = inv(ab)
+        for i, x in enumerate(a):
+            if x:
+                # inverse in Montgomery form: (x R^-1)^-1 * R = R^2 / x
+                assert int.from_bytes(gi[i * nbytes:(i + 1) * nbytes], "little") == pow(x, -1, mod) * Rm * Rm % mod
+
+
+def test_crs_checkpoint(orc):
+    # generate_crs(124).vec_G[0] compressed starts ac5f2023...
+    crs = orc.generate_crs_points(4)   # same StdRng(0) stream prefix for any ell
+    assert orc.g1_compress(crs[:96]).hex().startswith("ac5f20234d022490c77c18f9a9ec8458")
+
+
+def test_shuffle_checkpoint(orc):
+    # the permutation of KAT 4 is drawn after 248 tracker scalars (whisk.rs:418-424, :152-153)
+    rng = orc.rng(0)
+    rng.fr(248)
+    assert rng.shuffle(124)[:8] == [30, 94, 39, 35, 69, 3, 52, 115]
+
+
+def test_tracker_proof_kat(orc, whisk_kat):
+    # whisk.rs:381-402
+    valid, proof = orc.kat_tracker_proof()
+    assert valid == 1
+    assert proof.hex() == whisk_kat["tracker_proof"]
+
+
+def test_whisk_shuffle_proof_kat(orc, whisk_kat):
+    # whisk.rs:416-456: 4496 bytes = M || CurdleproofsProof::serialize at ell = 124
+    valid, proof, pre, post = orc.kat_shuffle_proof(124)
+    assert valid == 1
+    assert len(proof) == 4496
+    assert proof.hex() == whisk_kat["whisk_shuffle_proof_ell124"]

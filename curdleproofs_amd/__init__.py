@@ -1,0 +1,313 @@
+"""curdleproofs_amd — MI355X (gfx950) core for the Curdleproofs shuffle argument's G1 hot path.
+
+Python mirror of the reference's interface for this path (asn-d6/curdleproofs):
+
+    util::msm / msm_from_projective           -> Context.msm / Context.msm_from_projective
+    the fold / rescale loops                  -> Context.fold / Context.scale
+    msm_accumulator::MsmAccumulator           -> MsmAccumulator
+    CurdleproofsCrs::from_points              -> Context.set_crs
+    CurdleproofsProof::{new, verify}          -> Context.prove_batch / Context.verify_batch
+                                                 (CurdleproofsProof.new / .verify for one instance)
+
+All of it is a thin ctypes layer over the C-ABI in include/cpx.h (curdleproofs_amd/_lib/libcpx.so).
+There is no CPU implementation behind these calls: if the HIP library or a GPU is missing they raise.
+Byte layouts are arkworks' in-memory limbs (Fr 32 B, affine 96 B, Jacobian 144 B); see include/cpx.h.
+"""
+import ctypes
+import os
+
+from .build import LIB as _LIB_PATH
+
+FR = 32
+AFF = 96
+JAC = 144
+N_BLINDERS = 4   # reference src/lib.rs:35
+
+CPX_OK = 0
+CPX_ERR_ARG = -1
+CPX_ERR_NOT_POW2 = -2
+CPX_ERR_HIP = -3
+CPX_ERR_VERIFY = -4
+CPX_ERR_DESERIALIZE = -5
+CPX_ERR_STATE = -6
+CPX_ERR_INTERNAL = -7
+
+_ERRNAMES = {CPX_ERR_ARG: "bad argument", CPX_ERR_NOT_POW2: "ell + 4 is not a power of two", CPX_ERR_HIP: "HIP failure",
+             CPX_ERR_VERIFY: "verification failed", CPX_ERR_DESERIALIZE: "deserialization failed",
+             CPX_ERR_STATE: "call order (CRS / batch not set)", CPX_ERR_INTERNAL: "internal error"}
+
+
+class CpxError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("cpx error %d (%s) %s" % (code, _ERRNAMES.get(code, "?"), detail))
+
+
+class ProofError(CpxError):
+    """Mirror of the reference's ProofError::VerificationError (src/errors.rs:9)."""
+
+
+_lib = None
+
+EXPORTS = [
+    "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size",
+    "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress",
+    "cpx_accum_new", "cpx_accum_free", "cpx_accum_check", "cpx_accum_verify",
+    "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify",
+    "cpx_set_profiling", "cpx_reset_stats", "cpx_get_stat", "cpx_set_host_threads", "cpx_bench_fpmul",
+]
+
+
+def load_library():
+    """Loads libcpx.so; raises if it has not been built (python -m curdleproofs_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("curdleproofs_amd: %s is missing — build it with `python -m curdleproofs_amd.build` "
+                          "(hipcc, gfx950). There is no CPU fallback." % _LIB_PATH)
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.cpx_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.cpx_ctx_destroy.argtypes = [vp]
+    L.cpx_ctx_destroy.restype = None
+    L.cpx_last_error.argtypes = [vp]
+    L.cpx_last_error.restype = ctypes.c_char_p
+    L.cpx_device_count.argtypes = []
+    L.cpx_ctx_set_crs.argtypes = [vp, sz, vp]
+    L.cpx_crs_sums.argtypes = [vp, vp, vp]
+    L.cpx_proof_size.argtypes = [vp]
+    L.cpx_proof_size.restype = sz
+    L.cpx_g1_msm.argtypes = [vp, vp, vp, sz, vp]
+    L.cpx_g1_msm_jac.argtypes = [vp, vp, vp, sz, vp]
+    L.cpx_g1_fold.argtypes = [vp, vp, vp, vp, sz]
+    L.cpx_g1_scale.argtypes = [vp, vp, vp, sz, sz, vp]
+    L.cpx_g1_normalize.argtypes = [vp, vp, sz, vp, vp]
+    L.cpx_g1_decompress.argtypes = [vp, vp, sz, vp, ci]
+    L.cpx_accum_new.argtypes = [vp, ctypes.POINTER(vp)]
+    L.cpx_accum_free.argtypes = [vp]
+    L.cpx_accum_free.restype = None
+    L.cpx_accum_check.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.cpx_accum_verify.argtypes = [vp]
+    L.cpx_batch_load.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+    L.cpx_batch_prove.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.cpx_batch_verify.argtypes = [vp, vp, vp, vp]
+    L.cpx_set_profiling.argtypes = [vp, ci]
+    L.cpx_reset_stats.argtypes = [vp]
+    L.cpx_get_stat.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(ctypes.c_double)]
+    L.cpx_set_host_threads.argtypes = [vp, ci]
+    L.cpx_bench_fpmul.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    _lib = L
+    return L
+
+
+def device_count():
+    return load_library().cpx_device_count()
+
+
+def _in(b):
+    return (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(bytes(b) if len(b) else b"\0")
+
+
+def _out(n):
+    return (ctypes.c_uint8 * max(n, 1))()
+
+
+class Context:
+    """One HIP device + stream + device-resident CRS (cpx_ctx)."""
+
+    def __init__(self, device=0):
+        self._L = load_library()
+        h = ctypes.c_void_p()
+        rc = self._L.cpx_ctx_create(device, ctypes.byref(h))
+        if rc != CPX_OK:
+            raise CpxError(rc, "cpx_ctx_create(device=%d): no usable MI355X/HIP device" % device)
+        self._h = h
+        self.ell = None
+        self.batch = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cpx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != CPX_OK:
+            detail = self._L.cpx_last_error(self._h).decode(errors="replace")
+            raise (ProofError if rc == CPX_ERR_VERIFY else CpxError)(rc, detail)
+
+    # ---- CRS (crs.rs:37-58) ----
+    def set_crs(self, ell, points):
+        assert len(points) == AFF * (ell + 7), "need ell + 7 affine points"
+        self._check(self._L.cpx_ctx_set_crs(self._h, ell, _in(points)))
+        self.ell = ell
+        self.n = ell + N_BLINDERS
+        self.crs_points = bytes(points)
+
+    def crs_sums(self):
+        g, h = _out(AFF), _out(AFF)
+        self._check(self._L.cpx_crs_sums(self._h, g, h))
+        return bytes(g), bytes(h)
+
+    @property
+    def proof_size(self):
+        return self._L.cpx_proof_size(self._h)
+
+    # ---- tier 0 ----
+    def msm(self, bases, scalars):
+        """util.rs:19-22; panics in the reference on a length mismatch -> ValueError here."""
+        n = len(scalars) // FR
+        if len(bases) != AFF * n or len(scalars) != FR * n:
+            raise ValueError("number of points != number of scalars")
+        o = _out(JAC)
+        self._check(self._L.cpx_g1_msm(self._h, _in(bases), _in(scalars), n, o))
+        return bytes(o)
+
+    def msm_from_projective(self, bases_jac, scalars):
+        n = len(scalars) // FR
+        if len(bases_jac) != JAC * n:
+            raise ValueError("number of points != number of scalars")
+        o = _out(JAC)
+        self._check(self._L.cpx_g1_msm_jac(self._h, _in(bases_jac), _in(scalars), n, o))
+        return bytes(o)
+
+    def fold(self, PL, PR, gamma):
+        half = len(PL) // AFF
+        assert len(PR) == len(PL) and len(gamma) == FR
+        b = _in(PL)
+        self._check(self._L.cpx_g1_fold(self._h, b, _in(PR), _in(gamma), half))
+        return bytes(b)[: AFF * half]
+
+    def scale(self, P, scalars):
+        n = len(P) // AFF
+        stride = 0 if len(scalars) == FR else FR
+        o = _out(AFF * n)
+        self._check(self._L.cpx_g1_scale(self._h, _in(P), _in(scalars), stride, n, o))
+        return bytes(o)[: AFF * n]
+
+    def normalize(self, jac, compressed=False):
+        n = len(jac) // JAC
+        a, c = _out(AFF * n), _out(48 * n)
+        self._check(self._L.cpx_g1_normalize(self._h, _in(jac), n, a, c))
+        return (bytes(a)[: AFF * n], bytes(c)[: 48 * n]) if compressed else bytes(a)[: AFF * n]
+
+    def decompress(self, comp, check_subgroup=True):
+        n = len(comp) // 48
+        o = _out(AFF * n)
+        self._check(self._L.cpx_g1_decompress(self._h, _in(comp), n, o, 1 if check_subgroup else 0))
+        return bytes(o)[: AFF * n]
+
+    # ---- tier 2 ----
+    def load_batch(self, vec_R, vec_S, vec_T, vec_U, M):
+        """Uploads `batch` instances (concatenated per-proof buffers)."""
+        batch = len(M) // JAC
+        for v in (vec_R, vec_S, vec_T, vec_U):
+            assert len(v) == batch * self.ell * AFF
+        self._check(self._L.cpx_batch_load(self._h, batch, _in(vec_R), _in(vec_S), _in(vec_T), _in(vec_U), _in(M)))
+        self.batch = batch
+
+    def prove_batch(self, permutations, k, vec_m_blinders, rand):
+        """CurdleproofsProof::new for every loaded instance; returns a list of serialized proofs."""
+        B, ell, n = self.batch, self.ell, self.n
+        perm = (ctypes.c_uint32 * (B * ell))(*permutations)
+        assert len(k) == B * FR and len(vec_m_blinders) == B * 4 * FR and len(rand) == B * (3 * n + 9) * FR
+        psz = self.proof_size
+        out = _out(B * psz)
+        self._check(self._L.cpx_batch_prove(self._h, perm, _in(k), _in(vec_m_blinders), _in(rand), out))
+        raw = bytes(out)
+        return [raw[i * psz:(i + 1) * psz] for i in range(B)]
+
+    def verify_batch(self, proofs, rand):
+        """CurdleproofsProof::verify for every loaded instance; returns a list of CPX_* verdicts."""
+        B = self.batch
+        psz = self.proof_size
+        blob = b"".join(proofs)
+        assert len(blob) == B * psz and len(rand) == B * 8 * FR
+        verdict = (ctypes.c_int * B)()
+        self._check(self._L.cpx_batch_verify(self._h, _in(blob), _in(rand), verdict))
+        return list(verdict)
+
+    # ---- measurement ----
+    def set_profiling(self, on=True):
+        self._check(self._L.cpx_set_profiling(self._h, 1 if on else 0))
+
+    def reset_stats(self):
+        self._check(self._L.cpx_reset_stats(self._h))
+
+    def stat(self, name):
+        n, ms, by = ctypes.c_uint64(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._L.cpx_get_stat(self._h, name.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+        return dict(launches=n.value, ms=ms.value, alg_bytes=by.value)
+
+    def set_host_threads(self, t):
+        self._check(self._L.cpx_set_host_threads(self._h, t))
+
+    def bench_fpmul(self, blocks=2048, iters=2000, reps=3):
+        r = ctypes.c_double(0)
+        self._check(self._L.cpx_bench_fpmul(self._h, blocks, iters, reps, ctypes.byref(r)))
+        return r.value
+
+
+class MsmAccumulator:
+    """msm_accumulator.rs:22-68.  The random factor is drawn by the caller (the RNG stays outside)."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._L = ctx._L
+        h = ctypes.c_void_p()
+        ctx._check(self._L.cpx_accum_new(ctx._h, ctypes.byref(h)))
+        self._h = h
+
+    def accumulate_check(self, C, vec_x, vec_V, random_factor):
+        n = min(len(vec_x) // FR, len(vec_V) // AFF)   # Rust `zip`
+        self._ctx._check(self._L.cpx_accum_check(self._h, _in(C), _in(vec_x), _in(vec_V), n, _in(random_factor)))
+
+    def verify(self):
+        rc = self._L.cpx_accum_verify(self._h)
+        if rc == CPX_ERR_VERIFY:
+            raise ProofError(rc)
+        self._ctx._check(rc)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.cpx_accum_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class CurdleproofsProof:
+    """One serialized proof, with the reference's constructor / verifier names (curdleproofs.rs:59,197)."""
+
+    def __init__(self, data):
+        self.data = bytes(data)
+
+    @staticmethod
+    def new(ctx, vec_R, vec_S, vec_T, vec_U, M, permutation, k, vec_m_blinders, rand):
+        ctx.load_batch(vec_R, vec_S, vec_T, vec_U, M)
+        return CurdleproofsProof(ctx.prove_batch(list(permutation), k, vec_m_blinders, rand)[0])
+
+    def verify(self, ctx, vec_R, vec_S, vec_T, vec_U, M, rand):
+        ctx.load_batch(vec_R, vec_S, vec_T, vec_U, M)
+        v = ctx.verify_batch([self.data], rand)[0]
+        if v == CPX_ERR_VERIFY:
+            raise ProofError(v)
+        if v != CPX_OK:
+            raise CpxError(v)
+
+    def serialize(self):
+        return self.data
+
+    @staticmethod
+    def deserialize(data, log2_n):
+        if len(data) != 48 * (18 + 10 * log2_n) + 32 * 7:
+            raise CpxError(CPX_ERR_DESERIALIZE, "wrong length")
+        return CurdleproofsProof(data)

@@ -1,0 +1,1205 @@
+// Host engine of the MI355X Curdleproofs core — see engine.hpp.  Product code: no CPU fallback for
+// the group arithmetic exists here; every point operation below is a kernel launch (kernels.hip).
+#include "engine.hpp"
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <thread>
+
+namespace cpx {
+
+using host::S;
+using host::SVec;
+using host::Transcript;
+
+static const size_t N_BLINDERS = 4;   // /root/reference/src/lib.rs:35
+
+// ---- per-proof point registry ("slots") that follows the 4*ell instance points in d_pp_ ----
+// CRS singles, M, then every proof point in serialisation order (curdleproofs.rs:300-310), then scratch.
+enum { SL_H = 0, SL_GT, SL_GU, SL_GSUM, SL_HSUM, SL_M, SL_A, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, SL_R, SL_S, SL_B, SL_C, SL_BC, SL_BD, SL_IPA0 };
+struct SlotMap {
+  int L;
+  explicit SlotMap(size_t l) : L((int)l) {}
+  int LC(int j) const { return SL_IPA0 + j; }
+  int RC(int j) const { return SL_IPA0 + L + j; }
+  int LD(int j) const { return SL_IPA0 + 2 * L + j; }
+  int RD(int j) const { return SL_IPA0 + 3 * L + j; }
+  int CMA1() const { return SL_IPA0 + 4 * L; }
+  int CMA2() const { return CMA1() + 1; }
+  int CMB1() const { return CMA1() + 2; }
+  int CMB2() const { return CMA1() + 3; }
+  int BA() const { return CMA1() + 4; }
+  int BT() const { return CMA1() + 5; }
+  int BU() const { return CMA1() + 6; }
+  int LA(int j) const { return CMA1() + 7 + j; }
+  int LT(int j) const { return CMA1() + 7 + L + j; }
+  int LU(int j) const { return CMA1() + 7 + 2 * L + j; }
+  int RA(int j) const { return CMA1() + 7 + 3 * L + j; }
+  int RT(int j) const { return CMA1() + 7 + 4 * L + j; }
+  int RU(int j) const { return CMA1() + 7 + 5 * L + j; }
+  int D() const { return CMA1() + 7 + 6 * L; }
+  int APRIME() const { return D() + 1; }
+  int TMP(int i) const { return D() + 2 + i; }   // 8 scratch results
+  int count() const { return D() + 2 + 8; }
+  int first_proof_point() const { return SL_A; }
+  int n_proof_points() const { return 18 + 10 * L; }   // SL_A .. RU(L-1), contiguous
+};
+
+static inline S S_from_wire(const uint8_t* b) {
+  S s;
+  memcpy(s.f.v, b, 32);
+  return s;
+}
+
+Engine::Engine(int device) : device_(device) {
+  CPX_HIP(hipSetDevice(device_));
+  CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+}
+Engine::~Engine() {
+  for (auto p : idx_allocs_) (void)hipFree(p);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ---------------------------------------------------------------- timing
+void Engine::tick(const char* name, double bytes) {
+  if (!profiling_) return;
+  Timed t;
+  CPX_HIP(hipEventCreate(&t.a));
+  CPX_HIP(hipEventCreate(&t.b));
+  t.name = name;
+  t.bytes = bytes;
+  CPX_HIP(hipEventRecord(t.a, stream_));
+  pending_.push_back(t);
+}
+void Engine::tock() {
+  if (!profiling_) return;
+  CPX_HIP(hipEventRecord(pending_.back().b, stream_));
+}
+void Engine::flush_timers() {
+  if (pending_.empty()) return;
+  CPX_HIP(hipStreamSynchronize(stream_));
+  for (auto& t : pending_) {
+    float ms = 0;
+    CPX_HIP(hipEventElapsedTime(&ms, t.a, t.b));
+    KernelStat& st = stats_[t.name];
+    st.launches++;
+    st.ms += ms;
+    st.alg_bytes += t.bytes;
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  pending_.clear();
+}
+
+template <class F> void Engine::parallel_for(size_t n, F&& f) {
+  size_t T = host_threads_ > 0 ? (size_t)host_threads_ : std::min<size_t>(std::thread::hardware_concurrency(), 64);
+  T = std::max<size_t>(1, std::min(T, n));
+  if (T == 1) {
+    for (size_t i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  std::exception_ptr err;
+  std::atomic<bool> failed{false};
+  for (size_t t = 0; t < T; t++)
+    th.emplace_back([&]() {
+      try {
+        for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
+      } catch (...) {
+        if (!failed.exchange(true)) err = std::current_exception();
+      }
+    });
+  for (auto& x : th) x.join();
+  if (failed) std::rethrow_exception(err);
+}
+
+const uint32_t* Engine::idx_list(const std::vector<uint32_t>& v) {
+  auto it = idx_cache_.find(v);
+  if (it != idx_cache_.end()) return it->second;
+  uint32_t* d = nullptr;
+  CPX_HIP(hipMalloc(&d, v.size() * sizeof(uint32_t)));
+  CPX_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  idx_allocs_.push_back(d);
+  idx_cache_[v] = d;
+  return d;
+}
+
+// ---------------------------------------------------------------- generic phases
+// Uploads the scalars of all requests, runs accumulate + tails + finalize; affine results are
+// scattered to d_pp_[dst]; compressed results (48 B each, request order) returned if comp_out != null.
+void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out) {
+  const size_t nt = reqs.size();
+  if (!nt) return;
+  size_t total = 0;
+  for (auto& r : reqs) total += r.n;
+  d_scal_.ensure(total);
+  d_tasks_.ensure(nt);
+  d_wsum_.ensure(nt * 64);
+  d_part_.ensure(nt * 8);
+  d_res_.ensure(nt);
+  d_dst_.ensure(nt);
+  d_comp_.ensure(nt * 48);
+  const size_t stage_bytes = total * sizeof(Fr) + nt * sizeof(MsmTask) + nt * sizeof(uint32_t);
+  h_stage_.ensure(stage_bytes);
+  Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
+  MsmTask* ht = reinterpret_cast<MsmTask*>(h_stage_.p + total * sizeof(Fr));
+  uint32_t* hd = reinterpret_cast<uint32_t*>(h_stage_.p + total * sizeof(Fr) + nt * sizeof(MsmTask));
+  size_t off = 0;
+  double alg = 0;
+  for (size_t i = 0; i < nt; i++) {
+    const MsmReq& r = reqs[i];
+    for (uint32_t j = 0; j < r.n; j++) hs[off + j] = r.scalars[j].f;
+    ht[i] = MsmTask{r.bases, r.idx, d_scal_.p + off, r.n, 0};
+    hd[i] = r.dst;
+    off += r.n;
+    alg += 128.0 * r.n;   // 96 B affine base + 32 B scalar per MSM point
+  }
+  CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, total * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_tasks_.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_dst_.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  tick("msm", alg);
+  launch_msm(d_tasks_.p, (int)nt, d_wsum_.p, d_part_.p, d_res_.p, stream_);
+  tock();
+  tick("finalize", 0);
+  launch_finalize(d_res_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
+  tock();
+  if (comp_out) {
+    h_comp_.ensure(nt * 48);
+    CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, nt * 48, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipStreamSynchronize(stream_));
+    comp_out->assign(h_comp_.p, h_comp_.p + nt * 48);
+  }
+}
+
+// tasks[i].scalars must already point into d_scal_ (offsets in Fr units from its base are set by the caller
+// through `scalars`/`nscalars`, uploaded here).
+void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scalars, size_t nscalars, double alg_bytes) {
+  if (tasks.empty() || cnt <= 0) return;
+  d_stasks_.ensure(tasks.size());
+  h_stage_.ensure(nscalars * sizeof(Fr) + tasks.size() * sizeof(SmulTask));
+  Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
+  for (size_t i = 0; i < nscalars; i++) hs[i] = scalars[i].f;
+  SmulTask* ht = reinterpret_cast<SmulTask*>(h_stage_.p + nscalars * sizeof(Fr));
+  memcpy(ht, tasks.data(), tasks.size() * sizeof(SmulTask));
+  // the staging buffer may still be in flight from a previous async copy on this stream only if the caller
+  // did not synchronise; every phase ends with a synchronising D2H or the explicit sync below.
+  CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, nscalars * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_stasks_.p, ht, tasks.size() * sizeof(SmulTask), hipMemcpyHostToDevice, stream_));
+  tick("smul", alg_bytes);
+  launch_smul(d_stasks_.p, (int)tasks.size(), cnt, stream_);
+  tock();
+  CPX_HIP(hipStreamSynchronize(stream_));   // staging buffer reuse safety
+}
+
+// ---------------------------------------------------------------- CRS
+void Engine::set_crs(size_t ell, const uint8_t* points) {
+  const size_t n = ell + N_BLINDERS;
+  if (ell == 0 || (n & (n - 1))) throw std::invalid_argument("ell + 4 must be a power of two");
+  CPX_HIP(hipSetDevice(device_));
+  ell_ = ell;
+  n_ = n;
+  L_ = 0;
+  while ((size_t(1) << L_) < n) L_++;
+  const Aff* pts = reinterpret_cast<const Aff*>(points);
+  std::vector<Aff> crs(n + 1), gb(n);
+  for (size_t i = 0; i < n; i++) crs[i] = pts[i];   // G | Hvec
+  crs[n] = pts[n];                                  // H
+  for (size_t i = 0; i < ell + 2; i++) gb[i] = pts[i];
+  gb[ell + 2] = pts[n + 1];   // G_t
+  gb[ell + 3] = pts[n + 2];   // G_u
+  d_crs_.ensure(n + 1);
+  d_crs_gb_.ensure(n);
+  CPX_HIP(hipMemcpy(d_crs_.p, crs.data(), (n + 1) * sizeof(Aff), hipMemcpyHostToDevice));
+  CPX_HIP(hipMemcpy(d_crs_gb_.p, gb.data(), n * sizeof(Aff), hipMemcpyHostToDevice));
+  crs_single_[0] = pts[n];
+  crs_single_[1] = pts[n + 1];
+  crs_single_[2] = pts[n + 2];
+  // G_sum, H_sum (crs.rs:46-47) as unit-scalar MSMs on the device
+  B_ = 0;
+  pp_stride_ = 4 * ell_ + SlotMap(L_).count();
+  d_pp_.ensure(pp_stride_);
+  SVec ones(ell, S::one());
+  std::vector<MsmReq> reqs;
+  reqs.push_back(MsmReq{d_crs_.p, nullptr, ones.data(), (uint32_t)ell, 0});
+  reqs.push_back(MsmReq{d_crs_.p + ell, nullptr, ones.data(), (uint32_t)N_BLINDERS, 1});
+  std::vector<uint8_t> comp;
+  run_msm_phase(reqs, &comp);
+  Aff sums[2];
+  CPX_HIP(hipMemcpy(sums, d_pp_.p, 2 * sizeof(Aff), hipMemcpyDeviceToHost));
+  crs_single_[3] = sums[0];
+  crs_single_[4] = sums[1];
+  // compressed H (needed for the vec_T/vec_U blinder slots in the transcript)
+  d_comp_.ensure(48);
+  CPX_HIP(hipMemcpy(d_pp_.p, &crs_single_[0], sizeof(Aff), hipMemcpyHostToDevice));
+  launch_compress(d_pp_.p, 1, 1, 1, d_comp_.p, stream_);
+  CPX_HIP(hipMemcpyAsync(crs_H_comp_, d_comp_.p, 48, hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::crs_sums(uint8_t* g_sum, uint8_t* h_sum) const {
+  memcpy(g_sum, &crs_single_[3], sizeof(Aff));
+  memcpy(h_sum, &crs_single_[4], sizeof(Aff));
+}
+
+// ---------------------------------------------------------------- tier 0
+void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out_jac) {
+  CPX_HIP(hipSetDevice(device_));
+  DevBuf<Aff> db;
+  DevBuf<Fr> ds;
+  DevBuf<MsmTask> dt;
+  DevBuf<Jac> w, pt, res;
+  db.ensure(std::max<size_t>(n, 1));
+  ds.ensure(std::max<size_t>(n, 1));
+  dt.ensure(1);
+  w.ensure(64);
+  pt.ensure(8);
+  res.ensure(1);
+  if (n) {
+    CPX_HIP(hipMemcpyAsync(db.p, bases, n * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(ds.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  }
+  MsmTask t{db.p, nullptr, ds.p, (uint32_t)n, 0};
+  CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
+  tick("msm", 128.0 * n);
+  launch_msm(dt.p, 1, w.p, pt.p, res.p, stream_);
+  tock();
+  CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+  flush_timers();
+}
+void Engine::normalize(const uint8_t* jac, size_t n, uint8_t* out_aff, uint8_t* out_comp) {
+  CPX_HIP(hipSetDevice(device_));
+  if (!n) return;
+  DevBuf<Jac> dj;
+  DevBuf<Aff> da;
+  DevBuf<uint8_t> dc;
+  dj.ensure(n);
+  da.ensure(n);
+  dc.ensure(n * 48);
+  CPX_HIP(hipMemcpyAsync(dj.p, jac, n * sizeof(Jac), hipMemcpyHostToDevice, stream_));
+  launch_finalize(dj.p, (int)n, da.p, nullptr, dc.p, stream_);
+  if (out_aff) CPX_HIP(hipMemcpyAsync(out_aff, da.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
+  if (out_comp) CPX_HIP(hipMemcpyAsync(out_comp, dc.p, n * 48, hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::msm_jac(const uint8_t* bases_jac, const uint8_t* scalars, size_t n, uint8_t* out_jac) {
+  std::vector<uint8_t> aff(std::max<size_t>(n, 1) * sizeof(Aff));
+  normalize(bases_jac, n, aff.data(), nullptr);
+  msm(aff.data(), scalars, n, out_jac);
+}
+void Engine::fold(uint8_t* PL, const uint8_t* PR, const uint8_t* gamma, size_t half) {
+  CPX_HIP(hipSetDevice(device_));
+  if (!half) return;
+  DevBuf<Aff> dl, dr;
+  DevBuf<Fr> dg;
+  DevBuf<SmulTask> dt;
+  dl.ensure(half);
+  dr.ensure(half);
+  dg.ensure(1);
+  dt.ensure(1);
+  CPX_HIP(hipMemcpyAsync(dl.p, PL, half * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dr.p, PR, half * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dg.p, gamma, sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  SmulTask t{dl.p, dr.p, dl.p, dg.p, 0, 0};
+  CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
+  tick("smul", 288.0 * half);
+  launch_smul(dt.p, 1, (int)half, stream_);
+  tock();
+  CPX_HIP(hipMemcpyAsync(PL, dl.p, half * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+  flush_timers();
+}
+void Engine::scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_stride, size_t n, uint8_t* out) {
+  CPX_HIP(hipSetDevice(device_));
+  if (!n) return;
+  DevBuf<Aff> dp, dout;
+  DevBuf<Fr> dsc;
+  DevBuf<SmulTask> dt;
+  const size_t ns = scalar_stride ? n : 1;
+  dp.ensure(n);
+  dout.ensure(n);
+  dsc.ensure(ns);
+  dt.ensure(1);
+  CPX_HIP(hipMemcpyAsync(dp.p, P, n * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dsc.p, scalars, ns * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  SmulTask t{nullptr, dp.p, dout.p, dsc.p, scalar_stride ? 1u : 0u, 0};
+  CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
+  tick("smul", 224.0 * n);
+  launch_smul(dt.p, 1, (int)n, stream_);
+  tock();
+  CPX_HIP(hipMemcpyAsync(out, dout.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+  flush_timers();
+}
+int Engine::decompress(const uint8_t* comp, size_t n, uint8_t* out_aff, int check_subgroup) {
+  CPX_HIP(hipSetDevice(device_));
+  if (!n) return CPX_OK;
+  DevBuf<uint8_t> dc, dst;
+  DevBuf<Aff> da;
+  dc.ensure(n * 48);
+  dst.ensure(n);
+  da.ensure(n);
+  CPX_HIP(hipMemcpyAsync(dc.p, comp, n * 48, hipMemcpyHostToDevice, stream_));
+  launch_decompress(dc.p, (int)n, da.p, nullptr, dst.p, check_subgroup, stream_);
+  std::vector<uint8_t> st(n);
+  CPX_HIP(hipMemcpyAsync(out_aff, da.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipMemcpyAsync(st.data(), dst.p, n, hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+  for (auto s : st)
+    if (s) return CPX_ERR_DESERIALIZE;
+  return CPX_OK;
+}
+
+double Engine::bench_fpmul(int blocks, int iters, int reps) {
+  CPX_HIP(hipSetDevice(device_));
+  const size_t nth = (size_t)blocks * 256;
+  DevBuf<Fp> d;
+  d.ensure(2 * nth);
+  std::vector<Fp> h(2 * nth);
+  for (size_t i = 0; i < 2 * nth; i++) {
+    h[i] = Fp::one();
+    h[i].v[0] ^= (uint32_t)(i * 2654435761u);
+    h[i].v[5] ^= (uint32_t)(i * 40503u);
+    h[i].v[11] &= 0x0fffffffu;
+  }
+  CPX_HIP(hipMemcpy(d.p, h.data(), 2 * nth * sizeof(Fp), hipMemcpyHostToDevice));
+  hipEvent_t a, b;
+  CPX_HIP(hipEventCreate(&a));
+  CPX_HIP(hipEventCreate(&b));
+  launch_bench_fpmul(d.p, blocks, iters, stream_);   // warm-up
+  CPX_HIP(hipEventRecord(a, stream_));
+  for (int r = 0; r < reps; r++) launch_bench_fpmul(d.p, blocks, iters, stream_);
+  CPX_HIP(hipEventRecord(b, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+  float ms = 0;
+  CPX_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return (double)nth * 2.0 * iters * reps / (ms * 1e-3);
+}
+
+// ---------------------------------------------------------------- batch load
+void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M) {
+  if (!ell_) throw std::logic_error("set_crs first");
+  CPX_HIP(hipSetDevice(device_));
+  const SlotMap sm(L_);
+  pp_stride_ = 4 * ell_ + sm.count();
+  d_pp_.ensure(batch * pp_stride_);
+  d_Mjac_.ensure(batch);
+  for (DevBuf<Aff>* w : {&d_wGi_, &d_wGp_, &d_wGm_, &d_wT_, &d_wU_}) w->ensure(batch * (n_ + 1));
+  B_ = batch;
+  const size_t vb = ell_ * sizeof(Aff);
+  for (size_t p = 0; p < batch; p++) {
+    CPX_HIP(hipMemcpyAsync(pp(p), vec_R + p * vb, vb, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(pp(p) + ell_, vec_S + p * vb, vb, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(pp(p) + 2 * ell_, vec_T + p * vb, vb, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(pp(p) + 3 * ell_, vec_U + p * vb, vb, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(slot(p, SL_H), crs_single_, 5 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+  }
+  CPX_HIP(hipMemcpyAsync(d_Mjac_.p, M, batch * sizeof(Jac), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---------------------------------------------------------------- prover
+namespace {
+struct ProverState {
+  Transcript tr{"curdleproofs"};
+  SVec vec_a, a_perm, x;            // x: SameMSM witness vector
+  SVec c, d;                        // IPA vectors
+  SVec factors;
+  S alpha_sp, beta_sp, gprod, alpha_g, beta_g, beta_g_inv, r_p, z_ip, alpha_i, beta_i, alpha_m;
+  SVec vec_c_blinders, rb_plus_alpha, u;
+  SVec scal[8];                     // scalar vectors handed to the device for the current phase
+  S gam[2];
+  std::vector<uint8_t> comp;        // compressed bytes of every slot (count * 48)
+  S r_p_out, c_final, d_final, z_k, z_t, z_u, x_final;
+  const uint8_t* rnd;               // 3n+9 Fr draws, wire form
+  S draw(size_t i) const { return S_from_wire(rnd + 32 * i); }
+};
+}  // namespace
+
+void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
+  if (!B_) throw std::logic_error("batch_load first");
+  CPX_HIP(hipSetDevice(device_));
+  const size_t B = B_, ell = ell_, n = n_, L = L_;
+  const SlotMap sm(L);
+  const size_t nrand = 3 * n + 9;
+  const int NS = sm.count();
+  std::vector<ProverState> st(B);
+  std::vector<uint8_t> comp;
+
+  // draw indices: a_blinders 0-1, c_blinders 2-5, ipa r 6.., ipa z 6+n.., r_t, r_u, r_a, r_b, r_k, vec_r
+  const size_t I_AB = 0, I_CB = 2, I_IR = 6, I_IZ = 6 + n, I_RT = 2 * n + 4, I_RU = 2 * n + 5, I_RA = 2 * n + 6, I_RB = 2 * n + 7,
+               I_RK = 2 * n + 8, I_VR = 2 * n + 9;
+
+  // -- reset the folding work vectors (device-to-device)
+  {
+    std::vector<Aff> tail_T(4, Aff::identity()), tail_U(4, Aff::identity());
+    tail_T[2] = crs_single_[0];
+    tail_U[3] = crs_single_[0];
+    DevBuf<Aff> d_tail;
+    d_tail.ensure(8);
+    CPX_HIP(hipMemcpyAsync(d_tail.p, tail_T.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_tail.p + 4, tail_U.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+    for (size_t p = 0; p < B; p++) {
+      CPX_HIP(hipMemcpyAsync(d_wGi_.p + p * (n + 1), d_crs_.p, (n + 1) * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(d_wGm_.p + p * (n + 1), d_crs_gb_.p, n * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(d_wT_.p + p * (n + 1), pp(p) + 2 * ell, ell * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(d_wT_.p + p * (n + 1) + ell, d_tail.p, 4 * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(d_wU_.p + p * (n + 1), pp(p) + 3 * ell, ell * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(d_wU_.p + p * (n + 1) + ell, d_tail.p + 4, 4 * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
+    }
+    CPX_HIP(hipStreamSynchronize(stream_));   // d_tail goes out of scope
+  }
+
+  // -- P0: compressed instance vectors + M for the transcript (curdleproofs.rs:81-82)
+  std::vector<uint8_t> inst_comp(B * 4 * ell * 48);
+  {
+    d_bytes_.ensure(B * 4 * ell * 48);
+    tick("compress", 0);
+    launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
+    tock();
+    d_res_.ensure(B);
+    d_dst_.ensure(B);
+    d_comp_.ensure(B * 48);
+    std::vector<uint32_t> dst(B);
+    for (size_t p = 0; p < B; p++) dst[p] = slot_index(p, SL_M);
+    CPX_HIP(hipMemcpyAsync(d_dst_.p, dst.data(), B * 4, hipMemcpyHostToDevice, stream_));
+    launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
+    std::vector<uint8_t> mcomp(B * 48);
+    CPX_HIP(hipMemcpyAsync(inst_comp.data(), d_bytes_.p, inst_comp.size(), hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(mcomp.data(), d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipStreamSynchronize(stream_));
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      s.rnd = rand + p * nrand * 32;
+      s.comp.assign((size_t)NS * 48, 0);
+      memcpy(&s.comp[SL_M * 48], &mcomp[p * 48], 48);
+      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
+      for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
+      s.tr.append_point_bytes("curdleproofs_step1", &s.comp[SL_M * 48]);
+      s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
+      const uint32_t* perm = permutation + p * ell;
+      s.a_perm.resize(ell);
+      for (size_t i = 0; i < ell; i++) s.a_perm[i] = s.vec_a[perm[i]];
+      // scalars of phase 1
+      s.scal[0] = s.a_perm;                                                   // A over G | Hvec
+      s.scal[0].push_back(s.draw(I_AB));
+      s.scal[0].push_back(s.draw(I_AB + 1));
+      s.scal[0].push_back(S::zero());
+      s.scal[0].push_back(S::zero());
+      s.scal[1].resize(n);                                                    // vec_r of SameMSM
+      for (size_t i = 0; i < n; i++) s.scal[1][i] = s.draw(I_VR + i);
+      s.scal[2] = {s.draw(I_RT), s.draw(I_RU), s.draw(I_RA), s.draw(I_RB)};
+    });
+  }
+
+  auto take = [&](size_t p, int slot_id, size_t req_index) { memcpy(&st[p].comp[(size_t)slot_id * 48], &comp[req_index * 48], 48); };
+  const uint32_t* idx_gt = idx_list({(uint32_t)SL_GT});
+  const uint32_t* idx_gu = idx_list({(uint32_t)SL_GU});
+
+  // -- P1: A, R, S, B_a, B_t, B_u and the four r*G commitments halves
+  {
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      reqs.push_back({d_crs_.p, nullptr, s.scal[0].data(), (uint32_t)n, slot_index(p, SL_A)});
+      reqs.push_back({pp(p), nullptr, s.vec_a.data(), (uint32_t)ell, slot_index(p, SL_R)});
+      reqs.push_back({pp(p) + ell, nullptr, s.vec_a.data(), (uint32_t)ell, slot_index(p, SL_S)});
+      reqs.push_back({d_wGm_.p + p * (n + 1), nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, sm.BA())});
+      reqs.push_back({d_wT_.p + p * (n + 1), nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, sm.BT())});
+      reqs.push_back({d_wU_.p + p * (n + 1), nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, sm.BU())});
+      reqs.push_back({slot(p, 0), idx_gt, &s.scal[2][0], 1, slot_index(p, SL_CMT1)});
+      reqs.push_back({slot(p, 0), idx_gu, &s.scal[2][1], 1, slot_index(p, SL_CMU1)});
+      reqs.push_back({slot(p, 0), idx_gt, &s.scal[2][2], 1, slot_index(p, sm.CMA1())});
+      reqs.push_back({slot(p, 0), idx_gu, &s.scal[2][3], 1, slot_index(p, sm.CMB1())});
+    }
+    run_msm_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const int ids[10] = {SL_A, SL_R, SL_S, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1()};
+      for (int i = 0; i < 10; i++) take(p, ids[i], p * 10 + i);
+      // same_permutation_argument.rs:60-83
+      s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_A * 48]);
+      s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_M * 48]);
+      s.tr.append_scalar_vec("same_perm_step1", s.vec_a);
+      s.alpha_sp = s.tr.get_and_append_challenge("same_perm_alpha");
+      s.beta_sp = s.tr.get_and_append_challenge("same_perm_beta");
+      const uint32_t* perm = permutation + p * ell;
+      s.factors.resize(ell);
+      s.gprod = S::one();
+      for (size_t i = 0; i < ell; i++) {
+        s.factors[i] = s.a_perm[i] + S::from_u64(perm[i]) * s.alpha_sp + s.beta_sp;
+        s.gprod *= s.factors[i];
+      }
+      const S kk = S_from_wire(k_in + 32 * p), r_t = s.draw(I_RT), r_u = s.draw(I_RU), r_a = s.draw(I_RA), r_b = s.draw(I_RB), r_k = s.draw(I_RK);
+      s.scal[0] = {S::one(), s.alpha_sp, s.beta_sp};   // B = A + alpha M + beta G_sum  (= msm(G, [beta; ell]), crs.rs:31)
+      s.scal[1] = {kk, r_t};                           // cm_T.T_2 = k R + r_t H     (curdleproofs.rs:115)
+      s.scal[2] = {kk, r_u};                           // cm_U.T_2
+      s.scal[3] = {r_k, r_a};                          // cm_A.T_2                   (same_scalar_argument.rs:60)
+      s.scal[4] = {r_k, r_b};                          // cm_B.T_2
+      s.scal[5] = {S::one(), S::one(), S::one()};      // A' = A + cm_T.T_1 + cm_U.T_1 (curdleproofs.rs:134)
+    });
+  }
+
+  // -- P2: B, the T_2 halves, A'
+  {
+    const uint32_t* iB = idx_list({(uint32_t)SL_A, (uint32_t)SL_M, (uint32_t)SL_GSUM});
+    const uint32_t* iRH = idx_list({(uint32_t)SL_R, (uint32_t)SL_H});
+    const uint32_t* iSH = idx_list({(uint32_t)SL_S, (uint32_t)SL_H});
+    const uint32_t* iAp = idx_list({(uint32_t)SL_A, (uint32_t)SL_CMT1, (uint32_t)SL_CMU1});
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      reqs.push_back({slot(p, 0), iB, s.scal[0].data(), 3, slot_index(p, SL_B)});
+      reqs.push_back({slot(p, 0), iRH, s.scal[1].data(), 2, slot_index(p, SL_CMT2)});
+      reqs.push_back({slot(p, 0), iSH, s.scal[2].data(), 2, slot_index(p, SL_CMU2)});
+      reqs.push_back({slot(p, 0), iRH, s.scal[3].data(), 2, slot_index(p, sm.CMA2())});
+      reqs.push_back({slot(p, 0), iSH, s.scal[4].data(), 2, slot_index(p, sm.CMB2())});
+      reqs.push_back({slot(p, 0), iAp, s.scal[5].data(), 3, slot_index(p, sm.APRIME())});
+    }
+    run_msm_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const int ids[6] = {SL_B, SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2(), sm.APRIME()};
+      for (int i = 0; i < 6; i++) take(p, ids[i], p * 6 + i);
+      // grand_product_argument.rs:63-76
+      s.tr.append_point_bytes("gprod_step1", &s.comp[SL_B * 48]);
+      s.tr.append_scalar("gprod_step1", s.gprod);
+      s.alpha_g = s.tr.get_and_append_challenge("gprod_alpha");
+      s.c.assign(1, S::one());
+      for (size_t i = 0; i + 1 < ell; i++) s.c.push_back(s.c[i] * s.factors[i]);
+      s.vec_c_blinders.resize(N_BLINDERS);
+      for (size_t i = 0; i < N_BLINDERS; i++) s.vec_c_blinders[i] = s.draw(I_CB + i);
+      s.scal[0] = s.c;
+      s.scal[0].insert(s.scal[0].end(), s.vec_c_blinders.begin(), s.vec_c_blinders.end());
+    });
+  }
+
+  // -- P3: C
+  {
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) reqs.push_back({d_crs_.p, nullptr, st[p].scal[0].data(), (uint32_t)n, slot_index(p, SL_C)});
+    run_msm_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      take(p, SL_C, p);
+      // grand_product_argument.rs:78-148
+      const S mb[4] = {S_from_wire(m_blinders + (p * 4 + 0) * 32), S_from_wire(m_blinders + (p * 4 + 1) * 32),
+                       S_from_wire(m_blinders + (p * 4 + 2) * 32), S_from_wire(m_blinders + (p * 4 + 3) * 32)};
+      const S ab[4] = {s.draw(I_AB), s.draw(I_AB + 1), S::zero(), S::zero()};
+      s.rb_plus_alpha.resize(N_BLINDERS);
+      for (size_t i = 0; i < N_BLINDERS; i++) s.rb_plus_alpha[i] = (ab[i] + s.alpha_sp * mb[i]) + s.alpha_g;   // vec_b_blinders + alpha
+      s.r_p = host::inner_product(s.rb_plus_alpha.data(), s.vec_c_blinders.data(), N_BLINDERS);
+      s.tr.append_point_bytes("gprod_step2", &s.comp[SL_C * 48]);
+      s.tr.append_scalar("gprod_step2", s.r_p);
+      s.beta_g = s.tr.get_and_append_challenge("gprod_beta");
+      s.beta_g_inv = s.beta_g.inverse();
+      // u_i = beta^-(i+1) (i < ell), beta^-(ell+1) for the blinder bases: G'_i = u_i G_i
+      s.u.resize(n);
+      S pw = s.beta_g_inv;
+      for (size_t i = 0; i < ell; i++) {
+        s.u[i] = pw;
+        pw *= s.beta_g_inv;
+      }
+      for (size_t i = ell; i < n; i++) s.u[i] = pw;   // pw = beta^-(ell+1)
+      // d = b' - beta powers ; b'_i = b_i beta^(i+1)
+      s.d.resize(n);
+      S pb = s.beta_g, pbm = S::one();
+      for (size_t i = 0; i < ell; i++) {
+        s.d[i] = s.factors[i] * pb - pbm;
+        pbm = pb;
+        pb *= s.beta_g;
+      }
+      const S beta_l1 = pbm * s.beta_g;   // pbm = beta^ell after the loop
+      const S beta_l = pbm;
+      for (size_t i = 0; i < N_BLINDERS; i++) s.d[ell + i] = beta_l1 * s.rb_plus_alpha[i];
+      s.c.insert(s.c.end(), s.vec_c_blinders.begin(), s.vec_c_blinders.end());
+      s.z_ip = s.r_p * beta_l1 + s.gprod * beta_l - S::one();
+      // D = B - beta^-1 G_sum + alpha H_sum (grand_product_argument.rs:132 == :223)
+      s.scal[0] = {S::one(), -s.beta_g_inv, s.alpha_g};
+      // generate_ipa_blinders (inner_product_argument.rs:42-82)
+      SVec r(n), zz(n);
+      for (size_t i = 0; i < n; i++) r[i] = s.draw(I_IR + i);
+      for (size_t i = 0; i + 2 < n; i++) zz[i] = s.draw(I_IZ + i);
+      const S omega = host::inner_product(r.data(), s.d.data(), n) + host::inner_product(zz.data(), s.c.data(), n - 2);
+      const S delta = host::inner_product(r.data(), zz.data(), n - 2);
+      const S inv_c = s.c[n - 2].inverse();
+      const S last_z = (r[n - 2] * inv_c * omega - delta) * ((-r[n - 2]) * inv_c * s.c[n - 1] + r[n - 1]).inverse();
+      const S pen_z = (-inv_c) * (last_z * s.c[n - 1] + omega);
+      zz[n - 2] = pen_z;
+      zz[n - 1] = last_z;
+      s.scal[1] = r;    // r_c  -> B_c over G
+      s.scal[2] = zz;   // r_d  -> B_d over G'
+    });
+  }
+
+  // -- P4: D, G' = u o G, B_c, B_d
+  {
+    // rescaled basis (grand_product_argument.rs:90-102)
+    std::vector<SmulTask> tasks;
+    SVec us(B * n);
+    d_scal_.ensure(std::max<size_t>(B * n, 1));
+    for (size_t p = 0; p < B; p++) {
+      for (size_t i = 0; i < n; i++) us[p * n + i] = st[p].u[i];
+      tasks.push_back(SmulTask{nullptr, d_crs_.p, d_wGp_.p + p * (n + 1), d_scal_.p + p * n, 1, 0});
+    }
+    run_smul(tasks, (int)n, us.data(), us.size(), 224.0 * n * B);
+    const uint32_t* iD = idx_list({(uint32_t)SL_B, (uint32_t)SL_GSUM, (uint32_t)SL_HSUM});
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      reqs.push_back({slot(p, 0), iD, s.scal[0].data(), 3, slot_index(p, sm.D())});
+      reqs.push_back({d_crs_.p, nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, SL_BC)});
+      reqs.push_back({d_wGp_.p + p * (n + 1), nullptr, s.scal[2].data(), (uint32_t)n, slot_index(p, SL_BD)});
+    }
+    run_msm_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      take(p, sm.D(), p * 3);
+      take(p, SL_BC, p * 3 + 1);
+      take(p, SL_BD, p * 3 + 2);
+      // inner_product_argument.rs:129-139
+      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_C * 48]);
+      s.tr.append_point_bytes("ipa_step1", &s.comp[sm.D() * 48]);
+      s.tr.append_scalar("ipa_step1", s.z_ip);
+      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_BC * 48]);
+      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_BD * 48]);
+      s.alpha_i = s.tr.get_and_append_challenge("ipa_alpha");
+      s.beta_i = s.tr.get_and_append_challenge("ipa_beta");
+      for (size_t i = 0; i < n; i++) {
+        s.c[i] = s.scal[1][i] + s.alpha_i * s.c[i];
+        s.d[i] = s.scal[2][i] + s.alpha_i * s.d[i];
+      }
+    });
+  }
+
+  // -- P5: IPA rounds (inner_product_argument.rs:150-186)
+  for (size_t j = 0; j < L; j++) {
+    const size_t half = n >> (j + 1);
+    std::vector<uint32_t> il(half + 1), ir(half + 1);
+    for (size_t i = 0; i < half; i++) {
+      il[i] = (uint32_t)(half + i);   // G_R
+      ir[i] = (uint32_t)i;            // G_L
+    }
+    il[half] = ir[half] = (uint32_t)n;   // H rides along as one more base: H^(beta <c,d>)
+    const uint32_t* d_il = idx_list(il);
+    const uint32_t* d_ir = idx_list(ir);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const S* cL = s.c.data();
+      const S* cR = cL + half;
+      const S* dL = s.d.data();
+      const S* dR = dL + half;
+      s.scal[0].assign(cL, cL + half);
+      s.scal[0].push_back(s.beta_i * host::inner_product(cL, dR, half));   // L_C
+      s.scal[1].assign(dR, dR + half);                                     // L_D over G'_L
+      s.scal[2].assign(cR, cR + half);
+      s.scal[2].push_back(s.beta_i * host::inner_product(cR, dL, half));   // R_C
+      s.scal[3].assign(dL, dL + half);                                     // R_D over G'_R
+    });
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      Aff* Gi = d_wGi_.p + p * (n + 1);
+      Aff* Gp = d_wGp_.p + p * (n + 1);
+      reqs.push_back({Gi, d_il, s.scal[0].data(), (uint32_t)half + 1, slot_index(p, sm.LC((int)j))});
+      reqs.push_back({Gp, nullptr, s.scal[1].data(), (uint32_t)half, slot_index(p, sm.LD((int)j))});
+      reqs.push_back({Gi, d_ir, s.scal[2].data(), (uint32_t)half + 1, slot_index(p, sm.RC((int)j))});
+      reqs.push_back({Gp + half, nullptr, s.scal[3].data(), (uint32_t)half, slot_index(p, sm.RD((int)j))});
+    }
+    run_msm_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      take(p, sm.LC((int)j), p * 4);
+      take(p, sm.LD((int)j), p * 4 + 1);
+      take(p, sm.RC((int)j), p * 4 + 2);
+      take(p, sm.RD((int)j), p * 4 + 3);
+      const int order[4] = {sm.LC((int)j), sm.LD((int)j), sm.RC((int)j), sm.RD((int)j)};
+      for (int q : order) s.tr.append_point_bytes("ipa_loop", &s.comp[(size_t)q * 48]);
+      const S gamma = s.tr.get_and_append_challenge("ipa_gamma");
+      const S gamma_inv = gamma.inverse();
+      for (size_t i = 0; i < half; i++) {
+        s.c[i] += gamma_inv * s.c[half + i];
+        s.d[i] += gamma * s.d[half + i];
+      }
+      s.gam[0] = gamma;
+      s.gam[1] = gamma_inv;
+    });
+    {
+      // fold the two bases; the reference also folds after the last round (inner_product_argument.rs:174-179)
+      // but nothing reads that output, so it is skipped here
+      if (j + 1 < L) {
+        std::vector<SmulTask> tasks;
+        SVec gs(2 * B);
+        d_scal_.ensure(2 * B);
+        for (size_t p = 0; p < B; p++) {
+          gs[2 * p] = st[p].gam[0];
+          gs[2 * p + 1] = st[p].gam[1];
+          Aff* Gi = d_wGi_.p + p * (n + 1);
+          Aff* Gp = d_wGp_.p + p * (n + 1);
+          tasks.push_back(SmulTask{Gi, Gi + half, Gi, d_scal_.p + 2 * p, 0, 0});
+          tasks.push_back(SmulTask{Gp, Gp + half, Gp, d_scal_.p + 2 * p + 1, 0, 0});
+        }
+        run_smul(tasks, (int)half, gs.data(), gs.size(), 288.0 * half * 2 * B);
+      }
+    }
+  }
+
+  // -- P6 (host only): SameScalar transcript, SameMSM step 1
+  {
+    const std::vector<uint8_t> id_comp = [] {
+      std::vector<uint8_t> v(48, 0);
+      v[0] = 0xc0;
+      return v;
+    }();
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      s.c_final = s.c[0];
+      s.d_final = s.d[0];
+      // same_scalar_argument.rs:63-84
+      const int pts[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
+      for (int q : pts) s.tr.append_point_bytes("sameexp_points", &s.comp[(size_t)q * 48]);
+      const S alpha = s.tr.get_and_append_challenge("same_scalar_alpha");
+      const S kk = S_from_wire(k_in + 32 * p);
+      s.z_k = s.draw(I_RK) + kk * alpha;
+      s.z_t = s.draw(I_RA) + s.draw(I_RT) * alpha;
+      s.z_u = s.draw(I_RB) + s.draw(I_RU) * alpha;
+      // same_multiscalar_argument.rs:84-91
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.APRIME() * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[SL_CMT2 * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[SL_CMU2 * 48]);
+      std::vector<uint8_t> vb(n * 48);
+      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
+      memcpy(vb.data(), ic + 2 * ell * 48, ell * 48);   // vec_T || O O H O
+      const uint8_t* tailT[4] = {id_comp.data(), id_comp.data(), crs_H_comp_, id_comp.data()};
+      for (int i = 0; i < 4; i++) memcpy(&vb[(ell + i) * 48], tailT[i], 48);
+      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
+      memcpy(vb.data(), ic + 3 * ell * 48, ell * 48);   // vec_U || O O O H
+      const uint8_t* tailU[4] = {id_comp.data(), id_comp.data(), id_comp.data(), crs_H_comp_};
+      for (int i = 0; i < 4; i++) memcpy(&vb[(ell + i) * 48], tailU[i], 48);
+      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BA() * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BT() * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BU() * 48]);
+      s.alpha_m = s.tr.get_and_append_challenge("same_msm_alpha");
+      // x = vec_r + alpha * (sigma(a) | a_blinders | r_t | r_u)   (curdleproofs.rs:157-160)
+      s.x.resize(n);
+      for (size_t i = 0; i < ell; i++) s.x[i] = s.draw(I_VR + i) + s.alpha_m * s.a_perm[i];
+      s.x[ell] = s.draw(I_VR + ell) + s.alpha_m * s.draw(I_AB);
+      s.x[ell + 1] = s.draw(I_VR + ell + 1) + s.alpha_m * s.draw(I_AB + 1);
+      s.x[ell + 2] = s.draw(I_VR + ell + 2) + s.alpha_m * s.draw(I_RT);
+      s.x[ell + 3] = s.draw(I_VR + ell + 3) + s.alpha_m * s.draw(I_RU);
+    });
+  }
+
+  // -- P7: SameMSM rounds (same_multiscalar_argument.rs:99-136)
+  for (size_t j = 0; j < L; j++) {
+    const size_t half = n >> (j + 1);
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      const S* xL = s.x.data();
+      const S* xR = xL + half;
+      Aff* G = d_wGm_.p + p * (n + 1);
+      Aff* T = d_wT_.p + p * (n + 1);
+      Aff* U = d_wU_.p + p * (n + 1);
+      reqs.push_back({G + half, nullptr, xL, (uint32_t)half, slot_index(p, sm.LA((int)j))});
+      reqs.push_back({T + half, nullptr, xL, (uint32_t)half, slot_index(p, sm.LT((int)j))});
+      reqs.push_back({U + half, nullptr, xL, (uint32_t)half, slot_index(p, sm.LU((int)j))});
+      reqs.push_back({G, nullptr, xR, (uint32_t)half, slot_index(p, sm.RA((int)j))});
+      reqs.push_back({T, nullptr, xR, (uint32_t)half, slot_index(p, sm.RT((int)j))});
+      reqs.push_back({U, nullptr, xR, (uint32_t)half, slot_index(p, sm.RU((int)j))});
+    }
+    run_msm_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const int order[6] = {sm.LA((int)j), sm.LT((int)j), sm.LU((int)j), sm.RA((int)j), sm.RT((int)j), sm.RU((int)j)};
+      for (int i = 0; i < 6; i++) take(p, order[i], p * 6 + i);
+      for (int q : order) s.tr.append_point_bytes("same_msm_loop", &s.comp[(size_t)q * 48]);
+      const S gamma = s.tr.get_and_append_challenge("same_msm_gamma");
+      const S gamma_inv = gamma.inverse();
+      for (size_t i = 0; i < half; i++) s.x[i] += gamma_inv * s.x[half + i];
+      s.gam[0] = gamma;
+    });
+    if (j + 1 < L) {
+      std::vector<SmulTask> tasks;
+      SVec gs(B);
+      d_scal_.ensure(B);
+      for (size_t p = 0; p < B; p++) {
+        gs[p] = st[p].gam[0];
+        for (DevBuf<Aff>* w : {&d_wGm_, &d_wT_, &d_wU_}) {
+          Aff* V = w->p + p * (n + 1);
+          tasks.push_back(SmulTask{V, V + half, V, d_scal_.p + p, 0, 0});
+        }
+      }
+      run_smul(tasks, (int)half, gs.data(), gs.size(), 288.0 * half * 3 * B);
+    }
+  }
+
+  // -- serialise (curdleproofs.rs:300-310 and the nested serialisers)
+  const size_t psz = proof_size();
+  parallel_for(B, [&](size_t p) {
+    ProverState& s = st[p];
+    uint8_t* o = proofs_out + p * psz;
+    auto pt = [&](int slot_id) {
+      memcpy(o, &s.comp[(size_t)slot_id * 48], 48);
+      o += 48;
+    };
+    auto sc = [&](const S& x) {
+      x.to_le_bytes(o);
+      o += 32;
+    };
+    for (int q = SL_A; q <= SL_C; q++) pt(q);   // A, cm_T, cm_U, R, S, B, C
+    sc(s.r_p);
+    pt(SL_BC);
+    pt(SL_BD);
+    for (int q = SL_IPA0; q < SL_IPA0 + 4 * (int)L; q++) pt(q);
+    sc(s.c_final);
+    sc(s.d_final);
+    for (int q = sm.CMA1(); q <= sm.CMB2(); q++) pt(q);
+    sc(s.z_k);
+    sc(s.z_t);
+    sc(s.z_u);
+    for (int q = sm.BA(); q < sm.BA() + 3 + 6 * (int)L; q++) pt(q);
+    sc(s.x[0]);
+  });
+  flush_timers();
+}
+
+// ---------------------------------------------------------------- verifier
+void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdict) {
+  if (!B_) throw std::logic_error("batch_load first");
+  CPX_HIP(hipSetDevice(device_));
+  const size_t B = B_, ell = ell_, n = n_, L = L_;
+  const SlotMap sm(L);
+  const size_t psz = proof_size();
+  const int NPP = sm.n_proof_points();
+
+  struct VState {
+    Transcript tr{"curdleproofs"};
+    bool bad = false;           // deserialisation failure
+    bool reject = false;        // structural rejection
+    S r_p, c_fin, d_fin, z_k, z_t, z_u, x_fin;
+    SVec vec_a;
+    S alpha_sp, beta_sp, gprod, alpha_g, beta_g, beta_g_inv, z_ip, alpha_i, beta_i, alpha_s, alpha_m;
+    SVec gam_i, gam_i_inv, gam_m, gam_m_inv;
+    const uint8_t* pb;          // proof bytes
+    SVec scal[8];
+  };
+  std::vector<VState> st(B);
+
+  // byte offset of each proof point (slot order == serialisation order, scalars interleaved)
+  std::vector<size_t> pt_off(NPP);
+  size_t off_rp, off_c, off_d, off_zk, off_x;
+  {
+    size_t o = 0;
+    int q = 0;
+    auto P = [&](int cnt) {
+      for (int i = 0; i < cnt; i++) {
+        pt_off[q++] = o;
+        o += 48;
+      }
+    };
+    P(9);            // A cmT1 cmT2 cmU1 cmU2 R S B C
+    off_rp = o;
+    o += 32;
+    P(2 + 4 * (int)L);
+    off_c = o;
+    o += 32;
+    off_d = o;
+    o += 32;
+    P(4);
+    off_zk = o;
+    o += 96;
+    P(3 + 6 * (int)L);
+    off_x = o;
+    o += 32;
+    if (o != psz || q != NPP) throw std::logic_error("proof layout");
+  }
+
+  // -- V0: decompress proof points into their slots; M -> affine; compressed instance vectors
+  std::vector<uint8_t> inst_comp(B * 4 * ell * 48), mcomp(B * 48);
+  {
+    std::vector<uint8_t> pts((size_t)B * NPP * 48);
+    std::vector<uint32_t> dst((size_t)B * NPP);
+    for (size_t p = 0; p < B; p++)
+      for (int q = 0; q < NPP; q++) {
+        memcpy(&pts[(p * NPP + q) * 48], proofs + p * psz + pt_off[q], 48);
+        dst[p * NPP + q] = slot_index(p, SL_A + q);
+      }
+    DevBuf<uint8_t> d_in;
+    DevBuf<uint32_t> d_dst;
+    d_in.ensure(pts.size());
+    d_dst.ensure(dst.size());
+    d_status_.ensure(dst.size());
+    CPX_HIP(hipMemcpyAsync(d_in.p, pts.data(), pts.size(), hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_dst.p, dst.data(), dst.size() * 4, hipMemcpyHostToDevice, stream_));
+    tick("decompress", 0);
+    launch_decompress(d_in.p, (int)dst.size(), d_pp_.p, d_dst.p, d_status_.p, 1, stream_);
+    tock();
+    d_bytes_.ensure(B * 4 * ell * 48);
+    tick("compress", 0);
+    launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
+    tock();
+    d_dst_.ensure(B);
+    d_comp_.ensure(B * 48);
+    std::vector<uint32_t> mdst(B);
+    for (size_t p = 0; p < B; p++) mdst[p] = slot_index(p, SL_M);
+    CPX_HIP(hipMemcpyAsync(d_dst_.p, mdst.data(), B * 4, hipMemcpyHostToDevice, stream_));
+    launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
+    std::vector<uint8_t> status(dst.size());
+    CPX_HIP(hipMemcpyAsync(status.data(), d_status_.p, status.size(), hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(inst_comp.data(), d_bytes_.p, inst_comp.size(), hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(mcomp.data(), d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipStreamSynchronize(stream_));
+    for (size_t p = 0; p < B; p++)
+      for (int q = 0; q < NPP; q++)
+        if (status[p * NPP + q]) st[p].bad = true;
+  }
+
+  const uint8_t ID0 = 0xc0;
+  std::vector<uint8_t> comp;
+
+  // -- V1a: transcript up to the grand-product beta
+  parallel_for(B, [&](size_t p) {
+    VState& s = st[p];
+    s.pb = proofs + p * psz;
+    const uint8_t* pb = s.pb;
+    auto P = [&](int slot_id) { return pb + pt_off[slot_id - SL_A]; };
+    if (!S::from_le_bytes(pb + off_rp, &s.r_p) || !S::from_le_bytes(pb + off_c, &s.c_fin) || !S::from_le_bytes(pb + off_d, &s.d_fin) ||
+        !S::from_le_bytes(pb + off_zk, &s.z_k) || !S::from_le_bytes(pb + off_zk + 32, &s.z_t) || !S::from_le_bytes(pb + off_zk + 64, &s.z_u) ||
+        !S::from_le_bytes(pb + off_x, &s.x_fin))
+      s.bad = true;
+    const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
+    // curdleproofs.rs:218: the randomiser must not have wiped the ciphertexts
+    if (ic[2 * ell * 48] == ID0) s.reject = true;
+    for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
+    s.tr.append_point_bytes("curdleproofs_step1", &mcomp[p * 48]);
+    s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
+    // same_permutation_argument.rs:131-145
+    s.tr.append_point_bytes("same_perm_step1", P(SL_A));
+    s.tr.append_point_bytes("same_perm_step1", &mcomp[p * 48]);
+    s.tr.append_scalar_vec("same_perm_step1", s.vec_a);
+    s.alpha_sp = s.tr.get_and_append_challenge("same_perm_alpha");
+    s.beta_sp = s.tr.get_and_append_challenge("same_perm_beta");
+    s.gprod = S::one();
+    for (size_t i = 0; i < ell; i++) s.gprod *= s.vec_a[i] + S::from_u64(i) * s.alpha_sp + s.beta_sp;
+    // grand_product_argument.rs:200-209
+    s.tr.append_point_bytes("gprod_step1", P(SL_B));
+    s.tr.append_scalar("gprod_step1", s.gprod);
+    s.alpha_g = s.tr.get_and_append_challenge("gprod_alpha");
+    s.tr.append_point_bytes("gprod_step2", P(SL_C));
+    s.tr.append_scalar("gprod_step2", s.r_p);
+    s.beta_g = s.tr.get_and_append_challenge("gprod_beta");
+    s.beta_g_inv = s.beta_g.inverse();
+    s.scal[0] = {S::one(), -s.beta_g_inv, s.alpha_g};    // D  (grand_product_argument.rs:223)
+    s.scal[1] = {S::one(), S::one(), S::one()};          // A' (curdleproofs.rs:258)
+  });
+
+  // -- V1b: D and A' are hashed into the transcript, so they are needed as bytes
+  {
+    const uint32_t* iD = idx_list({(uint32_t)SL_B, (uint32_t)SL_GSUM, (uint32_t)SL_HSUM});
+    const uint32_t* iAp = idx_list({(uint32_t)SL_A, (uint32_t)SL_CMT1, (uint32_t)SL_CMU1});
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      reqs.push_back({slot(p, 0), iD, st[p].scal[0].data(), 3, slot_index(p, sm.D())});
+      reqs.push_back({slot(p, 0), iAp, st[p].scal[1].data(), 3, slot_index(p, sm.APRIME())});
+    }
+    run_msm_phase(reqs, &comp);
+  }
+
+  // -- V1c: rest of the transcript and the scalars of the accumulated check
+  // slot-relative gather list of the "misc" MSM: CRS singles, M, every proof point
+  std::vector<uint32_t> misc_idx;
+  for (int q = SL_H; q <= SL_M; q++) misc_idx.push_back((uint32_t)q);
+  for (int q = 0; q < NPP; q++) misc_idx.push_back((uint32_t)(SL_A + q));
+  const uint32_t* d_misc = idx_list(misc_idx);
+  const size_t NM = misc_idx.size();
+
+  parallel_for(B, [&](size_t p) {
+    VState& s = st[p];
+    const uint8_t* pb = s.pb;
+    auto P = [&](int slot_id) { return pb + pt_off[slot_id - SL_A]; };
+    const S a1 = S_from_wire(rand + (p * 8 + 0) * 32), a2 = S_from_wire(rand + (p * 8 + 1) * 32), a3 = S_from_wire(rand + (p * 8 + 2) * 32),
+            a4 = S_from_wire(rand + (p * 8 + 3) * 32), a5 = S_from_wire(rand + (p * 8 + 4) * 32), a6 = S_from_wire(rand + (p * 8 + 5) * 32),
+            a7 = S_from_wire(rand + (p * 8 + 6) * 32), a8 = S_from_wire(rand + (p * 8 + 7) * 32);
+    const S beta_l = s.beta_g.pow_u64(ell), beta_l1 = beta_l * s.beta_g;
+    s.z_ip = s.r_p * beta_l1 + s.gprod * beta_l - S::one();
+    // inner_product_argument.rs:283-290, 202-250
+    s.tr.append_point_bytes("ipa_step1", P(SL_C));
+    s.tr.append_point_bytes("ipa_step1", &comp[(p * 2) * 48]);   // D
+    s.tr.append_scalar("ipa_step1", s.z_ip);
+    s.tr.append_point_bytes("ipa_step1", P(SL_BC));
+    s.tr.append_point_bytes("ipa_step1", P(SL_BD));
+    s.alpha_i = s.tr.get_and_append_challenge("ipa_alpha");
+    s.beta_i = s.tr.get_and_append_challenge("ipa_beta");
+    s.gam_i.resize(L);
+    for (size_t j = 0; j < L; j++) {
+      s.tr.append_point_bytes("ipa_loop", P(sm.LC((int)j)));
+      s.tr.append_point_bytes("ipa_loop", P(sm.LD((int)j)));
+      s.tr.append_point_bytes("ipa_loop", P(sm.RC((int)j)));
+      s.tr.append_point_bytes("ipa_loop", P(sm.RD((int)j)));
+      s.gam_i[j] = s.tr.get_and_append_challenge("ipa_gamma");
+    }
+    s.gam_i_inv = s.gam_i;
+    host::batch_inverse(s.gam_i_inv);
+    // same_scalar_argument.rs:112-128
+    const int sp[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
+    for (int q : sp) s.tr.append_point_bytes("sameexp_points", P(q));
+    s.alpha_s = s.tr.get_and_append_challenge("same_scalar_alpha");
+    // same_multiscalar_argument.rs:229-233, 167-186
+    s.tr.append_point_bytes("same_msm_step1", &comp[(p * 2 + 1) * 48]);   // A'
+    s.tr.append_point_bytes("same_msm_step1", P(SL_CMT2));
+    s.tr.append_point_bytes("same_msm_step1", P(SL_CMU2));
+    {
+      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
+      std::vector<uint8_t> vb(n * 48, 0);
+      memcpy(vb.data(), ic + 2 * ell * 48, ell * 48);
+      for (int i = 0; i < 4; i++) vb[(ell + i) * 48] = ID0;
+      memcpy(&vb[(ell + 2) * 48], crs_H_comp_, 48);
+      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
+      std::fill(vb.begin() + ell * 48, vb.end(), 0);
+      memcpy(vb.data(), ic + 3 * ell * 48, ell * 48);
+      for (int i = 0; i < 4; i++) vb[(ell + i) * 48] = ID0;
+      memcpy(&vb[(ell + 3) * 48], crs_H_comp_, 48);
+      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
+    }
+    s.tr.append_point_bytes("same_msm_step1", P(sm.BA()));
+    s.tr.append_point_bytes("same_msm_step1", P(sm.BT()));
+    s.tr.append_point_bytes("same_msm_step1", P(sm.BU()));
+    s.alpha_m = s.tr.get_and_append_challenge("same_msm_alpha");
+    s.gam_m.resize(L);
+    for (size_t j = 0; j < L; j++) {
+      const int six[6] = {sm.LA((int)j), sm.LT((int)j), sm.LU((int)j), sm.RA((int)j), sm.RT((int)j), sm.RU((int)j)};
+      for (int q : six) s.tr.append_point_bytes("same_msm_loop", P(q));
+      s.gam_m[j] = s.tr.get_and_append_challenge("same_msm_gamma");
+    }
+    s.gam_m_inv = s.gam_m;
+    host::batch_inverse(s.gam_m_inv);
+
+    // verification scalars s_i = prod_{j : bit (L-1-j) of i set} gamma_j  (util.rs:40-64), built by doubling
+    auto svec = [&](const SVec& g) {
+      SVec sv(n);
+      sv[0] = S::one();
+      for (size_t j = 0; j < L; j++) {          // after step j, entries < 2^(j+1) are final for the low (j+1) bits
+        const size_t w = size_t(1) << j;
+        const S gj = g[L - 1 - j];              // bit j of i  <->  round L-1-j
+        for (size_t i = 0; i < w; i++) sv[w + i] = sv[i] * gj;
+      }
+      return sv;
+    };
+    const SVec s_i = svec(s.gam_i), s_m = svec(s.gam_m);
+    SVec s_i_inv = s_i;
+    host::batch_inverse(s_i_inv);
+    // u (grand_product_argument.rs:211-219)
+    SVec u(n);
+    {
+      S pw = s.beta_g_inv;
+      for (size_t i = 0; i < ell; i++) {
+        u[i] = pw;
+        pw *= s.beta_g_inv;
+      }
+      for (size_t i = ell; i < n; i++) u[i] = pw;
+    }
+    // ---- flattened accumulated check: sum_i a_i * (lhs_i - x_i . V_i) == O  (msm_accumulator.rs:38-68) ----
+    const S a2c = a2 * s.c_fin, a3d = a3 * s.d_fin, a4x = a4 * s.x_fin, a5x = a5 * s.x_fin, a6x = a6 * s.x_fin;
+    // (1) CRS part over G | Hvec (n bases)
+    SVec& k1 = s.scal[0];
+    k1.assign(n, S::zero());
+    const S a1b = a1 * s.beta_sp;
+    for (size_t i = 0; i < n; i++) {
+      S t = a2c * s_i[i] + a3d * (s_i_inv[i] * u[i]);
+      if (i < ell) t += a1b;
+      if (i < ell + 2) t += a4x * s_m[i];       // G_b = G | Hvec[0..2) | G_t | G_u
+      k1[i] = -t;
+    }
+    // (2) instance part over R | S | T | U
+    SVec& k2 = s.scal[1];
+    k2.resize(4 * ell);
+    for (size_t i = 0; i < ell; i++) {
+      k2[i] = -(a7 * s.vec_a[i]);
+      k2[ell + i] = -(a8 * s.vec_a[i]);
+      k2[2 * ell + i] = -(a5x * s_m[i]);
+      k2[3 * ell + i] = -(a6x * s_m[i]);
+    }
+    // (3) misc part: singles, M, proof points
+    SVec& k3 = s.scal[2];
+    k3.assign(NM, S::zero());
+    auto at = [&](int slot_id) -> S& { return k3[slot_id <= SL_M ? slot_id : (SL_M + 1) + (slot_id - SL_A)]; };
+    at(SL_GT) = -(a4x * s_m[ell + 2]);
+    at(SL_GU) = -(a4x * s_m[ell + 3]);
+    at(SL_H) = a2 * (s.alpha_i * s.alpha_i * s.z_ip * s.beta_i) - a2c * s.d_fin * s.beta_i - a5x * s_m[ell + 2] - a6x * s_m[ell + 3];
+    at(SL_GSUM) = -(a3 * s.alpha_i * s.beta_g_inv);
+    at(SL_HSUM) = a3 * s.alpha_i * s.alpha_g;
+    at(SL_M) = -(a1 * s.alpha_sp);
+    at(SL_B) = a1 + a3 * s.alpha_i;
+    at(SL_A) = a4 * s.alpha_m - a1;
+    at(SL_CMT1) = a4 * s.alpha_m;
+    at(SL_CMU1) = a4 * s.alpha_m;
+    at(SL_CMT2) = a5 * s.alpha_m;
+    at(SL_CMU2) = a6 * s.alpha_m;
+    at(SL_C) = a2 * s.alpha_i;
+    at(SL_BC) = a2;
+    at(SL_BD) = a3;
+    at(sm.BA()) = a4;
+    at(sm.BT()) = a5;
+    at(sm.BU()) = a6;
+    at(SL_R) = a7;
+    at(SL_S) = a8;
+    for (size_t j = 0; j < L; j++) {
+      at(sm.LC((int)j)) = a2 * s.gam_i[j];
+      at(sm.RC((int)j)) = a2 * s.gam_i_inv[j];
+      at(sm.LD((int)j)) = a3 * s.gam_i[j];
+      at(sm.RD((int)j)) = a3 * s.gam_i_inv[j];
+      at(sm.LA((int)j)) = a4 * s.gam_m[j];
+      at(sm.RA((int)j)) = a4 * s.gam_m_inv[j];
+      at(sm.LT((int)j)) = a5 * s.gam_m[j];
+      at(sm.RT((int)j)) = a5 * s.gam_m_inv[j];
+      at(sm.LU((int)j)) = a6 * s.gam_m[j];
+      at(sm.RU((int)j)) = a6 * s.gam_m_inv[j];
+    }
+    // SameScalar direct equalities (same_scalar_argument.rs:127-137), each as "... == O"
+    s.scal[3] = {S::one(), s.alpha_s, -s.z_t};             // cm_A.T_1 + alpha cm_T.T_1 - z_t G_t
+    s.scal[4] = {S::one(), s.alpha_s, -s.z_k, -s.z_t};     // cm_A.T_2 + alpha cm_T.T_2 - z_k R - z_t H
+    s.scal[5] = {S::one(), s.alpha_s, -s.z_u};             // cm_B.T_1 + alpha cm_U.T_1 - z_u G_u
+    s.scal[6] = {S::one(), s.alpha_s, -s.z_k, -s.z_u};     // cm_B.T_2 + alpha cm_U.T_2 - z_k S - z_u H
+    s.scal[7] = {S::one(), S::one(), S::one(), S::one()};  // combine the four partial sums
+  });
+
+  // -- V2: the accumulated MSM in four shards + the SameScalar equalities; V3: combine
+  {
+    const uint32_t* e1 = idx_list({(uint32_t)sm.CMA1(), (uint32_t)SL_CMT1, (uint32_t)SL_GT});
+    const uint32_t* e2 = idx_list({(uint32_t)sm.CMA2(), (uint32_t)SL_CMT2, (uint32_t)SL_R, (uint32_t)SL_H});
+    const uint32_t* e3 = idx_list({(uint32_t)sm.CMB1(), (uint32_t)SL_CMU1, (uint32_t)SL_GU});
+    const uint32_t* e4 = idx_list({(uint32_t)sm.CMB2(), (uint32_t)SL_CMU2, (uint32_t)SL_S, (uint32_t)SL_H});
+    const uint32_t* ecomb = idx_list({(uint32_t)sm.TMP(0), (uint32_t)sm.TMP(1), (uint32_t)sm.TMP(2), (uint32_t)sm.TMP(3)});
+    std::vector<MsmReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      VState& s = st[p];
+      reqs.push_back({d_crs_.p, nullptr, s.scal[0].data(), (uint32_t)n, slot_index(p, sm.TMP(0))});
+      reqs.push_back({pp(p), nullptr, s.scal[1].data(), (uint32_t)(2 * ell), slot_index(p, sm.TMP(1))});
+      reqs.push_back({pp(p) + 2 * ell, nullptr, s.scal[1].data() + 2 * ell, (uint32_t)(2 * ell), slot_index(p, sm.TMP(2))});
+      reqs.push_back({slot(p, 0), d_misc, s.scal[2].data(), (uint32_t)NM, slot_index(p, sm.TMP(3))});
+      reqs.push_back({slot(p, 0), e1, s.scal[3].data(), 3, slot_index(p, sm.TMP(4))});
+      reqs.push_back({slot(p, 0), e2, s.scal[4].data(), 4, slot_index(p, sm.TMP(5))});
+      reqs.push_back({slot(p, 0), e3, s.scal[5].data(), 3, slot_index(p, sm.TMP(6))});
+      reqs.push_back({slot(p, 0), e4, s.scal[6].data(), 4, slot_index(p, sm.TMP(7))});
+    }
+    std::vector<uint8_t> comp2;
+    run_msm_phase(reqs, &comp2);
+    std::vector<MsmReq> reqs3;
+    for (size_t p = 0; p < B; p++) reqs3.push_back({slot(p, 0), ecomb, st[p].scal[7].data(), 4, slot_index(p, sm.TMP(0))});
+    std::vector<uint8_t> comp3;
+    run_msm_phase(reqs3, &comp3);
+    for (size_t p = 0; p < B; p++) {
+      VState& s = st[p];
+      bool ok = comp3[p * 48] == ID0;
+      for (int e = 4; e < 8; e++) ok = ok && comp2[(p * 8 + e) * 48] == ID0;
+      verdict[p] = s.bad ? CPX_ERR_DESERIALIZE : ((s.reject || !ok) ? CPX_ERR_VERIFY : CPX_OK);
+    }
+  }
+  flush_timers();
+}
+
+}  // namespace cpx

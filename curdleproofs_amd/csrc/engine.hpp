@@ -1,0 +1,166 @@
+// Host engine of the MI355X Curdleproofs core — product code.
+//
+// One `Engine` = one HIP device + one stream + the device-resident CRS and batch buffers.  A batch of
+// B independent shuffle instances (same ell) advances in lock-step: every protocol phase is ONE set of
+// kernel launches covering all B proofs (the batch is a grid dimension), bracketed by the host-side
+// Fiat-Shamir step.  Mirrors /root/reference/src/curdleproofs.rs:59-298 and the sub-arguments it calls.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/cpx.h"   // public error codes
+#include "host_math.hpp"
+#include "kernels.h"
+
+namespace cpx {
+
+struct HipError : std::runtime_error {
+  hipError_t code;
+  HipError(hipError_t c, const char* what) : std::runtime_error(what), code(c) {}
+};
+#define CPX_HIP(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) throw ::cpx::HipError(_e, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
+  } while (0)
+
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) CPX_HIP(hipFree(p));
+    p = nullptr;
+    CPX_HIP(hipMalloc(&p, n * sizeof(T)));
+    cap = n;
+  }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+template <class T> struct PinBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) CPX_HIP(hipHostFree(p));
+    p = nullptr;
+    CPX_HIP(hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault));
+    cap = n;
+  }
+  ~PinBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+};
+
+struct KernelStat {
+  uint64_t launches = 0;
+  double ms = 0;
+  double alg_bytes = 0;   // algorithmic bytes moved (SURVEY §8d accounting)
+};
+
+
+class Engine {
+ public:
+  explicit Engine(int device);
+  ~Engine();
+
+  // crs.rs:37-58 CurdleproofsCrs::from_points: ell + 7 affine points (G[ell] | H[4] | H | G_t | G_u)
+  void set_crs(size_t ell, const uint8_t* points);
+  size_t ell() const { return ell_; }
+  size_t n() const { return n_; }
+  size_t log2n() const { return L_; }
+  size_t proof_size() const { return 48 * (18 + 10 * L_) + 32 * 7; }
+  void crs_sums(uint8_t* g_sum, uint8_t* h_sum) const;
+
+  // ---- tier 0: the reference's util::msm & friends on caller buffers ----
+  void msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out_jac);                  // util.rs:19-22
+  void msm_jac(const uint8_t* bases_jac, const uint8_t* scalars, size_t n, uint8_t* out_jac);          // util.rs:25-29
+  void fold(uint8_t* PL, const uint8_t* PR, const uint8_t* gamma, size_t half);                        // IPA / SameMSM folds
+  void scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_stride, size_t n, uint8_t* out);  // G' rescale / k*R
+  void normalize(const uint8_t* jac, size_t n, uint8_t* out_aff, uint8_t* out_comp);                   // normalize_batch (+compress)
+  int decompress(const uint8_t* comp, size_t n, uint8_t* out_aff, int check_subgroup);                 // whisk.rs:318-320
+
+  // ---- tier 2: batches of whole proofs, instance data resident in HBM ----
+  void batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M);
+  // witnesses + the 3n+9 Fr draws per proof (SURVEY §8b RNG contract); writes batch * proof_size() bytes
+  void batch_prove(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
+  // proofs: batch * proof_size() bytes; rand: batch * 8 Fr; verdict[i] = CPX_OK / CPX_ERR_VERIFY / CPX_ERR_DESERIALIZE
+  void batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdict);
+  size_t batch() const { return B_; }
+
+  // ---- measurement ----
+  void set_profiling(bool on) { profiling_ = on; }
+  void reset_stats() { stats_.clear(); }
+  const std::map<std::string, KernelStat>& stats() const { return stats_; }
+  double bench_fpmul(int blocks, int iters, int reps);   // returns Fp products per second
+  void set_host_threads(int t) { host_threads_ = t; }
+  hipStream_t stream() const { return stream_; }
+  void sync() { CPX_HIP(hipStreamSynchronize(stream_)); }
+
+ private:
+  struct MsmReq {
+    const Aff* bases;
+    const uint32_t* idx;
+    const host::S* scalars;   // host pointer, n entries
+    uint32_t n;
+    uint32_t dst;             // index into d_pp_ (Aff units) receiving the affine result
+  };
+  struct Timed {
+    hipEvent_t a, b;
+    std::string name;
+    double bytes;
+  };
+
+  void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
+  void run_smul(const std::vector<SmulTask>& tasks, int cnt, const host::S* scalars, size_t nscalars, double alg_bytes);
+  const uint32_t* idx_list(const std::vector<uint32_t>& v);
+  void tick(const char* name, double bytes);
+  void tock();
+  void flush_timers();
+  template <class F> void parallel_for(size_t n, F&& f);
+
+  Aff* pp(size_t p) const { return d_pp_.p + p * pp_stride_; }
+  Aff* slot(size_t p, int s) const { return pp(p) + 4 * ell_ + s; }
+  uint32_t slot_index(size_t p, int s) const { return (uint32_t)(p * pp_stride_ + 4 * ell_ + s); }
+
+  int device_;
+  hipStream_t stream_ = nullptr;
+  bool profiling_ = false;
+  int host_threads_ = 0;
+  std::map<std::string, KernelStat> stats_;
+  std::vector<Timed> pending_;
+
+  // CRS
+  size_t ell_ = 0, n_ = 0, L_ = 0;
+  DevBuf<Aff> d_crs_;        // [n+1] G | Hvec | H      (IPA basis + H)
+  DevBuf<Aff> d_crs_gb_;     // [n]   G | Hvec[0..2) | G_t | G_u   (SameMSM basis)
+  Aff crs_single_[5];        // H, G_t, G_u, G_sum, H_sum (host copies)
+  uint8_t crs_H_comp_[48];
+
+  // batch
+  size_t B_ = 0;
+  size_t pp_stride_ = 0;     // 4*ell + NSLOT
+  DevBuf<Aff> d_pp_;         // per proof: R|S|T|U | slots
+  DevBuf<Aff> d_wGi_, d_wGp_, d_wGm_, d_wT_, d_wU_;   // folding work vectors, [B][n+1]
+  DevBuf<Jac> d_Mjac_;
+
+  // phase scratch
+  DevBuf<MsmTask> d_tasks_;
+  DevBuf<SmulTask> d_stasks_;
+  DevBuf<Fr> d_scal_;
+  DevBuf<Jac> d_wsum_, d_part_, d_res_;
+  DevBuf<uint32_t> d_dst_;
+  DevBuf<uint8_t> d_comp_;
+  PinBuf<uint8_t> h_stage_;
+  PinBuf<uint8_t> h_comp_;
+  std::map<std::vector<uint32_t>, uint32_t*> idx_cache_;
+  std::vector<uint32_t*> idx_allocs_;
+  DevBuf<uint8_t> d_bytes_;
+  DevBuf<uint8_t> d_status_;
+};
+
+}  // namespace cpx

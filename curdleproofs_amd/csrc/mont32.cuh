@@ -1,0 +1,236 @@
+// Montgomery prime-field arithmetic on 32-bit limbs for gfx950 (CDNA4) — product code.
+//
+// BLS12-381 Fp (12 limbs, R = 2^384) and Fr (8 limbs, R = 2^256).  The Montgomery radix equals
+// the one arkworks uses on 64-bit limbs, so a field element has the same bytes in memory on both
+// sides of the C-ABI: no conversion at the boundary.
+//
+// Everything here is `__host__ __device__` and branch-light so that
+//   * the HIP kernels (msm / fold / scale / normalise) keep a whole element in VGPRs
+//     (12 registers per Fp, fully unrolled limb loops -> static register indexing), and
+//   * the host engine uses the very same code for the Fr bookkeeping of the protocol, and
+//   * tests can run the device math bit-for-bit on the CPU (tests/host_emul) against the oracle.
+// The 32x32->64 multiply-accumulate `(u64)a*b + c` lowers to one v_mad_u64_u32 on gfx950.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#include <hip/hip_runtime.h>
+#define CPX_HD __host__ __device__ __forceinline__
+// Real (non-inlined) functions for the big bodies: one copy of the ~1.3k-instruction Montgomery
+// product and of each point formula per code object keeps the kernels inside the instruction
+// cache (a fully inlined mixed add is > 100 KB of code) and cuts compile time by an order of magnitude.
+#define CPX_HD_FN __host__ __device__ __noinline__ inline
+#define CPX_UNROLL _Pragma("unroll")
+#else
+#define CPX_HD inline __attribute__((always_inline))
+#define CPX_HD_FN inline __attribute__((noinline))
+#define CPX_UNROLL _Pragma("GCC unroll 16")
+#endif
+
+namespace cpx {
+
+// ---- field configurations (little-endian 32-bit limbs) ----
+struct FpCfg {
+  static constexpr int N = 12;
+  static constexpr uint32_t P[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                     0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+  // R mod p
+  static constexpr uint32_t ONE[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
+                                       0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+  // R^2 mod p
+  static constexpr uint32_t R2[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
+                                      0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+  static constexpr uint32_t INV = 0xfffcfffdu;   // -p^{-1} mod 2^32
+};
+struct FrCfg {
+  static constexpr int N = 8;
+  static constexpr uint32_t P[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                                    0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+  static constexpr uint32_t ONE[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                                      0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+  static constexpr uint32_t R2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                                     0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+  static constexpr uint32_t INV = 0xffffffffu;   // -r^{-1} mod 2^32
+};
+
+template <class C> struct Fe {
+  static constexpr int N = C::N;
+  typedef C Cfg;
+  uint32_t v[N];
+
+  static CPX_HD Fe zero() {
+    Fe r;
+    CPX_UNROLL for (int i = 0; i < N; i++) r.v[i] = 0;
+    return r;
+  }
+  static CPX_HD Fe one() {
+    Fe r;
+    CPX_UNROLL for (int i = 0; i < N; i++) r.v[i] = C::ONE[i];
+    return r;
+  }
+  static CPX_HD Fe r2() {
+    Fe r;
+    CPX_UNROLL for (int i = 0; i < N; i++) r.v[i] = C::R2[i];
+    return r;
+  }
+  CPX_HD bool is_zero() const {
+    uint32_t o = 0;
+    CPX_UNROLL for (int i = 0; i < N; i++) o |= v[i];
+    return o == 0;
+  }
+  CPX_HD bool eq(const Fe& b) const {
+    uint32_t o = 0;
+    CPX_UNROLL for (int i = 0; i < N; i++) o |= v[i] ^ b.v[i];
+    return o == 0;
+  }
+};
+
+// r = a - p if a >= p else a   (a < 2p)
+template <class C> CPX_HD void fe_reduce_once(Fe<C>& a) {
+  constexpr int N = C::N;
+  uint32_t s[N];
+  uint32_t borrow = 0;
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    uint64_t d = (uint64_t)a.v[i] - C::P[i] - borrow;
+    s[i] = (uint32_t)d;
+    borrow = (uint32_t)(d >> 63);
+  }
+  CPX_UNROLL for (int i = 0; i < N; i++) a.v[i] = borrow ? a.v[i] : s[i];
+}
+
+template <class C> CPX_HD Fe<C> fe_add(const Fe<C>& a, const Fe<C>& b) {
+  constexpr int N = C::N;
+  Fe<C> r;
+  uint32_t carry = 0;
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    uint64_t s = (uint64_t)a.v[i] + b.v[i] + carry;
+    r.v[i] = (uint32_t)s;
+    carry = (uint32_t)(s >> 32);
+  }
+  // both moduli leave the top bit of the top limb clear, so a + b < 2^(32N): carry == 0
+  fe_reduce_once(r);
+  return r;
+}
+template <class C> CPX_HD Fe<C> fe_sub(const Fe<C>& a, const Fe<C>& b) {
+  constexpr int N = C::N;
+  Fe<C> r;
+  uint32_t borrow = 0;
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
+    r.v[i] = (uint32_t)d;
+    borrow = (uint32_t)(d >> 63);
+  }
+  uint32_t mask = 0u - borrow, carry = 0;
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    uint64_t s = (uint64_t)r.v[i] + (C::P[i] & mask) + carry;
+    r.v[i] = (uint32_t)s;
+    carry = (uint32_t)(s >> 32);
+  }
+  return r;
+}
+template <class C> CPX_HD Fe<C> fe_neg(const Fe<C>& a) {
+  constexpr int N = C::N;
+  Fe<C> r;
+  uint32_t borrow = 0, nz = 0;
+  CPX_UNROLL for (int i = 0; i < N; i++) nz |= a.v[i];
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    uint64_t d = (uint64_t)C::P[i] - a.v[i] - borrow;
+    r.v[i] = nz ? (uint32_t)d : 0u;
+    borrow = (uint32_t)(d >> 63);
+  }
+  return r;
+}
+template <class C> CPX_HD Fe<C> fe_dbl(const Fe<C>& a) {
+  constexpr int N = C::N;
+  Fe<C> r;
+  uint32_t carry = 0;
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    uint32_t x = a.v[i];
+    r.v[i] = (x << 1) | carry;
+    carry = x >> 31;
+  }
+  fe_reduce_once(r);
+  return r;
+}
+
+// Montgomery product a*b*R^-1 mod p.  CIOS, "no-carry" variant (valid because the top bit of the
+// modulus' top limb is clear for both Fp and Fr): 2N multiply-accumulates per outer step.
+template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
+  constexpr int N = C::N;
+  uint32_t t[N];
+  CPX_UNROLL for (int i = 0; i < N; i++) t[i] = 0;
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    const uint32_t bi = b.v[i];
+    uint64_t A = (uint64_t)a.v[0] * bi + t[0];
+    const uint32_t t0 = (uint32_t)A;
+    A >>= 32;
+    const uint32_t m = t0 * C::INV;
+    uint64_t Cc = (uint64_t)m * C::P[0] + t0;
+    Cc >>= 32;
+    CPX_UNROLL for (int j = 1; j < N; j++) {
+      A += (uint64_t)a.v[j] * bi + t[j];
+      Cc += (uint64_t)m * C::P[j] + (uint32_t)A;
+      A >>= 32;
+      t[j - 1] = (uint32_t)Cc;
+      Cc >>= 32;
+    }
+    t[N - 1] = (uint32_t)(Cc + A);
+  }
+  Fe<C> r;
+  CPX_UNROLL for (int i = 0; i < N; i++) r.v[i] = t[i];
+  fe_reduce_once(r);
+  return r;
+}
+template <class C> CPX_HD Fe<C> fe_sqr(const Fe<C>& a) { return fe_mul(a, a); }
+
+// Montgomery form -> canonical integer (multiply by 1) and back (multiply by R^2)
+template <class C> CPX_HD Fe<C> fe_from_mont(const Fe<C>& a) {
+  Fe<C> o = Fe<C>::zero();
+  o.v[0] = 1;
+  return fe_mul(a, o);
+}
+template <class C> CPX_HD Fe<C> fe_to_mont(const Fe<C>& a) { return fe_mul(a, Fe<C>::r2()); }
+
+// canonical-integer comparison helper: a > b on raw limbs
+template <class C> CPX_HD bool fe_raw_gt(const Fe<C>& a, const Fe<C>& b) {
+  constexpr int N = C::N;
+  bool gt = false, decided = false;
+  CPX_UNROLL for (int i = N - 1; i >= 0; i--) {
+    bool g = a.v[i] > b.v[i], l = a.v[i] < b.v[i];
+    gt = decided ? gt : g;
+    decided = decided || g || l;
+  }
+  return gt;
+}
+
+// a^e for a public exponent given as little-endian 32-bit limbs (nl limbs); plain square-and-multiply.
+// Not unrolled: used for inversion / sqrt where the exponent is a fixed constant.
+template <class C> CPX_HD Fe<C> fe_pow(const Fe<C>& a, const uint32_t* e, int nl) {
+  Fe<C> r = Fe<C>::one();
+  bool started = false;
+  for (int i = nl * 32 - 1; i >= 0; i--) {
+    if (started) r = fe_sqr(r);
+    if ((e[i >> 5] >> (i & 31)) & 1u) {
+      r = started ? fe_mul(r, a) : a;
+      started = true;
+    }
+  }
+  return r;
+}
+// Fermat inverse a^(p-2); 0 -> 0.
+template <class C> CPX_HD Fe<C> fe_inv(const Fe<C>& a) {
+  constexpr int N = C::N;
+  uint32_t e[N];
+  uint32_t borrow = 2;   // e = p - 2 with borrow propagation (r ends in ...00000001)
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    uint64_t d = (uint64_t)C::P[i] - borrow;
+    e[i] = (uint32_t)d;
+    borrow = (uint32_t)(d >> 63);
+  }
+  return fe_pow(a, e, N);
+}
+
+typedef Fe<FpCfg> Fp;
+typedef Fe<FrCfg> Fr;
+
+}  // namespace cpx

@@ -1,0 +1,112 @@
+/* cpx.h — C-ABI of the MI355X (gfx950) Curdleproofs G1 core.
+ *
+ * This is the drop-in boundary for the one hot path of asn-d6/curdleproofs: the BLS12-381 G1 group
+ * arithmetic behind `CurdleproofsProof::{new,verify}`.  The reference is a pure-Rust crate with no
+ * FFI of its own; the functions below are what an FFI for this path would bind, each one citing the
+ * reference interface it replaces (paths relative to the reference repo, file:line).
+ * INTEGRATION.md shows the Rust-side `extern "C"` block and the three edits that route the crate here.
+ *
+ * Data layouts — exactly arkworks' in-memory limbs, so a Rust caller passes slices through untouched:
+ *   Fr     32 B   4 x u64 little-endian limbs, Montgomery form (R = 2^256)      = ark_bls12_381::Fr
+ *   Fp     48 B   6 x u64 little-endian limbs, Montgomery form (R = 2^384)
+ *   affine 96 B   x || y ; the point at infinity is encoded as 96 zero bytes     ~ G1Affine {x,y,infinity}
+ *   jac   144 B   X || Y || Z Jacobian ; infinity <=> Z == 0                     = G1Projective
+ *   compressed 48 B  zcash/ark-serialize compressed encoding
+ *
+ * Ownership: the caller owns every buffer it passes (valid for the duration of the call only); the
+ * library owns device memory, the HIP stream and the device-resident CRS inside the opaque cpx_ctx.
+ * Threading: one ctx = one HIP device + one stream; a ctx is not re-entrant, distinct ctxs may be driven
+ * from distinct host threads.  Errors: int return, 0 = ok, negative = CPX_ERR_*; nothing unwinds
+ * across this boundary (the reference's panics — util.rs:20, inner_product_argument.rs:115-116 —
+ * become error codes).  There is NO CPU fallback: without a usable HIP device every call fails.
+ */
+#ifndef CPX_H
+#define CPX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPX_OK 0
+#define CPX_ERR_ARG (-1)         /* bad length / null pointer                                   */
+#define CPX_ERR_NOT_POW2 (-2)    /* ell + 4 not a power of two (inner_product_argument.rs:116)  */
+#define CPX_ERR_HIP (-3)         /* HIP runtime failure (no device, OOM, launch error)          */
+#define CPX_ERR_VERIFY (-4)      /* ProofError::VerificationError (errors.rs:9)                 */
+#define CPX_ERR_DESERIALIZE (-5) /* ark_serialize::SerializationError                           */
+#define CPX_ERR_STATE (-6)       /* call order: CRS / batch not set                             */
+#define CPX_ERR_INTERNAL (-7)
+
+typedef struct cpx_ctx cpx_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int cpx_ctx_create(int device_id, cpx_ctx** out);
+void cpx_ctx_destroy(cpx_ctx* ctx);
+const char* cpx_last_error(const cpx_ctx* ctx); /* message of the last failing call on this ctx    */
+int cpx_device_count(void);
+
+/* crs.rs:37-58 `CurdleproofsCrs::from_points(ell, points)`: ell + 7 affine points in the order
+ * vec_G[ell] | vec_H[4] | H | G_t | G_u.  Uploads them, computes G_sum / H_sum on the device. */
+int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points);
+int cpx_crs_sums(const cpx_ctx* ctx, uint8_t g_sum[96], uint8_t h_sum[96]);
+size_t cpx_proof_size(const cpx_ctx* ctx); /* 48*(18+10*log2(ell+4)) + 32*7, e.g. 4928 at ell = 252 */
+
+/* ---- tier 0: the reference's MSM funnel and the loops that bypass it ------------------------- */
+/* util.rs:19-22 `msm(points: &[G1Affine], scalars: &[Fr]) -> G1Projective` */
+int cpx_g1_msm(cpx_ctx* ctx, const uint8_t* bases /* n*96 */, const uint8_t* scalars /* n*32 */, size_t n, uint8_t out[144]);
+/* util.rs:25-29 `msm_from_projective(points: &[G1Projective], scalars: &[Fr])` */
+int cpx_g1_msm_jac(cpx_ctx* ctx, const uint8_t* bases /* n*144 */, const uint8_t* scalars, size_t n, uint8_t out[144]);
+/* inner_product_argument.rs:177-178, same_multiscalar_argument.rs:128-130:
+ *   PL[i] <- (PL[i] + PR[i] * gamma).into_affine(), i < half, in place */
+int cpx_g1_fold(cpx_ctx* ctx, uint8_t* PL /* half*96 */, const uint8_t* PR /* half*96 */, const uint8_t gamma[32], size_t half);
+/* grand_product_argument.rs:90-102 (per-element scalars, scalar_stride = 32) and util.rs:94-95
+ * (one shared scalar, scalar_stride = 0):  out[i] <- (P[i] * s_i).into_affine() */
+int cpx_g1_scale(cpx_ctx* ctx, const uint8_t* P /* n*96 */, const uint8_t* scalars, size_t scalar_stride, size_t n, uint8_t* out /* n*96 */);
+/* ark_ec `CurveGroup::normalize_batch` (+ optional `serialize_compressed`); either output may be NULL */
+int cpx_g1_normalize(cpx_ctx* ctx, const uint8_t* jac /* n*144 */, size_t n, uint8_t* out_affine /* n*96 */, uint8_t* out_compressed /* n*48 */);
+/* whisk.rs:318-320 `from_bytes_g1affine` = deserialize_compressed with on-curve + subgroup validation */
+int cpx_g1_decompress(cpx_ctx* ctx, const uint8_t* compressed /* n*48 */, size_t n, uint8_t* out_affine /* n*96 */, int check_subgroup);
+
+/* ---- tier 1: msm_accumulator.rs:22-68 `MsmAccumulator` -------------------------------------- */
+typedef struct cpx_accum cpx_accum;
+int cpx_accum_new(cpx_ctx* ctx, cpx_accum** out);
+void cpx_accum_free(cpx_accum* acc);
+/* `accumulate_check(&mut self, C, vec_x, vec_V, rng)`; the caller passes the `Fr::rand(rng)` value it drew */
+int cpx_accum_check(cpx_accum* acc, const uint8_t C[144], const uint8_t* vec_x /* n*32 */, const uint8_t* vec_V /* n*96 */, size_t n,
+                    const uint8_t random_factor[32]);
+/* `verify(self)`: CPX_OK or CPX_ERR_VERIFY */
+int cpx_accum_verify(cpx_accum* acc);
+
+/* ---- tier 2: whole proofs, batched, instance data resident in HBM --------------------------- */
+/* Uploads `batch` instances (vec_R, vec_S, vec_T, vec_U: batch*ell*96 each; M: batch*144 Jacobian):
+ * the public inputs of curdleproofs.rs:59-70 / :197-207. */
+int cpx_batch_load(cpx_ctx* ctx, size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U,
+                   const uint8_t* M);
+/* curdleproofs.rs:59 `CurdleproofsProof::new` for every loaded instance.
+ *   permutation  batch*ell u32          k  batch*32          vec_m_blinders  batch*4*32
+ *   rand         batch*(3n+9)*32, n = ell+4: the `Fr::rand(rng)` draws in the reference's order —
+ *                vec_a_blinders[2] (curdleproofs.rs:86), vec_c_blinders[4] (grand_product_argument.rs:75),
+ *                IPA r[n], z[n-2] (inner_product_argument.rs:46-47), r_t, r_u (curdleproofs.rs:110-111),
+ *                r_a, r_b, r_k (same_scalar_argument.rs:56-58), vec_r[n] (same_multiscalar_argument.rs:78)
+ *   proofs_out   batch*cpx_proof_size() bytes = `CurdleproofsProof::serialize` (curdleproofs.rs:300-310) */
+int cpx_batch_prove(cpx_ctx* ctx, const uint32_t* permutation, const uint8_t* k, const uint8_t* vec_m_blinders, const uint8_t* rand,
+                    uint8_t* proofs_out);
+/* curdleproofs.rs:197 `verify` (after `deserialize`, :312-323) for every loaded instance.
+ *   rand     batch*8*32: the eight `accumulate_check` factors (msm_accumulator.rs:44) in call order
+ *   verdict  batch ints: CPX_OK, CPX_ERR_VERIFY or CPX_ERR_DESERIALIZE */
+int cpx_batch_verify(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, int* verdict);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+int cpx_set_profiling(cpx_ctx* ctx, int on); /* time every kernel group with HIP events on the ctx stream */
+int cpx_reset_stats(cpx_ctx* ctx);
+/* name in {"msm","smul","finalize","compress","decompress"}; any out pointer may be NULL */
+int cpx_get_stat(const cpx_ctx* ctx, const char* name, uint64_t* launches, double* total_ms, double* algorithmic_bytes);
+int cpx_set_host_threads(cpx_ctx* ctx, int threads);
+/* dependent Fp multiply chains: returns achieved Fp products per second */
+int cpx_bench_fpmul(cpx_ctx* ctx, int blocks, int iters, int reps, double* products_per_second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPX_H */

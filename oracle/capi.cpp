@@ -97,6 +97,14 @@ void orc_merlin_test_vector(uint8_t out[32]) {
   t.challenge_bytes("challenge", out, 32);
 }
 
+// transcript.rs:41-54 on a small transcript: hash `len` bytes under "lbl", return two challenges "ch"
+void orc_challenges(const uint8_t* msg, size_t len, uint8_t out[64]) {
+  Transcript t("curdleproofs");
+  t.append_message("lbl", msg, len);
+  fr_to_wire(t.get_and_append_challenge("ch"), out);
+  fr_to_wire(t.get_and_append_challenge("ch"), out + 32);
+}
+
 // whisk.rs:381-402 `whisk_tracker_proof`: returns validity, writes the 128-byte proof
 int orc_kat_tracker_proof(uint8_t out[128]) {
   StdRng rng(0);

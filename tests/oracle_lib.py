@@ -52,6 +52,7 @@ class Oracle:
         L.orc_rng_shuffle.argtypes = [vp_, vp_, sz_]
         sz = ctypes.c_size_t
         vp = ctypes.c_void_p
+        L.orc_challenges.argtypes = [vp, sz, vp]
         L.orc_kat_shuffle_proof.argtypes = [sz, vp, vp, vp, sz, ctypes.POINTER(sz)]
         L.orc_fp_mul.argtypes = [vp, vp, vp, sz]
         L.orc_fp_inv.argtypes = [vp, vp, sz]
@@ -91,6 +92,11 @@ class Oracle:
         b = _cb(state200)
         self.lib.orc_keccak_f1600(b)
         return bytes(b)
+
+    def challenges(self, msg):
+        o = _buf(64)
+        self.lib.orc_challenges(_cb(msg), len(msg), o)
+        return bytes(o)
 
     def kat_tracker_proof(self):
         o = _buf(128)

@@ -1,0 +1,123 @@
+"""CPU checks of the PRODUCT's portable math (curdleproofs_amd/csrc/*.cuh + host_math.hpp), compiled
+for the host by tests/host_emul/emul.cpp, against the oracle.  The emulation library is test-only: it
+mirrors what each kernel computes per lane so that arithmetic / recoding bugs surface without a GPU."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_emul", "emul.cpp")
+LIB = os.path.join(HERE, "host_emul", "_emul.so")
+CSRC = os.path.join(HERE, "..", "curdleproofs_amd", "csrc")
+P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+FR, AFF, JAC = 32, 96, 144
+
+
+@pytest.fixture(scope="module")
+def emul():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC])
+    L = ctypes.CDLL(LIB)
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    L.emul_fp_mul.argtypes = [vp, vp, vp, sz]
+    L.emul_fr_mul.argtypes = [vp, vp, vp, sz]
+    L.emul_msm.argtypes = [vp, vp, sz, vp]
+    L.emul_smul.argtypes = [vp, vp, vp, vp]
+    L.emul_challenges.argtypes = [vp, sz, vp]
+    return L
+
+
+def _b(x):
+    return (ctypes.c_uint8 * len(x)).from_buffer_copy(x)
+
+
+def _o(n):
+    return (ctypes.c_uint8 * n)()
+
+
+def test_limb_arithmetic_matches_oracle_and_python(emul, orc):
+    rnd = os.urandom
+    vals = [int.from_bytes(rnd(48), "little") % P for _ in range(64)] + [0, 1, P - 1, P - 2, (1 << 380), (1 << 381) - 1 - (1 << 380)]
+    a = b"".join(v.to_bytes(48, "little") for v in vals)
+    b = b"".join(v.to_bytes(48, "little") for v in reversed(vals))
+    o = _o(len(a))
+    emul.emul_fp_mul(_b(a), _b(b), o, len(vals))
+    assert bytes(o) == orc.fp_mul(a, b)
+    for x, y in zip(vals[:20] + vals[-6:], list(reversed(vals))[:20] + vals[-6:]):
+        r = _o(4 * 48)
+        emul.emul_fp_addsubnegdbl(_b(x.to_bytes(48, "little")), _b(y.to_bytes(48, "little")), r)
+        got = [int.from_bytes(bytes(r)[i * 48:(i + 1) * 48], "little") for i in range(4)]
+        assert got == [(x + y) % P, (x - y) % P, (-x) % P, (2 * x) % P]
+    x = vals[3].to_bytes(48, "little")
+    r = _o(48)
+    emul.emul_fp_inv(_b(x), r)
+    assert bytes(r) == orc.fp_inv(x)
+    s = orc.rng(5).fr(40)
+    t = orc.rng(6).fr(40)
+    o = _o(len(s))
+    emul.emul_fr_mul(_b(s), _b(t), o, 40)
+    assert bytes(o) == orc.fr_mul(s, t)
+    r = _o(32)
+    emul.emul_fr_inv(_b(s[:32]), r)
+    assert bytes(r) == orc.fr_inv(s[:32])
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 64])
+def test_msm_kernel_algorithm(emul, orc, n):
+    rng = orc.rng(40 + n)
+    bases = bytearray(rng.g1_affine(n))
+    scalars = bytearray(rng.fr(n))
+    if n >= 17:
+        bases[0:AFF] = bytes(AFF)                                   # identity base
+        bases[3 * AFF:4 * AFF] = bases[2 * AFF:3 * AFF]             # duplicate base + same scalar: P + P in a bucket
+        scalars[3 * FR:4 * FR] = scalars[2 * FR:3 * FR]
+        scalars[5 * FR:6 * FR] = bytes(FR)                          # zero scalar
+        rm1 = (0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001 - 1).to_bytes(32, "little")
+        scalars[6 * FR:7 * FR] = orc.fr_from_canonical_bytes(rm1)   # r - 1: top digits + carries
+    o = _o(JAC)
+    emul.emul_msm(_b(bytes(bases)), _b(bytes(scalars)), n, o)
+    assert orc.g1_compress_jac(bytes(o)) == orc.g1_compress_jac(orc.g1_msm(bytes(bases), bytes(scalars), naive=True))
+
+
+def test_smul_kernel_algorithm(emul, orc):
+    rng = orc.rng(77)
+    for i in range(6):
+        A, M, s = rng.g1_affine(1), rng.g1_affine(1), rng.fr(1)
+        if i == 1:
+            A = bytes(AFF)
+        if i == 2:
+            M = bytes(AFF)
+        if i == 3:
+            s = orc.fr_from_u64(0)
+        if i == 4:
+            s = orc.fr_from_canonical_bytes((0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001 - 1).to_bytes(32, "little"))
+        o = _o(JAC)
+        emul.emul_smul(_b(A), _b(M), _b(s), o)
+        a = _o(AFF)
+        emul.emul_to_affine(o, a)
+        assert bytes(a) == orc.g1_fold(A, M, s)
+        c = _o(48)
+        emul.emul_compress(a, c)
+        assert bytes(c) == orc.g1_compress(bytes(a))
+        o2 = _o(JAC)
+        emul.emul_smul(None, _b(M), _b(s), o2)
+        emul.emul_to_affine(o2, a)
+        assert bytes(a) == orc.g1_scale(M, s)
+
+
+def test_engine_transcript(emul, orc):
+    o = _o(32)
+    emul.emul_merlin_vector(o)
+    assert bytes(o).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    for ln in (0, 1, 47, 165, 166, 167, 400, 12104):
+        msg = bytes((i * 7 + ln) & 0xFF for i in range(ln))
+        o = _o(64)
+        emul.emul_challenges(_b(msg) if ln else None, ln, o)
+        assert bytes(o) == orc.challenges(msg)
+    st = os.urandom(200)
+    b = _b(st)
+    emul.emul_keccak(b)
+    assert bytes(b) == orc.keccak_f1600(st)

@@ -95,7 +95,7 @@ def load_library():
     L.cpx_set_profiling.argtypes = [vp, ci]
     L.cpx_reset_stats.argtypes = [vp]
     L.cpx_get_stat.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
-                               ctypes.POINTER(ctypes.c_double)]
+                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.cpx_set_host_threads.argtypes = [vp, ci]
     L.cpx_bench_fpmul.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     _lib = L
@@ -242,9 +242,14 @@ class Context:
         self._check(self._L.cpx_reset_stats(self._h))
 
     def stat(self, name):
-        n, ms, by = ctypes.c_uint64(0), ctypes.c_double(0), ctypes.c_double(0)
-        self._check(self._L.cpx_get_stat(self._h, name.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
-        return dict(launches=n.value, ms=ms.value, alg_bytes=by.value)
+        n, ms, by, un = ctypes.c_uint64(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._L.cpx_get_stat(self._h, name.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(un)))
+        return dict(launches=n.value, ms=ms.value, alg_bytes=by.value, units=un.value)
+
+    KERNELS = ("k_msm_accum", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress")
+
+    def stats(self):
+        return {k: self.stat(k) for k in self.KERNELS}
 
     def set_host_threads(self, t):
         self._check(self._L.cpx_set_host_threads(self._h, t))

@@ -227,7 +227,7 @@ int cpx_reset_stats(cpx_ctx* ctx) {
   ctx->eng->reset_stats();
   return CPX_OK;
 }
-int cpx_get_stat(const cpx_ctx* ctx, const char* name, uint64_t* launches, double* total_ms, double* algorithmic_bytes) {
+int cpx_get_stat(const cpx_ctx* ctx, const char* name, uint64_t* launches, double* total_ms, double* algorithmic_bytes, double* units) {
   if (!ctx || !ctx->eng || !name) return CPX_ERR_ARG;
   auto& m = ctx->eng->stats();
   auto it = m.find(name);
@@ -236,6 +236,7 @@ int cpx_get_stat(const cpx_ctx* ctx, const char* name, uint64_t* launches, doubl
   if (launches) *launches = st.launches;
   if (total_ms) *total_ms = st.ms;
   if (algorithmic_bytes) *algorithmic_bytes = st.alg_bytes;
+  if (units) *units = st.units;
   return CPX_OK;
 }
 int cpx_set_host_threads(cpx_ctx* ctx, int threads) {

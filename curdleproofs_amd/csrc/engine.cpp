@@ -61,9 +61,10 @@ Engine::~Engine() {
 }
 
 // ---------------------------------------------------------------- timing
-void Engine::tick(const char* name, double bytes) {
+void Engine::tick(const char* name, double bytes, double units) {
   if (!profiling_) return;
   Timed t;
+  t.units = units;
   CPX_HIP(hipEventCreate(&t.a));
   CPX_HIP(hipEventCreate(&t.b));
   t.name = name;
@@ -85,6 +86,7 @@ void Engine::flush_timers() {
     st.launches++;
     st.ms += ms;
     st.alg_bytes += t.bytes;
+    st.units += t.units;
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
   }
@@ -158,10 +160,16 @@ void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, total * sizeof(Fr), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_tasks_.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-  tick("msm", alg);
-  launch_msm(d_tasks_.p, (int)nt, d_wsum_.p, d_part_.p, d_res_.p, stream_);
+  tick("k_msm_accum", alg, (double)total);
+  launch_msm_accum(d_tasks_.p, (int)nt, d_wsum_.p, stream_);
   tock();
-  tick("finalize", 0);
+  tick("k_msm_tail", 0, (double)nt * 8);
+  launch_msm_tail(d_wsum_.p, d_part_.p, (int)nt * 8, 8, 4, stream_);
+  tock();
+  tick("k_msm_tail", 0, (double)nt);
+  launch_msm_tail(d_part_.p, d_res_.p, (int)nt, 8, 32, stream_);
+  tock();
+  tick("k_finalize", 0, (double)nt);
   launch_finalize(d_res_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
   tock();
   if (comp_out) {
@@ -186,7 +194,7 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
   // did not synchronise; every phase ends with a synchronising D2H or the explicit sync below.
   CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, nscalars * sizeof(Fr), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_stasks_.p, ht, tasks.size() * sizeof(SmulTask), hipMemcpyHostToDevice, stream_));
-  tick("smul", alg_bytes);
+  tick("k_smul", alg_bytes, (double)tasks.size() * cnt);
   launch_smul(d_stasks_.p, (int)tasks.size(), cnt, stream_);
   tock();
   CPX_HIP(hipStreamSynchronize(stream_));   // staging buffer reuse safety
@@ -260,9 +268,11 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   }
   MsmTask t{db.p, nullptr, ds.p, (uint32_t)n, 0};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
-  tick("msm", 128.0 * n);
-  launch_msm(dt.p, 1, w.p, pt.p, res.p, stream_);
+  tick("k_msm_accum", 128.0 * n, (double)n);
+  launch_msm_accum(dt.p, 1, w.p, stream_);
   tock();
+  launch_msm_tail(w.p, pt.p, 8, 8, 4, stream_);
+  launch_msm_tail(pt.p, res.p, 1, 8, 32, stream_);
   CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
   flush_timers();
@@ -302,7 +312,7 @@ void Engine::fold(uint8_t* PL, const uint8_t* PR, const uint8_t* gamma, size_t h
   CPX_HIP(hipMemcpyAsync(dg.p, gamma, sizeof(Fr), hipMemcpyHostToDevice, stream_));
   SmulTask t{dl.p, dr.p, dl.p, dg.p, 0, 0};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
-  tick("smul", 288.0 * half);
+  tick("k_smul", 288.0 * half, (double)half);
   launch_smul(dt.p, 1, (int)half, stream_);
   tock();
   CPX_HIP(hipMemcpyAsync(PL, dl.p, half * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
@@ -324,7 +334,7 @@ void Engine::scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_strid
   CPX_HIP(hipMemcpyAsync(dsc.p, scalars, ns * sizeof(Fr), hipMemcpyHostToDevice, stream_));
   SmulTask t{nullptr, dp.p, dout.p, dsc.p, scalar_stride ? 1u : 0u, 0};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
-  tick("smul", 224.0 * n);
+  tick("k_smul", 224.0 * n, (double)n);
   launch_smul(dt.p, 1, (int)n, stream_);
   tock();
   CPX_HIP(hipMemcpyAsync(out, dout.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
@@ -456,7 +466,7 @@ void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const
   std::vector<uint8_t> inst_comp(B * 4 * ell * 48);
   {
     d_bytes_.ensure(B * 4 * ell * 48);
-    tick("compress", 0);
+    tick("k_compress", 0, (double)(4 * ell * B));
     launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
     tock();
     d_res_.ensure(B);
@@ -935,11 +945,11 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     d_status_.ensure(dst.size());
     CPX_HIP(hipMemcpyAsync(d_in.p, pts.data(), pts.size(), hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_dst.p, dst.data(), dst.size() * 4, hipMemcpyHostToDevice, stream_));
-    tick("decompress", 0);
+    tick("k_decompress", 0, (double)dst.size());
     launch_decompress(d_in.p, (int)dst.size(), d_pp_.p, d_dst.p, d_status_.p, 1, stream_);
     tock();
     d_bytes_.ensure(B * 4 * ell * 48);
-    tick("compress", 0);
+    tick("k_compress", 0, (double)(4 * ell * B));
     launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
     tock();
     d_dst_.ensure(B);

@@ -60,6 +60,7 @@ struct KernelStat {
   uint64_t launches = 0;
   double ms = 0;
   double alg_bytes = 0;   // algorithmic bytes moved (SURVEY §8d accounting)
+  double units = 0;       // MSM points / scalar-mul elements / points processed
 };
 
 
@@ -112,13 +113,13 @@ class Engine {
   struct Timed {
     hipEvent_t a, b;
     std::string name;
-    double bytes;
+    double bytes, units;
   };
 
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
   void run_smul(const std::vector<SmulTask>& tasks, int cnt, const host::S* scalars, size_t nscalars, double alg_bytes);
   const uint32_t* idx_list(const std::vector<uint32_t>& v);
-  void tick(const char* name, double bytes);
+  void tick(const char* name, double bytes, double units);
   void tock();
   void flush_timers();
   template <class F> void parallel_for(size_t n, F&& f);

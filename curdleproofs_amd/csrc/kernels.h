@@ -27,8 +27,10 @@ struct SmulTask {
   uint32_t flags;
 };
 
-// ntasks MSMs -> d_out[ntasks] Jacobian.  d_wsum: ntasks*64 Jac scratch, d_part: ntasks*8 Jac scratch.
-void launch_msm(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, Jac* d_part, Jac* d_out, hipStream_t s);
+// ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian) ...
+void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream_t s);
+// ... then Horner tails: out[t] = sum_{j<group} 2^(shift*j) in[t*group+j]; (8,4) then (8,32) gives the MSM results
+void launch_msm_tail(const Jac* d_in, Jac* d_out, int nout, int group, int shift, hipStream_t s);
 // Jacobian -> affine (+ optional scatter through dst_index) and optional 48-byte compressed form.
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
 // `batch` rows of n points, row r starting at d_in + r*stride; output dense [batch][n][48]

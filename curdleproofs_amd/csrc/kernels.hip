@@ -322,12 +322,13 @@ __global__ __launch_bounds__(256) void k_bench_fpmul(Fp* data, int iters) {
 }
 
 // ------------------------------------------------------------------ host-callable launchers
-void launch_msm(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, Jac* d_part, Jac* d_out, hipStream_t s) {
+void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream_t s) {
   if (ntasks <= 0) return;
   hipLaunchKernelGGL(k_msm_accum, dim3(ntasks), dim3(MSM_THREADS), MSM_LDS_BYTES, s, d_tasks, d_wsum);
-  const int n1 = ntasks * 8;
-  hipLaunchKernelGGL(k_msm_tail, dim3((n1 + 63) / 64), dim3(64), 0, s, d_wsum, d_part, n1, 8, 4);
-  hipLaunchKernelGGL(k_msm_tail, dim3((ntasks + 63) / 64), dim3(64), 0, s, d_part, d_out, ntasks, 8, 32);
+}
+void launch_msm_tail(const Jac* d_in, Jac* d_out, int nout, int group, int shift, hipStream_t s) {
+  if (nout <= 0) return;
+  hipLaunchKernelGGL(k_msm_tail, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, nout, group, shift);
 }
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
   if (n <= 0) return;

@@ -100,8 +100,9 @@ int cpx_batch_verify(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, i
 /* ---- measurement --------------------------------------------------------------------------- */
 int cpx_set_profiling(cpx_ctx* ctx, int on); /* time every kernel group with HIP events on the ctx stream */
 int cpx_reset_stats(cpx_ctx* ctx);
-/* name in {"msm","smul","finalize","compress","decompress"}; any out pointer may be NULL */
-int cpx_get_stat(const cpx_ctx* ctx, const char* name, uint64_t* launches, double* total_ms, double* algorithmic_bytes);
+/* name = kernel name as rocprofv3 reports it: "k_msm_accum", "k_msm_tail", "k_smul", "k_finalize",
+ * "k_compress", "k_decompress"; units = MSM points / scalar-mul elements / points; out pointers may be NULL */
+int cpx_get_stat(const cpx_ctx* ctx, const char* name, uint64_t* launches, double* total_ms, double* algorithmic_bytes, double* units);
 int cpx_set_host_threads(cpx_ctx* ctx, int threads);
 /* dependent Fp multiply chains: returns achieved Fp products per second */
 int cpx_bench_fpmul(cpx_ctx* ctx, int blocks, int iters, int reps, double* products_per_second);

@@ -63,10 +63,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
+    path = os.environ.get("CPX_LIB", _LIB_PATH)   # CPX_LIB: experimental build variant for A/B runs
+    if not os.path.exists(path):
         raise ImportError("curdleproofs_amd: %s is missing — build it with `python -m curdleproofs_amd.build` "
                           "(hipcc, gfx950). There is no CPU fallback." % _LIB_PATH)
-    L = ctypes.CDLL(_LIB_PATH)
+    L = ctypes.CDLL(path)
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     L.cpx_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.cpx_ctx_destroy.argtypes = [vp]

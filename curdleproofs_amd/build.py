@@ -34,6 +34,19 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines, verbose=False):
+    """Builds an experimental variant libcpx_<name>.so with extra -D flags (A/B runs; select it at load
+    time with the CPX_LIB environment variable)."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    out = os.path.join(OUT_DIR, "libcpx_%s.so" % name)
+    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-shared", "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out, "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB

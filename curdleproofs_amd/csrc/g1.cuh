@@ -9,6 +9,15 @@
 #pragma once
 #include "mont32.cuh"
 
+// Point formulas: inlined into the kernels by default so that a kernel's __launch_bounds__ governs their
+// register budget (a non-kernel function is compiled for the maximum budget: 248 VGPRs here, which pins
+// every caller at 2 waves per SIMD).  -DCPX_PT_NOINLINE restores real calls for A/B runs.
+#if defined(CPX_PT_NOINLINE)
+#define CPX_PT_FN CPX_HD_FN
+#else
+#define CPX_PT_FN CPX_HD
+#endif
+
 namespace cpx {
 
 struct Aff {
@@ -44,7 +53,7 @@ CPX_HD Aff aff_cneg(const Aff& p, bool neg) {
 CPX_HD Jac jac_neg(const Jac& p) { return Jac{p.x, fe_neg(p.y), p.z}; }
 
 // dbl-2009-l (a = 0): 2M + 5S
-CPX_HD_FN Jac jac_dbl(const Jac& p) {
+CPX_PT_FN Jac jac_dbl(const Jac& p) {
   // Z = 0 stays 0 through the formula (Z3 = 2*Y*Z), so no identity branch is needed.
   Fp A = fe_sqr(p.x), B = fe_sqr(p.y), C = fe_sqr(B);
   Fp D = fe_sub(fe_sub(fe_sqr(fe_add(p.x, B)), A), C);
@@ -59,7 +68,7 @@ CPX_HD_FN Jac jac_dbl(const Jac& p) {
 }
 
 // madd-2007-bl: 7M + 4S; complete
-CPX_HD_FN Jac jac_add_mixed(const Jac& p, const Aff& q) {
+CPX_PT_FN Jac jac_add_mixed(const Jac& p, const Aff& q) {
   if (q.is_identity()) return p;
   if (p.is_identity()) return Jac::from_affine(q);
   Fp z1z1 = fe_sqr(p.z);
@@ -84,7 +93,7 @@ CPX_HD_FN Jac jac_add_mixed(const Jac& p, const Aff& q) {
 }
 
 // add-2007-bl: 11M + 5S; complete
-CPX_HD_FN Jac jac_add(const Jac& p, const Jac& q) {
+CPX_PT_FN Jac jac_add(const Jac& p, const Jac& q) {
   if (p.is_identity()) return q;
   if (q.is_identity()) return p;
   Fp z1z1 = fe_sqr(p.z), z2z2 = fe_sqr(q.z);
@@ -106,6 +115,13 @@ CPX_HD_FN Jac jac_add(const Jac& p, const Jac& q) {
   r.z = fe_mul(fe_sub(fe_sub(fe_sqr(fe_add(p.z, q.z)), z1z1), z2z2), h);
   return r;
 }
+
+// Real-call versions of the three formulas.  k_smul uses these: with the formulas inlined, hipcc (ROCm 7.2)
+// miscompiles that kernel at register budgets above 128 VGPRs (every fold/scale parity test fails, with
+// or without the inline-asm multiply) while the called form is bit-exact; see DESIGN.md "toolchain notes".
+CPX_HD_FN Jac jac_dbl_fn(const Jac& p) { return jac_dbl(p); }
+CPX_HD_FN Jac jac_add_mixed_fn(const Jac& p, const Aff& q) { return jac_add_mixed(p, q); }
+CPX_HD_FN Jac jac_add_fn(const Jac& p, const Jac& q) { return jac_add(p, q); }
 
 // Jacobian -> affine given zinv = Z^-1 (caller handles identity)
 CPX_HD Aff jac_to_affine_with_zinv(const Jac& p, const Fp& zinv) {

@@ -89,7 +89,10 @@ constexpr int MSM_THREADS = 512;
 constexpr int MSM_CHUNK = 256;
 constexpr int MSM_LDS_BYTES = 512 * (int)sizeof(Jac);   // 73,728 B >= 64*256 + 256*96 = 40,960 B
 
-__global__ __launch_bounds__(MSM_THREADS) void k_msm_accum(const MsmTask* __restrict__ tasks, Jac* __restrict__ wsum) {
+#ifndef CPX_MSM_WAVES
+#define CPX_MSM_WAVES 2   // waves per SIMD the register allocator must leave room for (2 = one 512-thread group per CU)
+#endif
+__global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const MsmTask* __restrict__ tasks, Jac* __restrict__ wsum) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int8_t* digits = reinterpret_cast<int8_t*>(smem);                       // [64][MSM_CHUNK]
   Aff* pts = reinterpret_cast<Aff*>(smem + 64 * MSM_CHUNK);               // [MSM_CHUNK]
@@ -134,15 +137,33 @@ __global__ __launch_bounds__(MSM_THREADS) void k_msm_accum(const MsmTask* __rest
   __syncthreads();
   buckets[tid] = acc;
   __syncthreads();
-  if (tid < 64) {
-    // window tid: sum_{b=1..8} b * B_b by the running-sum trick, one full wave, no idle lanes
-    Jac run = Jac::identity(), tot = Jac::identity();
-    for (int b = 7; b >= 0; b--) {
-      run = jac_add(run, buckets[tid * 8 + b]);
-      tot = jac_add(tot, run);
+  // Window sum  sum_{b=1..8} b * B_b  =  sum_b (suffix sum of B from b): a Hillis-Steele suffix scan over the
+  // window's 8 lanes (3 steps) followed by a tree sum (3 steps) — 6 point additions with every wave of the
+  // work-group busy, instead of 16 on one wave with seven waves idle.
+  const int b = tid & 7;
+  for (int sft = 1; sft < 8; sft <<= 1) {
+    const bool has = b + sft < 8;
+    Jac other;
+    if (has) other = buckets[tid + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      buckets[tid] = acc;
     }
-    wsum[(size_t)blockIdx.x * 64 + tid] = tot;
+    __syncthreads();
   }
+  for (int sft = 4; sft >= 1; sft >>= 1) {
+    const bool has = b < sft;
+    Jac other;
+    if (has) other = buckets[tid + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      buckets[tid] = acc;
+    }
+    __syncthreads();
+  }
+  if (b == 0) wsum[(size_t)blockIdx.x * 64 + w] = acc;
 }
 
 // ------------------------------------------------------------------ MSM: Horner tails
@@ -192,7 +213,10 @@ __global__ __launch_bounds__(256) void k_compress(const Aff* __restrict__ in, in
 // 96-byte point loads/stores of a wave are contiguous.
 constexpr int SMUL_THREADS = 256;
 
-__global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
+#ifndef CPX_SMUL_WAVES
+#define CPX_SMUL_WAVES 2
+#endif
+__global__ __launch_bounds__(SMUL_THREADS, CPX_SMUL_WAVES) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   Fp* buf = reinterpret_cast<Fp*>(smem);                                             // 2*256 Fp = 24 KB
   uint32_t* naf = reinterpret_cast<uint32_t*>(smem + 2 * SMUL_THREADS * sizeof(Fp));  // [18][256]
@@ -216,14 +240,14 @@ __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restric
     }
     const Aff P = task.mul[e];
     for (int i = 256; i >= 0; i--) {
-      acc = jac_dbl(acc);
+      acc = jac_dbl_fn(acc);
       const uint32_t nzw = naf[(i >> 5) * SMUL_THREADS + tid];
       if ((nzw >> (i & 31)) & 1u) {
         const uint32_t ngw = naf[(9 + (i >> 5)) * SMUL_THREADS + tid];
-        acc = jac_add_mixed(acc, aff_cneg(P, (ngw >> (i & 31)) & 1u));
+        acc = jac_add_mixed_fn(acc, aff_cneg(P, (ngw >> (i & 31)) & 1u));
       }
     }
-    if (task.add) acc = jac_add_mixed(acc, task.add[e]);
+    if (task.add) acc = jac_add_mixed_fn(acc, task.add[e]);
   }
   const bool inf = acc.is_identity();
   Fp zinv = block_batch_inverse(acc.z, buf);

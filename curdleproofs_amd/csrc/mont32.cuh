@@ -153,8 +153,34 @@ template <class C> CPX_HD Fe<C> fe_dbl(const Fe<C>& a) {
   return r;
 }
 
-// Montgomery product a*b*R^-1 mod p.  CIOS, "no-carry" variant (valid because the top bit of the
-// modulus' top limb is clear for both Fp and Fr): 2N multiply-accumulates per outer step.
+// 96-bit column accumulator step: (c2 : acc) += a * b.
+// On gfx950: v_mad_u64_u32 (64-bit accumulate, carry-out to VCC) + v_addc_co_u32 (carry into the third
+// word) — no register shuffling, which is what the compiler's own lowering of 64-bit carry chains drowns
+// in (~1000 v_mov/v_lshl_add_u64 per product).  gfx950 needs 2 wait states between a VALU that writes VCC
+// and a VALU that reads it as carry-in; hipcc pads nothing inside an asm string, hence the s_nop 1.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CPX_MAC_V(acc, c2, a, b) \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(c2) : "v"(a), "v"(b) : "vcc")
+#define CPX_MAC_S(acc, c2, a, b) \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(c2) : "v"(a), "s"(b) : "vcc")
+#else
+#define CPX_MAC_V(acc, c2, a, b)                     \
+  do {                                               \
+    uint64_t _p = (uint64_t)(a) * (b);               \
+    (acc) += _p;                                     \
+    (c2) += ((acc) < _p) ? 1u : 0u;                  \
+  } while (0)
+#define CPX_MAC_S(acc, c2, a, b) CPX_MAC_V(acc, c2, a, b)
+#endif
+
+// Montgomery product a*b*R^-1 mod p — finely integrated product scanning (FIPS): column k gathers
+// all a_i*b_(k-i) and m_i*p_(k-i) into a 96-bit accumulator, emits one result limb, shifts by a limb.
+// 2N^2 multiply-accumulates, each a (v_mad_u64_u32, v_addc_co_u32) pair; the modulus limbs sit in SGPRs.
+#ifndef CPX_FE_MUL_VARIANT
+#define CPX_FE_MUL_VARIANT 1
+#endif
+#if CPX_FE_MUL_VARIANT == 0
+// variant 0 (A/B reference): CIOS "no-carry" form, carry chains left to the compiler
 template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
   constexpr int N = C::N;
   uint32_t t[N];
@@ -181,6 +207,39 @@ template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
   fe_reduce_once(r);
   return r;
 }
+#else
+template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
+  constexpr int N = C::N;
+  uint32_t m[N], t[N];
+  uint64_t acc = 0;
+  uint32_t c2 = 0;
+  CPX_UNROLL for (int k = 0; k < N; k++) {
+    CPX_UNROLL for (int i = 0; i < k; i++) {
+      CPX_MAC_V(acc, c2, a.v[i], b.v[k - i]);
+      CPX_MAC_S(acc, c2, m[i], C::P[k - i]);
+    }
+    CPX_MAC_V(acc, c2, a.v[k], b.v[0]);
+    m[k] = (uint32_t)acc * C::INV;
+    CPX_MAC_S(acc, c2, m[k], C::P[0]);
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+    c2 = 0;
+  }
+  CPX_UNROLL for (int k = N; k < 2 * N - 1; k++) {
+    CPX_UNROLL for (int i = k - N + 1; i < N; i++) {
+      CPX_MAC_V(acc, c2, a.v[i], b.v[k - i]);
+      CPX_MAC_S(acc, c2, m[i], C::P[k - i]);
+    }
+    t[k - N] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)c2 << 32);
+    c2 = 0;
+  }
+  t[N - 1] = (uint32_t)acc;   // the top word is zero: result < 2p < 2^(32N)
+  Fe<C> r;
+  CPX_UNROLL for (int i = 0; i < N; i++) r.v[i] = t[i];
+  fe_reduce_once(r);
+  return r;
+}
+#endif
 template <class C> CPX_HD Fe<C> fe_sqr(const Fe<C>& a) { return fe_mul(a, a); }
 
 // Montgomery form -> canonical integer (multiply by 1) and back (multiply by R^2)

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--ell", type=int, default=252)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--ctxs", type=int, default=1, help="engine contexts (HIP streams + host threads) per GPU; the batch is split over them")
     args = ap.parse_args()
 
     import torch
@@ -98,17 +99,47 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import curdleproofs_amd as cpx
-    ctx = cpx.Context(local_rank)          # raises without a GPU: no CPU fallback
-    if args.host_threads:
-        ctx.set_host_threads(args.host_threads)
-    ell, B = args.ell, args.batch
+    import threading
+    ell, B, K = args.ell, args.batch, max(1, args.ctxs)
+    assert B % K == 0, "--batch must be a multiple of --ctxs"
+    ctxs = [cpx.Context(local_rank) for _ in range(K)]          # raises without a GPU: no CPU fallback
+    for c in ctxs:
+        if args.host_threads:
+            c.set_host_threads(args.host_threads)
+    ctx = ctxs[0]
     data = synth_batch(ctx, ell, B, seed=1234 + rank)
-    ctx.load_batch(data["vec_R"], data["vec_S"], data["vec_T"], data["vec_U"], data["M"])   # inputs now resident in HBM
+    # split the batch over the contexts; every context holds the CRS and its share of instances in HBM
+    Bk = B // K
+    n_ = ell + 4
+    def part(buf, unit, k):
+        return buf[k * Bk * unit:(k + 1) * Bk * unit]
+    shares = []
+    for k, c in enumerate(ctxs):
+        if k:
+            c.set_crs(ell, data["crs"])
+        sh = dict(vec_R=part(data["vec_R"], ell * cpx.AFF, k), vec_S=part(data["vec_S"], ell * cpx.AFF, k),
+                  vec_T=part(data["vec_T"], ell * cpx.AFF, k), vec_U=part(data["vec_U"], ell * cpx.AFF, k), M=part(data["M"], cpx.JAC, k),
+                  perms=data["perms"][k * Bk * ell:(k + 1) * Bk * ell], k=part(data["k"], cpx.FR, k), mbl=part(data["mbl"], 4 * cpx.FR, k),
+                  prand=part(data["prand"], (3 * n_ + 9) * cpx.FR, k), vrand=part(data["vrand"], 8 * cpx.FR, k))
+        c.load_batch(sh["vec_R"], sh["vec_S"], sh["vec_T"], sh["vec_U"], sh["M"])   # inputs now resident in HBM
+        shares.append(sh)
+
+    def step_one(k, out):
+        c, sh = ctxs[k], shares[k]
+        proofs = c.prove_batch(sh["perms"], sh["k"], sh["mbl"], sh["prand"])
+        out[k] = (proofs, c.verify_batch(proofs, sh["vrand"]))
 
     def step():
-        proofs = ctx.prove_batch(data["perms"], data["k"], data["mbl"], data["prand"])
-        verdicts = ctx.verify_batch(proofs, data["vrand"])
-        return proofs, verdicts
+        out = [None] * K
+        if K == 1:
+            step_one(0, out)
+        else:
+            th = [threading.Thread(target=step_one, args=(k, out)) for k in range(K)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        return [p for o in out for p in o[0]], [v for o in out for v in o[1]]
 
     def barrier():
         torch.cuda.synchronize()
@@ -118,8 +149,9 @@ def main():
 
     for _ in range(args.warmup):
         proofs, verdicts = step()
-    ctx.set_profiling(True)
-    ctx.reset_stats()
+    for c in ctxs:
+        c.set_profiling(True)
+        c.reset_stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -131,8 +163,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     all_ok = all(v == cpx.CPX_OK for v in verdicts)
-    stats = ctx.stats()
-    ctx.set_profiling(False)
+    stats = {}
+    for c in ctxs:
+        for name, st in c.stats().items():
+            acc = stats.setdefault(name, dict(launches=0, ms=0.0, alg_bytes=0.0, units=0.0))
+            for f in acc:
+                acc[f] += st[f]
+        c.set_profiling(False)
 
     if rank == 0:
         n = ell + 4
@@ -141,7 +178,7 @@ def main():
         b_prove = 128 * (6 * ell + 15 * n + 2) + 288 * 5 * (n - 1) + 224 * n
         b_verify = 128 * (5 * ell + 8) + 10 * L * 176
         value = world * B * args.steps / dt
-        dom = max(("k_msm_accum", "k_smul"), key=lambda k: stats[k]["ms"])
+        dom = max(("k_msm_tblw", "k_msm_tbl", "k_msm_accum", "k_smul"), key=lambda k: stats[k]["ms"])
         st = stats[dom]
         avg_ms = st["ms"] / max(st["launches"], 1)
         bytes_per_launch = st["alg_bytes"] / max(st["launches"], 1)
@@ -157,7 +194,7 @@ def main():
                    config=dict(workload="ell=%d (n=%d, log2 n=%d): %d independent shuffle instances per GPU per step, each proven "
                                         "(CurdleproofsProof::new) then verified; BASELINE configs[1] instance shape, per-GPU share "
                                         "of configs[3]" % (ell, n, L, B),
-                               ell=ell, batch_per_gpu=B, global_batch=B * world, parallelism="proofs sharded over %d GPU(s), no collective" % world),
+                               ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, parallelism="proofs sharded over %d GPU(s), no collective" % world),
                    all_verified=all_ok, algorithmic_bytes_per_proof=b_prove + b_verify,
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items()},

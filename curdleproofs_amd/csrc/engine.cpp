@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 namespace cpx {
@@ -54,6 +55,12 @@ static inline S S_from_wire(const uint8_t* b) {
 Engine::Engine(int device) : device_(device) {
   CPX_HIP(hipSetDevice(device_));
   CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  if (const char* e = getenv("CPX_PROVER")) use_tables_ = std::string(e) != "fold";
+  if (const char* e = getenv("CPX_WAVE_MSM")) wave_msm_ = atoi(e) != 0;
+  if (const char* e = getenv("CPX_TBL_COPIES")) {
+    int c = atoi(e);
+    if (c == 8 || c == 16 || c == 32 || c == 64) copies_ = c;
+  }
 }
 Engine::~Engine() {
   for (auto p : idx_allocs_) (void)hipFree(p);
@@ -200,6 +207,64 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
   CPX_HIP(hipStreamSynchronize(stream_));   // staging buffer reuse safety
 }
 
+// Table-backed MSM phase: every request is one work-group of k_msm_tbl; results are normalised + compressed.
+void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out) {
+  const size_t nt = reqs.size();
+  if (!nt) return;
+  size_t total = 0;
+  for (auto& r : reqs) total += r.seg0.n + r.seg1.n;
+  d_scal_.ensure(total);
+  d_ttasks_.ensure(nt);
+  d_res_.ensure(nt);
+  d_comp_.ensure(nt * 48);
+  h_stage_.ensure(total * sizeof(Fr) + nt * sizeof(TblTask));
+  Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
+  TblTask* ht = reinterpret_cast<TblTask*>(h_stage_.p + total * sizeof(Fr));
+  std::vector<size_t> offs(nt);
+  size_t off = 0;
+  for (size_t i = 0; i < nt; i++) {
+    offs[i] = off;
+    off += reqs[i].seg0.n + reqs[i].seg1.n;
+  }
+  parallel_for(nt, [&](size_t i) {
+    const TblReq& r = reqs[i];
+    Fr* d = hs + offs[i];
+    for (uint32_t j = 0; j < r.seg0.n; j++) d[j] = r.s0[j].f;
+    for (uint32_t j = 0; j < r.seg1.n; j++) d[r.seg0.n + j] = r.s1[j].f;
+    TblTask t;
+    t.seg[0] = r.seg0;
+    t.seg[1] = r.seg1;
+    t.scalars = d_scal_.p + offs[i];
+    t.flags = 0;
+    t.pad = 0;
+    ht[i] = t;
+  });
+  CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, total * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_ttasks_.p, ht, nt * sizeof(TblTask), hipMemcpyHostToDevice, stream_));
+  if (copies_ == 64 && wave_msm_) {
+    d_part_.ensure(nt * 8);
+    tick("k_msm_tblw", 128.0 * total, (double)total);
+    launch_msm_tblw(d_ttasks_.p, (int)nt, d_part_.p, stream_);
+    tock();
+    tick("k_finalize_sum", 0, (double)nt);
+    launch_finalize_sum(d_part_.p, 8, (int)nt, nullptr, nullptr, d_comp_.p, stream_);
+    tock();
+  } else {
+    tick("k_msm_tbl", 128.0 * total, (double)total);
+    launch_msm_tbl(d_ttasks_.p, (int)nt, copies_, d_res_.p, stream_);
+    tock();
+    tick("k_finalize", 0, (double)nt);
+    launch_finalize(d_res_.p, (int)nt, nullptr, nullptr, d_comp_.p, stream_);
+    tock();
+  }
+  if (comp_out) {
+    h_comp_.ensure(nt * 48);
+    CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, nt * 48, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipStreamSynchronize(stream_));
+    comp_out->assign(h_comp_.p, h_comp_.p + nt * 48);
+  }
+}
+
 // ---------------------------------------------------------------- CRS
 void Engine::set_crs(size_t ell, const uint8_t* points) {
   const size_t n = ell + N_BLINDERS;
@@ -243,6 +308,20 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
   launch_compress(d_pp_.p, 1, 1, 1, d_comp_.p, stream_);
   CPX_HIP(hipMemcpyAsync(crs_H_comp_, d_comp_.p, 48, hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
+  // shifted-base table of the CRS: built once per CRS, shared by every proof
+  {
+    const size_t NC = n + 3;
+    d_ctab_.ensure((size_t)copies_ * NC);
+    std::vector<Aff> row(NC);
+    for (size_t i = 0; i < n; i++) row[i] = pts[i];
+    row[n] = pts[n];
+    row[n + 1] = pts[n + 1];
+    row[n + 2] = pts[n + 2];
+    CPX_HIP(hipMemcpy(d_ctab_.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
+    d_tbltmp_.ensure(NC * (size_t)(copies_ - 1));
+    launch_table_build(d_ctab_.p, 1, 0, (int)NC, (int)NC, copies_, d_tbltmp_.p, stream_);
+    CPX_HIP(hipStreamSynchronize(stream_));
+  }
 }
 void Engine::crs_sums(uint8_t* g_sum, uint8_t* h_sum) const {
   memcpy(g_sum, &crs_single_[3], sizeof(Aff));
@@ -407,6 +486,24 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
     CPX_HIP(hipMemcpyAsync(slot(p, SL_H), crs_single_, 5 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
   }
   CPX_HIP(hipMemcpyAsync(d_Mjac_.p, M, batch * sizeof(Jac), hipMemcpyHostToDevice, stream_));
+  if (use_tables_) {
+    // copy 0 of the per-proof tables: M (filled at prove time) | R | S | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
+    const size_t NP = np();
+    d_ptab_.ensure(batch * (size_t)copies_ * NP);
+    d_tbltmp_.ensure(std::max(batch * NP, n_ + 3) * (size_t)(copies_ - 1));
+    std::vector<Aff> tails(8, Aff::identity());
+    tails[2] = crs_single_[0];
+    tails[7] = crs_single_[0];
+    for (size_t p = 0; p < batch; p++) {
+      Aff* t = ptab(p);
+      CPX_HIP(hipMemcpyAsync(t + 1, vec_R + p * vb, vb, hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + ell_, vec_S + p * vb, vb, hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_, vec_T + p * vb, vb, hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_ + ell_, tails.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_ + n_, vec_U + p * vb, vb, hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_ + n_ + ell_, tails.data() + 4, 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+    }
+  }
   CPX_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -419,6 +516,7 @@ struct ProverState {
   SVec factors;
   S alpha_sp, beta_sp, gprod, alpha_g, beta_g, beta_g_inv, r_p, z_ip, alpha_i, beta_i, alpha_m;
   SVec vec_c_blinders, rb_plus_alpha, u;
+  SVec SG, SGp, SM;                 // all-MSM prover: per-original-base fold coefficients (IPA G, IPA G' incl. u, SameMSM)
   SVec scal[8];                     // scalar vectors handed to the device for the current phase
   S gam[2];
   std::vector<uint8_t> comp;        // compressed bytes of every slot (count * 48)
@@ -430,6 +528,12 @@ struct ProverState {
 
 void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   if (!B_) throw std::logic_error("batch_load first");
+  if (use_tables_) batch_prove_tables(permutation, k_in, m_blinders, rand, proofs_out);
+  else batch_prove_fold(permutation, k_in, m_blinders, rand, proofs_out);
+}
+
+// Fold-based prover: mirrors the reference's loop structure (basis folds + shrinking MSMs).
+void Engine::batch_prove_fold(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;
   const SlotMap sm(L);
@@ -861,6 +965,431 @@ void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const
       o += 32;
     };
     for (int q = SL_A; q <= SL_C; q++) pt(q);   // A, cm_T, cm_U, R, S, B, C
+    sc(s.r_p);
+    pt(SL_BC);
+    pt(SL_BD);
+    for (int q = SL_IPA0; q < SL_IPA0 + 4 * (int)L; q++) pt(q);
+    sc(s.c_final);
+    sc(s.d_final);
+    for (int q = sm.CMA1(); q <= sm.CMB2(); q++) pt(q);
+    sc(s.z_k);
+    sc(s.z_t);
+    sc(s.z_u);
+    for (int q = sm.BA(); q < sm.BA() + 3 + 6 * (int)L; q++) pt(q);
+    sc(s.x[0]);
+  });
+  flush_timers();
+}
+
+
+// ---------------------------------------------------------------- all-MSM prover over shifted-base tables
+// Same protocol, same outputs, different evaluation order of the group arithmetic.  The reference folds the
+// bases every round (inner_product_argument.rs:174-179, same_multiscalar_argument.rs:126-131) and takes MSMs
+// over the folded bases.  A folded base is a known linear combination of ORIGINAL bases,
+//     G^(j)_i = sum_t S^(j)_t * G_(t * n/2^j + i),   S^(j)_t = prod_{m<=j} gamma_m^(bit_(j-m) of t)
+// (doc/optimizations.md "IPA verification scalars"), so every cross term L/R of round j is an MSM over the n/2
+// original bases whose index has bit (L-j) set / clear, with scalars  vector_entry * S  (and * u_k for the
+// rescaled basis G' = u o G of grand_product_argument.rs:90-102, which is never materialised).  Likewise every
+// commitment (B, D, cm_T, cm_A, A', ...) expands into an MSM over CRS / instance points.  Hence: no basis
+// folds, no per-round normalisation, every MSM runs on pre-shifted tables (k_msm_tbl) without a doubling tail.
+void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
+  CPX_HIP(hipSetDevice(device_));
+  const size_t B = B_, ell = ell_, n = n_, L = L_;
+  const SlotMap sm(L);
+  const size_t nrand = 3 * n + 9;
+  const int NS = sm.count();
+  const size_t NP = np();
+  std::vector<ProverState> st(B);
+  std::vector<uint8_t> comp;
+  const size_t I_AB = 0, I_CB = 2, I_IR = 6, I_IZ = 6 + n, I_RT = 2 * n + 4, I_RU = 2 * n + 5, I_RA = 2 * n + 6, I_RB = 2 * n + 7,
+               I_RK = 2 * n + 8, I_VR = 2 * n + 9;
+  // table offsets inside a per-proof row
+  const size_t O_M = 0, O_R = 1, O_S = 1 + ell, O_T = 1 + 2 * ell, O_U = 1 + 2 * ell + n;
+  // CRS table indices: G | Hvec at 0..n-1, H at n, G_t at n+1, G_u at n+2
+  const uint32_t* iH = idx_list({(uint32_t)n});
+  const uint32_t* iGt = idx_list({(uint32_t)(n + 1)});
+  const uint32_t* iGu = idx_list({(uint32_t)(n + 2)});
+  std::vector<uint32_t> gb(n);   // SameMSM basis G | Hvec[0..2) | G_t | G_u as CRS-table indices
+  for (size_t i = 0; i < ell + 2; i++) gb[i] = (uint32_t)i;
+  gb[ell + 2] = (uint32_t)(n + 1);
+  gb[ell + 3] = (uint32_t)(n + 2);
+  const uint32_t* iGb = idx_list(gb);
+  std::vector<uint32_t> ap(n + 2);   // A' : G | Hvec | G_t | G_u
+  for (size_t i = 0; i < n; i++) ap[i] = (uint32_t)i;
+  ap[n] = (uint32_t)(n + 1);
+  ap[n + 1] = (uint32_t)(n + 2);
+  const uint32_t* iAp = idx_list(ap);
+  const TblSeg none{nullptr, nullptr, 0, 0};
+
+  // -- P0: compressed instance vectors, M -> affine (into table slot 0), then the per-proof tables
+  std::vector<uint8_t> inst_comp(B * 4 * ell * 48);
+  {
+    d_bytes_.ensure(B * 4 * ell * 48);
+    tick("k_compress", 0, (double)(4 * ell * B));
+    launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
+    tock();
+    d_dst_.ensure(B);
+    d_comp_.ensure(B * 48);
+    std::vector<uint32_t> dst(B);
+    for (size_t p = 0; p < B; p++) dst[p] = (uint32_t)(p * (size_t)copies_ * NP + O_M);
+    CPX_HIP(hipMemcpyAsync(d_dst_.p, dst.data(), B * 4, hipMemcpyHostToDevice, stream_));
+    launch_finalize(d_Mjac_.p, (int)B, d_ptab_.p, d_dst_.p, d_comp_.p, stream_);
+    tick("k_table_build", 0, (double)(B * NP));
+    launch_table_build(d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, d_tbltmp_.p, stream_);
+    tock();
+    std::vector<uint8_t> mcomp(B * 48);
+    CPX_HIP(hipMemcpyAsync(inst_comp.data(), d_bytes_.p, inst_comp.size(), hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(mcomp.data(), d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipStreamSynchronize(stream_));
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      s.rnd = rand + p * nrand * 32;
+      s.comp.assign((size_t)NS * 48, 0);
+      memcpy(&s.comp[SL_M * 48], &mcomp[p * 48], 48);
+      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
+      for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
+      s.tr.append_point_bytes("curdleproofs_step1", &s.comp[SL_M * 48]);
+      s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
+      const uint32_t* perm = permutation + p * ell;
+      s.a_perm.resize(ell);
+      for (size_t i = 0; i < ell; i++) s.a_perm[i] = s.vec_a[perm[i]];
+      const S kk = S_from_wire(k_in + 32 * p), r_k = s.draw(I_RK);
+      // scalar vectors of phase 1
+      s.scal[0] = s.a_perm;                                   // A (and the head of A') over G | Hvec
+      s.scal[0].push_back(s.draw(I_AB));
+      s.scal[0].push_back(s.draw(I_AB + 1));
+      s.scal[0].push_back(S::zero());
+      s.scal[0].push_back(S::zero());
+      s.scal[0].push_back(s.draw(I_RT));                      // ... then r_t on G_t, r_u on G_u for A' (curdleproofs.rs:134)
+      s.scal[0].push_back(s.draw(I_RU));
+      s.scal[1].resize(n);                                    // vec_r of SameMSM: B_a, B_t, B_u
+      for (size_t i = 0; i < n; i++) s.scal[1][i] = s.draw(I_VR + i);
+      s.scal[2] = {s.draw(I_RT), s.draw(I_RU), s.draw(I_RA), s.draw(I_RB)};
+      s.scal[3].resize(ell);                                  // k * a   : cm_T.T_2 = k R + r_t H with R = a x vec_R
+      s.scal[4].resize(ell);                                  // r_k * a : cm_A.T_2 = r_k R + r_a H
+      for (size_t i = 0; i < ell; i++) {
+        s.scal[3][i] = kk * s.vec_a[i];
+        s.scal[4][i] = r_k * s.vec_a[i];
+      }
+    });
+  }
+  auto take = [&](size_t p, int slot_id, size_t req_index) { memcpy(&st[p].comp[(size_t)slot_id * 48], &comp[req_index * 48], 48); };
+
+  // -- P1: everything that depends only on vec_a and the prover's randomness
+  {
+    std::vector<TblReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      const S* rt = &s.scal[2][0];
+      const S* ru = &s.scal[2][1];
+      const S* ra = &s.scal[2][2];
+      const S* rb = &s.scal[2][3];
+      reqs.push_back({cseg(0, (uint32_t)n), s.scal[0].data(), none, nullptr});                       // A
+      reqs.push_back({pseg(p, O_R, (uint32_t)ell), s.vec_a.data(), none, nullptr});                   // R  (curdleproofs.rs:112)
+      reqs.push_back({pseg(p, O_S, (uint32_t)ell), s.vec_a.data(), none, nullptr});                   // S
+      reqs.push_back({cseg(0, (uint32_t)n, iGb), s.scal[1].data(), none, nullptr});                   // B_a (same_multiscalar_argument.rs:80)
+      reqs.push_back({pseg(p, O_T, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_t
+      reqs.push_back({pseg(p, O_U, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_u
+      reqs.push_back({cseg(0, 1, iGt), rt, none, nullptr});                                           // cm_T.T_1 = r_t G_t
+      reqs.push_back({cseg(0, 1, iGu), ru, none, nullptr});                                           // cm_U.T_1
+      reqs.push_back({cseg(0, 1, iGt), ra, none, nullptr});                                           // cm_A.T_1
+      reqs.push_back({cseg(0, 1, iGu), rb, none, nullptr});                                           // cm_B.T_1
+      reqs.push_back({pseg(p, O_R, (uint32_t)ell), s.scal[3].data(), cseg(0, 1, iH), rt});            // cm_T.T_2
+      reqs.push_back({pseg(p, O_S, (uint32_t)ell), s.scal[3].data(), cseg(0, 1, iH), ru});            // cm_U.T_2
+      reqs.push_back({pseg(p, O_R, (uint32_t)ell), s.scal[4].data(), cseg(0, 1, iH), ra});            // cm_A.T_2
+      reqs.push_back({pseg(p, O_S, (uint32_t)ell), s.scal[4].data(), cseg(0, 1, iH), rb});            // cm_B.T_2
+      reqs.push_back({cseg(0, (uint32_t)(n + 2), iAp), s.scal[0].data(), none, nullptr});             // A'
+    }
+    run_tbl_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const int ids[15] = {SL_A, SL_R, SL_S, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2(), sm.APRIME()};
+      for (int i = 0; i < 15; i++) take(p, ids[i], p * 15 + i);
+      // same_permutation_argument.rs:60-83
+      s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_A * 48]);
+      s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_M * 48]);
+      s.tr.append_scalar_vec("same_perm_step1", s.vec_a);
+      s.alpha_sp = s.tr.get_and_append_challenge("same_perm_alpha");
+      s.beta_sp = s.tr.get_and_append_challenge("same_perm_beta");
+      const uint32_t* perm = permutation + p * ell;
+      s.factors.resize(ell);
+      s.gprod = S::one();
+      for (size_t i = 0; i < ell; i++) {
+        s.factors[i] = s.a_perm[i] + S::from_u64(perm[i]) * s.alpha_sp + s.beta_sp;
+        s.gprod *= s.factors[i];
+      }
+      // B = A + alpha M + beta * sum(G)  ->  (a' + beta | r_a') over G | Hvec, alpha on M
+      s.scal[5].resize(n);
+      for (size_t i = 0; i < ell; i++) s.scal[5][i] = s.a_perm[i] + s.beta_sp;
+      s.scal[5][ell] = s.draw(I_AB);
+      s.scal[5][ell + 1] = s.draw(I_AB + 1);
+      s.scal[5][ell + 2] = S::zero();
+      s.scal[5][ell + 3] = S::zero();
+      s.scal[6] = {s.alpha_sp};
+    });
+  }
+
+  // -- P2: B
+  {
+    std::vector<TblReq> reqs;
+    for (size_t p = 0; p < B; p++) reqs.push_back({cseg(0, (uint32_t)n), st[p].scal[5].data(), pseg(p, O_M, 1), st[p].scal[6].data()});
+    run_tbl_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      take(p, SL_B, p);
+      s.tr.append_point_bytes("gprod_step1", &s.comp[SL_B * 48]);
+      s.tr.append_scalar("gprod_step1", s.gprod);
+      s.alpha_g = s.tr.get_and_append_challenge("gprod_alpha");
+      s.c.assign(1, S::one());
+      for (size_t i = 0; i + 1 < ell; i++) s.c.push_back(s.c[i] * s.factors[i]);
+      s.vec_c_blinders.resize(N_BLINDERS);
+      for (size_t i = 0; i < N_BLINDERS; i++) s.vec_c_blinders[i] = s.draw(I_CB + i);
+      s.c.insert(s.c.end(), s.vec_c_blinders.begin(), s.vec_c_blinders.end());
+    });
+  }
+
+  // -- P3: C
+  {
+    std::vector<TblReq> reqs;
+    for (size_t p = 0; p < B; p++) reqs.push_back({cseg(0, (uint32_t)n), st[p].c.data(), none, nullptr});
+    run_tbl_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      take(p, SL_C, p);
+      const S mb[4] = {S_from_wire(m_blinders + (p * 4 + 0) * 32), S_from_wire(m_blinders + (p * 4 + 1) * 32),
+                       S_from_wire(m_blinders + (p * 4 + 2) * 32), S_from_wire(m_blinders + (p * 4 + 3) * 32)};
+      const S ab[4] = {s.draw(I_AB), s.draw(I_AB + 1), S::zero(), S::zero()};
+      s.rb_plus_alpha.resize(N_BLINDERS);
+      for (size_t i = 0; i < N_BLINDERS; i++) s.rb_plus_alpha[i] = (ab[i] + s.alpha_sp * mb[i]) + s.alpha_g;
+      s.r_p = host::inner_product(s.rb_plus_alpha.data(), s.vec_c_blinders.data(), N_BLINDERS);
+      s.tr.append_point_bytes("gprod_step2", &s.comp[SL_C * 48]);
+      s.tr.append_scalar("gprod_step2", s.r_p);
+      s.beta_g = s.tr.get_and_append_challenge("gprod_beta");
+      s.beta_g_inv = s.beta_g.inverse();
+      s.u.resize(n);
+      S pw = s.beta_g_inv;
+      for (size_t i = 0; i < ell; i++) {
+        s.u[i] = pw;
+        pw *= s.beta_g_inv;
+      }
+      for (size_t i = ell; i < n; i++) s.u[i] = pw;
+      s.d.resize(n);
+      S pb = s.beta_g, pbm = S::one();
+      for (size_t i = 0; i < ell; i++) {
+        s.d[i] = s.factors[i] * pb - pbm;
+        pbm = pb;
+        pb *= s.beta_g;
+      }
+      const S beta_l1 = pbm * s.beta_g, beta_l = pbm;
+      for (size_t i = 0; i < N_BLINDERS; i++) s.d[ell + i] = beta_l1 * s.rb_plus_alpha[i];
+      s.z_ip = s.r_p * beta_l1 + s.gprod * beta_l - S::one();
+      // D = B - beta^-1 sum(G) + alpha sum(Hvec)  ->  (a' + beta_sp - beta_g^-1 | r_a' + alpha_g) over G | Hvec, alpha_sp on M
+      s.scal[0].resize(n);
+      for (size_t i = 0; i < ell; i++) s.scal[0][i] = s.scal[5][i] - s.beta_g_inv;
+      for (size_t i = ell; i < n; i++) s.scal[0][i] = s.scal[5][i] + s.alpha_g;
+      // generate_ipa_blinders (inner_product_argument.rs:42-82)
+      SVec r(n), zz(n);
+      for (size_t i = 0; i < n; i++) r[i] = s.draw(I_IR + i);
+      for (size_t i = 0; i + 2 < n; i++) zz[i] = s.draw(I_IZ + i);
+      const S omega = host::inner_product(r.data(), s.d.data(), n) + host::inner_product(zz.data(), s.c.data(), n - 2);
+      const S delta = host::inner_product(r.data(), zz.data(), n - 2);
+      const S inv_c = s.c[n - 2].inverse();
+      const S last_z = (r[n - 2] * inv_c * omega - delta) * ((-r[n - 2]) * inv_c * s.c[n - 1] + r[n - 1]).inverse();
+      const S pen_z = (-inv_c) * (last_z * s.c[n - 1] + omega);
+      zz[n - 2] = pen_z;
+      zz[n - 1] = last_z;
+      s.scal[1] = r;                                      // r_c -> B_c over G
+      s.scal[2] = zz;                                     // r_d
+      s.scal[3].resize(n);                                // B_d = msm(G', r_d) = msm(G, r_d o u)
+      for (size_t i = 0; i < n; i++) s.scal[3][i] = zz[i] * s.u[i];
+    });
+  }
+
+  // -- P4: D, B_c, B_d
+  {
+    std::vector<TblReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      reqs.push_back({cseg(0, (uint32_t)n), s.scal[0].data(), pseg(p, O_M, 1), s.scal[6].data()});
+      reqs.push_back({cseg(0, (uint32_t)n), s.scal[1].data(), none, nullptr});
+      reqs.push_back({cseg(0, (uint32_t)n), s.scal[3].data(), none, nullptr});
+    }
+    run_tbl_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      take(p, sm.D(), p * 3);
+      take(p, SL_BC, p * 3 + 1);
+      take(p, SL_BD, p * 3 + 2);
+      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_C * 48]);
+      s.tr.append_point_bytes("ipa_step1", &s.comp[sm.D() * 48]);
+      s.tr.append_scalar("ipa_step1", s.z_ip);
+      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_BC * 48]);
+      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_BD * 48]);
+      s.alpha_i = s.tr.get_and_append_challenge("ipa_alpha");
+      s.beta_i = s.tr.get_and_append_challenge("ipa_beta");
+      for (size_t i = 0; i < n; i++) {
+        s.c[i] = s.scal[1][i] + s.alpha_i * s.c[i];
+        s.d[i] = s.scal[2][i] + s.alpha_i * s.d[i];
+      }
+      s.SG.assign(n, S::one());
+      s.SGp = s.u;
+    });
+  }
+
+  // -- P5: IPA rounds as MSMs over the original bases
+  for (size_t j = 0; j < L; j++) {
+    const size_t half = n >> (j + 1);
+    std::vector<uint32_t> hi, lo;
+    for (size_t k = 0; k < n; k++) ((k & half) ? hi : lo).push_back((uint32_t)k);
+    const uint32_t* d_hi = idx_list(hi);
+    const uint32_t* d_lo = idx_list(lo);
+    const size_t hn = n / 2;
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const S* cL = s.c.data();
+      const S* cR = cL + half;
+      const S* dL = s.d.data();
+      const S* dR = dL + half;
+      for (int q = 0; q < 4; q++) s.scal[q].resize(hn);
+      for (size_t t = 0; t < hn; t++) {
+        const size_t kh = hi[t], kl = lo[t];
+        const size_t ih = kh & (half - 1), il = kl & (half - 1);
+        s.scal[0][t] = cL[ih] * s.SG[kh];     // L_C : G_R with c_L
+        s.scal[1][t] = dR[il] * s.SGp[kl];    // L_D : G'_L with d_R
+        s.scal[2][t] = cR[il] * s.SG[kl];     // R_C : G_L with c_R
+        s.scal[3][t] = dL[ih] * s.SGp[kh];    // R_D : G'_R with d_L
+      }
+      s.scal[4] = {s.beta_i * host::inner_product(cL, dR, half), s.beta_i * host::inner_product(cR, dL, half)};
+    });
+    std::vector<TblReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      reqs.push_back({cseg(0, (uint32_t)hn, d_hi), s.scal[0].data(), cseg(0, 1, iH), &s.scal[4][0]});
+      reqs.push_back({cseg(0, (uint32_t)hn, d_lo), s.scal[1].data(), none, nullptr});
+      reqs.push_back({cseg(0, (uint32_t)hn, d_lo), s.scal[2].data(), cseg(0, 1, iH), &s.scal[4][1]});
+      reqs.push_back({cseg(0, (uint32_t)hn, d_hi), s.scal[3].data(), none, nullptr});
+    }
+    run_tbl_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const int order[4] = {sm.LC((int)j), sm.LD((int)j), sm.RC((int)j), sm.RD((int)j)};
+      for (int q = 0; q < 4; q++) take(p, order[q], p * 4 + q);
+      for (int q : order) s.tr.append_point_bytes("ipa_loop", &s.comp[(size_t)q * 48]);
+      const S gamma = s.tr.get_and_append_challenge("ipa_gamma");
+      const S gamma_inv = gamma.inverse();
+      for (size_t i = 0; i < half; i++) {
+        s.c[i] += gamma_inv * s.c[half + i];
+        s.d[i] += gamma * s.d[half + i];
+      }
+      for (size_t t = 0; t < hn; t++) {
+        s.SG[hi[t]] *= gamma;
+        s.SGp[hi[t]] *= gamma_inv;
+      }
+    });
+  }
+
+  // -- P6 (host only): SameScalar transcript, SameMSM step 1
+  {
+    std::vector<uint8_t> id_comp(48, 0);
+    id_comp[0] = 0xc0;
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      s.c_final = s.c[0];
+      s.d_final = s.d[0];
+      const int pts[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
+      for (int q : pts) s.tr.append_point_bytes("sameexp_points", &s.comp[(size_t)q * 48]);
+      const S alpha = s.tr.get_and_append_challenge("same_scalar_alpha");
+      const S kk = S_from_wire(k_in + 32 * p);
+      s.z_k = s.draw(I_RK) + kk * alpha;
+      s.z_t = s.draw(I_RA) + s.draw(I_RT) * alpha;
+      s.z_u = s.draw(I_RB) + s.draw(I_RU) * alpha;
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.APRIME() * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[SL_CMT2 * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[SL_CMU2 * 48]);
+      std::vector<uint8_t> vb(n * 48);
+      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
+      memcpy(vb.data(), ic + 2 * ell * 48, ell * 48);
+      const uint8_t* tailT[4] = {id_comp.data(), id_comp.data(), crs_H_comp_, id_comp.data()};
+      for (int i = 0; i < 4; i++) memcpy(&vb[(ell + i) * 48], tailT[i], 48);
+      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
+      memcpy(vb.data(), ic + 3 * ell * 48, ell * 48);
+      const uint8_t* tailU[4] = {id_comp.data(), id_comp.data(), id_comp.data(), crs_H_comp_};
+      for (int i = 0; i < 4; i++) memcpy(&vb[(ell + i) * 48], tailU[i], 48);
+      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BA() * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BT() * 48]);
+      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BU() * 48]);
+      s.alpha_m = s.tr.get_and_append_challenge("same_msm_alpha");
+      s.x.resize(n);
+      for (size_t i = 0; i < ell; i++) s.x[i] = s.draw(I_VR + i) + s.alpha_m * s.a_perm[i];
+      s.x[ell] = s.draw(I_VR + ell) + s.alpha_m * s.draw(I_AB);
+      s.x[ell + 1] = s.draw(I_VR + ell + 1) + s.alpha_m * s.draw(I_AB + 1);
+      s.x[ell + 2] = s.draw(I_VR + ell + 2) + s.alpha_m * s.draw(I_RT);
+      s.x[ell + 3] = s.draw(I_VR + ell + 3) + s.alpha_m * s.draw(I_RU);
+      s.SM.assign(n, S::one());
+    });
+  }
+
+  // -- P7: SameMSM rounds
+  for (size_t j = 0; j < L; j++) {
+    const size_t half = n >> (j + 1);
+    std::vector<uint32_t> hi, lo, ghi, glo;
+    for (size_t k = 0; k < n; k++) {
+      ((k & half) ? hi : lo).push_back((uint32_t)k);
+      ((k & half) ? ghi : glo).push_back(gb[k]);
+    }
+    const uint32_t* d_hi = idx_list(hi);
+    const uint32_t* d_lo = idx_list(lo);
+    const uint32_t* d_ghi = idx_list(ghi);
+    const uint32_t* d_glo = idx_list(glo);
+    const size_t hn = n / 2;
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      s.scal[0].resize(hn);
+      s.scal[1].resize(hn);
+      for (size_t t = 0; t < hn; t++) {
+        const size_t kh = hi[t], kl = lo[t];
+        s.scal[0][t] = s.x[kh & (half - 1)] * s.SM[kh];            // L_* : right-half bases with x_L
+        s.scal[1][t] = s.x[(kl & (half - 1)) + half] * s.SM[kl];   // R_* : left-half bases with x_R
+      }
+    });
+    std::vector<TblReq> reqs;
+    for (size_t p = 0; p < B; p++) {
+      ProverState& s = st[p];
+      reqs.push_back({cseg(0, (uint32_t)hn, d_ghi), s.scal[0].data(), none, nullptr});          // L_A
+      reqs.push_back({pseg(p, O_T, (uint32_t)hn, d_hi), s.scal[0].data(), none, nullptr});      // L_T
+      reqs.push_back({pseg(p, O_U, (uint32_t)hn, d_hi), s.scal[0].data(), none, nullptr});      // L_U
+      reqs.push_back({cseg(0, (uint32_t)hn, d_glo), s.scal[1].data(), none, nullptr});          // R_A
+      reqs.push_back({pseg(p, O_T, (uint32_t)hn, d_lo), s.scal[1].data(), none, nullptr});      // R_T
+      reqs.push_back({pseg(p, O_U, (uint32_t)hn, d_lo), s.scal[1].data(), none, nullptr});      // R_U
+    }
+    run_tbl_phase(reqs, &comp);
+    parallel_for(B, [&](size_t p) {
+      ProverState& s = st[p];
+      const int order[6] = {sm.LA((int)j), sm.LT((int)j), sm.LU((int)j), sm.RA((int)j), sm.RT((int)j), sm.RU((int)j)};
+      for (int i = 0; i < 6; i++) take(p, order[i], p * 6 + i);
+      for (int q : order) s.tr.append_point_bytes("same_msm_loop", &s.comp[(size_t)q * 48]);
+      const S gamma = s.tr.get_and_append_challenge("same_msm_gamma");
+      const S gamma_inv = gamma.inverse();
+      for (size_t i = 0; i < half; i++) s.x[i] += gamma_inv * s.x[half + i];
+      for (size_t t = 0; t < hn; t++) s.SM[hi[t]] *= gamma;
+    });
+  }
+
+  // -- serialise (identical to the fold prover)
+  const size_t psz = proof_size();
+  parallel_for(B, [&](size_t p) {
+    ProverState& s = st[p];
+    uint8_t* o = proofs_out + p * psz;
+    auto pt = [&](int slot_id) {
+      memcpy(o, &s.comp[(size_t)slot_id * 48], 48);
+      o += 48;
+    };
+    auto sc = [&](const S& x) {
+      x.to_le_bytes(o);
+      o += 32;
+    };
+    for (int q = SL_A; q <= SL_C; q++) pt(q);
     sc(s.r_p);
     pt(SL_BC);
     pt(SL_BD);

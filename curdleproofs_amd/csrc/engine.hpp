@@ -110,6 +110,13 @@ class Engine {
     uint32_t n;
     uint32_t dst;             // index into d_pp_ (Aff units) receiving the affine result
   };
+  // table-backed MSM request: up to two base segments, each with its own host scalar vector
+  struct TblReq {
+    TblSeg seg0;
+    const host::S* s0;
+    TblSeg seg1;
+    const host::S* s1;
+  };
   struct Timed {
     hipEvent_t a, b;
     std::string name;
@@ -117,6 +124,9 @@ class Engine {
   };
 
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
+  void run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out);
+  void batch_prove_fold(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
+  void batch_prove_tables(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   void run_smul(const std::vector<SmulTask>& tasks, int cnt, const host::S* scalars, size_t nscalars, double alg_bytes);
   const uint32_t* idx_list(const std::vector<uint32_t>& v);
   void tick(const char* name, double bytes, double units);
@@ -124,6 +134,11 @@ class Engine {
   void flush_timers();
   template <class F> void parallel_for(size_t n, F&& f);
 
+  // per-proof table row: copy-major [copies][NP], NP = 1 + 2 ell + 2 n : M | R | S | T_b | U_b
+  size_t np() const { return 1 + 2 * ell_ + 2 * n_; }
+  Aff* ptab(size_t p) const { return d_ptab_.p + p * (size_t)copies_ * np(); }
+  TblSeg pseg(size_t p, size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ptab(p) + off, idx, (uint32_t)np(), cnt}; }
+  TblSeg cseg(size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{d_ctab_.p + off, idx, (uint32_t)(n_ + 3), cnt}; }
   Aff* pp(size_t p) const { return d_pp_.p + p * pp_stride_; }
   Aff* slot(size_t p, int s) const { return pp(p) + 4 * ell_ + s; }
   uint32_t slot_index(size_t p, int s) const { return (uint32_t)(p * pp_stride_ + 4 * ell_ + s); }
@@ -141,6 +156,15 @@ class Engine {
   DevBuf<Aff> d_crs_gb_;     // [n]   G | Hvec[0..2) | G_t | G_u   (SameMSM basis)
   Aff crs_single_[5];        // H, G_t, G_u, G_sum, H_sum (host copies)
   uint8_t crs_H_comp_[48];
+
+  // shifted-base tables (all-MSM prover)
+  int copies_ = 64;          // table copies per base: 2^(256/copies * c) P, c < copies
+  bool wave_msm_ = true;     // 64-copy tables: barrier-free one-wave-per-8-windows MSM kernel
+  bool use_tables_ = true;
+  DevBuf<Aff> d_ctab_;       // CRS table [copies][n+3] : G | Hvec | H | G_t | G_u
+  DevBuf<Aff> d_ptab_;       // per-proof tables [B][copies][NP]
+  DevBuf<TblTmp> d_tbltmp_;
+  DevBuf<TblTask> d_ttasks_;
 
   // batch
   size_t B_ = 0;

@@ -27,6 +27,35 @@ struct SmulTask {
   uint32_t flags;
 };
 
+// ---- table-backed MSM (no doubling tails) ----
+// A table holds, for every base point P_i, the affine copies 2^(sb*c) * P_i, c = 0..C-1, sb = 256/C,
+// copy-major: entry (c, i) at base + c*copy_stride + i.  With C copies a 256-bit scalar splits into C chunks
+// of sb bits, so the 64 radix-16 windows need only q = 64/C in-kernel Horner steps (none at C = 64).
+struct TblSeg {
+  const Aff* base;          // copy 0
+  const uint32_t* idx;      // optional gather list (indices within a copy)
+  uint32_t copy_stride;     // in Aff units
+  uint32_t n;
+};
+struct TblTask {
+  TblSeg seg[2];            // bases = seg[0] followed by seg[1]
+  const Fr* scalars;        // seg[0].n + seg[1].n scalars
+  uint32_t flags;
+  uint32_t pad;
+};
+struct TblTmp {   // table-build scratch: a Jacobian copy and the running product of the previous copies' Z
+  Jac p;
+  Fp pre;
+};
+// one work-group per task -> d_out[task] (Jacobian)
+void launch_msm_tbl(const TblTask* d_tasks, int ntasks, int copies, Jac* d_out, hipStream_t s);
+// 64-copy tables only: single-wave work-groups, 8 per task -> d_part[task*8 + j]; sum them with launch_finalize_sum
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, Jac* d_part, hipStream_t s);
+void launch_finalize_sum(const Jac* d_part, int group, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
+// In place: for `rows` rows of `npts` points (row r at table + r*row_stride, copy 0 filled by the caller) writes
+// copies 1..C-1.  d_tmp: rows*npts*(C-1) TblTmp scratch.
+void launch_table_build(Aff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, TblTmp* d_tmp, hipStream_t s);
+
 // ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian) ...
 void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream_t s);
 // ... then Horner tails: out[t] = sum_{j<group} 2^(shift*j) in[t*group+j]; (8,4) then (8,32) gives the MSM results

@@ -166,6 +166,280 @@ __global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const 
   if (b == 0) wsum[(size_t)blockIdx.x * 64 + w] = acc;
 }
 
+// ------------------------------------------------------------------ table-backed MSM
+// Same thread <-> (window, bucket) ownership as k_msm_accum, but window w reads the pre-shifted copy
+// c = w / q of each base (q = 64 / copies windows share a copy), so the 64 window sums need only q-1 Horner
+// steps of 4 doublings — none at 64 copies — instead of the 252-doubling tail.  Points come straight from the
+// table in HBM/L2 (one 96-byte gather per digit addition, prefetched one match ahead); only the digit rows
+// are staged in LDS.  The reduction (copies tree -> bucket suffix-sum/tree -> short Horner) runs in-kernel.
+constexpr int TBL_CHUNK = 256;
+
+__device__ __forceinline__ const Aff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
+  const uint32_t n0 = t.seg[0].n;
+  const TblSeg& sg = (g < n0) ? t.seg[0] : t.seg[1];
+  const uint32_t i = (g < n0) ? g : g - n0;
+  return sg.base + (size_t)copy * sg.copy_stride + (sg.idx ? sg.idx[i] : i);
+}
+
+__global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_tbl(const TblTask* __restrict__ tasks, int q, Jac* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [64][TBL_CHUNK]
+  Jac* buckets = reinterpret_cast<Jac*>(smem);        // [512] (aliases the digits later)
+  const TblTask task = tasks[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int w = tid >> 3, mag = (tid & 7) + 1;
+  const uint32_t copy = (uint32_t)(w / q);
+  const uint32_t ntot = task.seg[0].n + task.seg[1].n;
+  Jac acc = Jac::identity();
+
+  for (uint32_t base = 0; base < ntot; base += TBL_CHUNK) {
+    const int m = min((uint32_t)TBL_CHUNK, ntot - base);
+    __syncthreads();
+    if (tid < m) {
+      Fr k = task.scalars[base + tid];
+      if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
+      recode_signed16(k.v, digits + tid, TBL_CHUNK);
+    }
+    __syncthreads();
+    const int8_t* row = digits + w * TBL_CHUNK;
+    // software pipeline: locate + fetch the next matching point while the current addition runs
+    int i = 0, d = 0;
+    while (i < m) {
+      d = row[i];
+      if (d == mag || d == -mag) break;
+      i++;
+    }
+    bool have = i < m;
+    Aff cur = Aff::identity();
+    bool cur_neg = false;
+    if (have) {
+      cur = *tbl_point(task, base + i, copy);
+      cur_neg = d < 0;
+      i++;
+    }
+    while (__any(have)) {
+      int d2 = 0;
+      while (i < m) {
+        d2 = row[i];
+        if (d2 == mag || d2 == -mag) break;
+        i++;
+      }
+      const bool have2 = have && i < m;
+      Aff nxt = Aff::identity();
+      if (have2) nxt = *tbl_point(task, base + i, copy);
+      if (have) acc = jac_add_mixed(acc, aff_cneg(cur, cur_neg));
+      cur = nxt;
+      cur_neg = d2 < 0;
+      have = have2;
+      i++;
+    }
+  }
+  __syncthreads();
+  buckets[tid] = acc;
+  __syncthreads();
+  // (1) sum the copies: threads (copy, w', b) with the same (w', b) are q*8 apart
+  const int lane_span = q * 8;                      // threads per copy
+  for (int half = (MSM_THREADS / lane_span) >> 1; half >= 1; half >>= 1) {
+    const bool has = tid < half * lane_span;
+    Jac other;
+    if (has) other = buckets[tid + half * lane_span];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      buckets[tid] = acc;
+    }
+    __syncthreads();
+  }
+  // (2) per remaining window w' < q: sum_b b * B_b  (suffix scan + tree over the 8 bucket lanes)
+  const int b = tid & 7;
+  const bool in_q = tid < lane_span;
+  for (int sft = 1; sft < 8; sft <<= 1) {
+    const bool has = in_q && (b + sft < 8);
+    Jac other;
+    if (has) other = buckets[tid + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      buckets[tid] = acc;
+    }
+    __syncthreads();
+  }
+  for (int sft = 4; sft >= 1; sft >>= 1) {
+    const bool has = in_q && (b < sft);
+    Jac other;
+    if (has) other = buckets[tid + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      buckets[tid] = acc;
+    }
+    __syncthreads();
+  }
+  // (3) Horner over the q window sums (buckets[w' * 8]), 4 doublings per step
+  if (tid == 0) {
+    Jac r = buckets[(q - 1) * 8];
+    for (int wq = q - 2; wq >= 0; wq--) {
+      for (int s4 = 0; s4 < 4; s4++) r = jac_dbl(r);
+      r = jac_add(r, buckets[wq * 8]);
+    }
+    out[blockIdx.x] = r;
+  }
+}
+
+// ------------------------------------------------------------------ table-backed MSM, one wave per 8 windows
+// Barrier-free variant for 64-copy tables (every radix-16 window has its own pre-shifted copy, so all window
+// sums carry weight 1): a single-wave work-group owns windows [8*w8, 8*w8+8) of one task, lane = (window,
+// bucket).  Waves never wait for each other, and the CU scheduler backfills a finished wave's slot with the
+// next one of the grid, which is what keeps both wave slots of a SIMD issuing (PMC: the 8-wave group version
+// idles 67 % of its wave-cycles at barriers / s_waitcnt).  Output: one partial sum per wave; k_finalize_sum
+// adds the 8 partials of a task.
+constexpr int TBW_CHUNK = 256;
+constexpr int TBW_LDS = 64 * (int)sizeof(Jac);   // 9216 B >= 8 * 256 digit bytes
+
+__global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, Jac* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [8][TBW_CHUNK]
+  Jac* red = reinterpret_cast<Jac*>(smem);            // [64] (aliases the digits afterwards)
+  const TblTask task = tasks[blockIdx.x >> 3];
+  const int w8 = blockIdx.x & 7;
+  const int lane = threadIdx.x;
+  const int wl = lane >> 3, mag = (lane & 7) + 1;
+  const uint32_t copy = (uint32_t)(w8 * 8 + wl);
+  const uint32_t ntot = task.seg[0].n + task.seg[1].n;
+  Jac acc = Jac::identity();
+
+  for (uint32_t base = 0; base < ntot; base += TBW_CHUNK) {
+    const int m = min((uint32_t)TBW_CHUNK, ntot - base);
+    __syncthreads();
+    for (int t = lane; t < m; t += 64) {
+      Fr k = task.scalars[base + t];
+      if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
+      int8_t d[64];
+      recode_signed16(k.v, d);
+      CPX_UNROLL for (int j = 0; j < 8; j++) digits[j * TBW_CHUNK + t] = d[w8 * 8 + j];
+    }
+    __syncthreads();
+    const int8_t* row = digits + wl * TBW_CHUNK;
+    int i = 0;
+    for (;;) {
+      int d = 0;
+      while (i < m) {
+        d = row[i];
+        if (d == mag || d == -mag) break;
+        i++;
+      }
+      const bool have = i < m;
+      if (!__any(have)) break;
+      if (have) {
+        const Aff q = *tbl_point(task, base + i, copy);
+        acc = jac_add_mixed(acc, aff_cneg(q, d < 0));
+        i++;
+      }
+    }
+  }
+  __syncthreads();
+  red[lane] = acc;
+  __syncthreads();
+  const int b = lane & 7;
+  for (int sft = 1; sft < 8; sft <<= 1) {           // suffix sums over the 8 bucket lanes of a window
+    const bool has = b + sft < 8;
+    Jac other;
+    if (has) other = red[lane + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  for (int sft = 4; sft >= 1; sft >>= 1) {          // ... summed: sum_b b * B_b in lane b == 0
+    const bool has = b < sft;
+    Jac other;
+    if (has) other = red[lane + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  for (int sft = 32; sft >= 8; sft >>= 1) {         // the wave's 8 window sums (weight 1 each)
+    const bool has = (b == 0) && lane < sft;
+    Jac other;
+    if (has) other = red[lane + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) part[blockIdx.x] = acc;
+}
+
+// Thread per task: add the `group` partial sums of the task, then normalise + compress as k_finalize does.
+__global__ __launch_bounds__(256) void k_finalize_sum(const Jac* __restrict__ part, int group, int n, Aff* __restrict__ out_aff,
+                                                      const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  Fp* buf = reinterpret_cast<Fp*>(smem);
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  Jac p = Jac::identity();
+  if (g < n) {
+    const Jac* src = part + (size_t)g * group;
+    p = src[0];
+    for (int j = 1; j < group; j++) p = jac_add_fn(p, src[j]);
+  }
+  const bool inf = p.is_identity();
+  Fp zinv = block_batch_inverse(p.z, buf);
+  if (g >= n) return;
+  Aff a = inf ? Aff::identity() : jac_to_affine_with_zinv(p, zinv);
+  if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
+  if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
+}
+
+// ------------------------------------------------------------------ table construction
+// Thread per base point: a chain of 256 - sb doublings, storing every sb-th value; the C-1 Jacobian copies
+// are normalised with the thread's own Montgomery trick plus one inversion per work-group.
+__global__ __launch_bounds__(256) void k_table_build(Aff* __restrict__ table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
+                                                     TblTmp* __restrict__ tmp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  Fp* buf = reinterpret_cast<Fp*>(smem);
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)rows * npts;
+  const bool live = g < total;
+  const int sb = 256 / copies;
+  Aff* col = nullptr;
+  TblTmp* mytmp = nullptr;
+  Fp prod = Fp::one();
+  bool inf = true;
+  if (live) {
+    const long r = g / npts, i = g % npts;
+    col = table + r * row_stride + i;
+    mytmp = tmp + g * (copies - 1);
+    const Aff P = *col;
+    inf = P.is_identity();
+    Jac acc = Jac::from_affine(P);
+    for (int c = 1; c < copies; c++) {
+      for (int s = 0; s < sb; s++) acc = jac_dbl_fn(acc);
+      mytmp[c - 1].p = acc;
+      mytmp[c - 1].pre = prod;               // z_1 ... z_{c-1}
+      if (!inf) prod = fe_mul(prod, acc.z);
+    }
+  }
+  Fp inv = block_batch_inverse(prod, buf);   // 1 / (z_1 ... z_{C-1})
+  if (!live) return;
+  for (int c = copies - 1; c >= 1; c--) {
+    Aff a = Aff::identity();
+    if (!inf) {
+      const Jac p = mytmp[c - 1].p;
+      const Fp zinv = fe_mul(inv, mytmp[c - 1].pre);   // inv = 1/(z_1..z_c)
+      inv = fe_mul(inv, p.z);
+      a = jac_to_affine_with_zinv(p, zinv);
+    }
+    col[(size_t)c * copy_stride] = a;
+  }
+}
+
 // ------------------------------------------------------------------ MSM: Horner tails
 // out[t] = sum_{j < group} 2^(shift*j) in[t*group + j], one lane per output.
 __global__ __launch_bounds__(64) void k_msm_tail(const Jac* __restrict__ in, Jac* __restrict__ out, int nout, int group, int shift) {
@@ -353,6 +627,23 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream
 void launch_msm_tail(const Jac* d_in, Jac* d_out, int nout, int group, int shift, hipStream_t s) {
   if (nout <= 0) return;
   hipLaunchKernelGGL(k_msm_tail, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, nout, group, shift);
+}
+void launch_msm_tbl(const TblTask* d_tasks, int ntasks, int copies, Jac* d_out, hipStream_t s) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(k_msm_tbl, dim3(ntasks), dim3(MSM_THREADS), MSM_LDS_BYTES, s, d_tasks, 64 / copies, d_out);
+}
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, Jac* d_part, hipStream_t s) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(k_msm_tblw, dim3(ntasks * 8), dim3(64), TBW_LDS, s, d_tasks, d_part);
+}
+void launch_finalize_sum(const Jac* d_part, int group, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_finalize_sum, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(Fp), s, d_part, group, n, d_aff, d_dst_index, d_comp);
+}
+void launch_table_build(Aff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, TblTmp* d_tmp, hipStream_t s) {
+  const long total = (long)rows * npts;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(k_table_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 2 * 256 * sizeof(Fp), s, d_table, rows, row_stride, npts, copy_stride, copies, d_tmp);
 }
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
   if (n <= 0) return;

@@ -181,7 +181,7 @@ template <class C> CPX_HD Fe<C> fe_dbl(const Fe<C>& a) {
 #endif
 #if CPX_FE_MUL_VARIANT == 0
 // variant 0 (A/B reference): CIOS "no-carry" form, carry chains left to the compiler
-template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
+template <class C> CPX_HD Fe<C> fe_mul_body(const Fe<C>& a, const Fe<C>& b) {
   constexpr int N = C::N;
   uint32_t t[N];
   CPX_UNROLL for (int i = 0; i < N; i++) t[i] = 0;
@@ -208,7 +208,7 @@ template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
   return r;
 }
 #else
-template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
+template <class C> CPX_HD Fe<C> fe_mul_body(const Fe<C>& a, const Fe<C>& b) {
   constexpr int N = C::N;
   uint32_t m[N], t[N];
   uint64_t acc = 0;
@@ -240,6 +240,30 @@ template <class C> CPX_HD_FN Fe<C> fe_mul(const Fe<C> a, const Fe<C> b) {
   return r;
 }
 #endif
+// Out-of-line entry points.  The AMDGPU calling convention passes at most 16 dwords of aggregate arguments in
+// registers; `fe_mul(Fe, Fe)` therefore sent its second operand through scratch memory (store, s_waitcnt
+// vmcnt(0), scratch_load) on EVERY multiplication.  Scalar arguments are not subject to that budget, so the
+// 2 x N limbs travel as 2N u32 register arguments and the result comes back in N registers.
+#define CPX_L12(p) p##0, p##1, p##2, p##3, p##4, p##5, p##6, p##7, p##8, p##9, p##10, p##11
+#define CPX_A12(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, uint32_t p##5, uint32_t p##6, uint32_t p##7, uint32_t p##8, uint32_t p##9, uint32_t p##10, uint32_t p##11
+#define CPX_L8(p) p##0, p##1, p##2, p##3, p##4, p##5, p##6, p##7
+#define CPX_A8(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, uint32_t p##5, uint32_t p##6, uint32_t p##7
+CPX_HD_FN Fe<FpCfg> fe_mul_regs12(CPX_A12(a), CPX_A12(b)) {
+  const Fe<FpCfg> x{{CPX_L12(a)}}, y{{CPX_L12(b)}};
+  return fe_mul_body<FpCfg>(x, y);
+}
+CPX_HD_FN Fe<FrCfg> fe_mul_regs8(CPX_A8(a), CPX_A8(b)) {
+  const Fe<FrCfg> x{{CPX_L8(a)}}, y{{CPX_L8(b)}};
+  return fe_mul_body<FrCfg>(x, y);
+}
+CPX_HD Fe<FpCfg> fe_mul(const Fe<FpCfg>& a, const Fe<FpCfg>& b) {
+  return fe_mul_regs12(a.v[0], a.v[1], a.v[2], a.v[3], a.v[4], a.v[5], a.v[6], a.v[7], a.v[8], a.v[9], a.v[10], a.v[11],
+                       b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7], b.v[8], b.v[9], b.v[10], b.v[11]);
+}
+CPX_HD Fe<FrCfg> fe_mul(const Fe<FrCfg>& a, const Fe<FrCfg>& b) {
+  return fe_mul_regs8(a.v[0], a.v[1], a.v[2], a.v[3], a.v[4], a.v[5], a.v[6], a.v[7],
+                      b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7]);
+}
 template <class C> CPX_HD Fe<C> fe_sqr(const Fe<C>& a) { return fe_mul(a, a); }
 
 // Montgomery form -> canonical integer (multiply by 1) and back (multiply by R^2)

@@ -80,9 +80,9 @@ def cpu_baseline(ell, data, gpu_proof0, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="instances per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (BASELINE configs[3] batch size)")
     ap.add_argument("--ell", type=int, default=252)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)

@@ -108,7 +108,13 @@ def device_count():
 
 
 def _in(b):
+    if isinstance(b, ctypes.Array):   # already marshalled (see Context.marshal): no copy
+        return b
     return (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(bytes(b) if len(b) else b"\0")
+
+
+def _len(b):
+    return ctypes.sizeof(b) if isinstance(b, ctypes.Array) else len(b)
 
 
 def _out(n):
@@ -214,23 +220,35 @@ class Context:
         self._check(self._L.cpx_batch_load(self._h, batch, _in(vec_R), _in(vec_S), _in(vec_T), _in(vec_U), _in(M)))
         self.batch = batch
 
-    def prove_batch(self, permutations, k, vec_m_blinders, rand):
-        """CurdleproofsProof::new for every loaded instance; returns a list of serialized proofs."""
+    @staticmethod
+    def marshal(data):
+        """Pre-marshal a bytes object (or a list of u32 for permutations) into a ctypes buffer once, so that
+        repeated batch calls do not pay Python-side copies."""
+        if isinstance(data, (bytes, bytearray)):
+            return (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) if len(data) else b"\0")
+        return (ctypes.c_uint32 * len(data))(*data)
+
+    def prove_batch(self, permutations, k, vec_m_blinders, rand, raw=False):
+        """CurdleproofsProof::new for every loaded instance; returns a list of serialized proofs
+        (or, with raw=True, the ctypes buffer holding all of them back to back)."""
         B, ell, n = self.batch, self.ell, self.n
-        perm = (ctypes.c_uint32 * (B * ell))(*permutations)
-        assert len(k) == B * FR and len(vec_m_blinders) == B * 4 * FR and len(rand) == B * (3 * n + 9) * FR
+        perm = permutations if isinstance(permutations, ctypes.Array) else (ctypes.c_uint32 * (B * ell))(*permutations)
+        assert _len(k) == B * FR and _len(vec_m_blinders) == B * 4 * FR and _len(rand) == B * (3 * n + 9) * FR
         psz = self.proof_size
         out = _out(B * psz)
         self._check(self._L.cpx_batch_prove(self._h, perm, _in(k), _in(vec_m_blinders), _in(rand), out))
-        raw = bytes(out)
-        return [raw[i * psz:(i + 1) * psz] for i in range(B)]
+        if raw:
+            return out
+        blob = bytes(out)
+        return [blob[i * psz:(i + 1) * psz] for i in range(B)]
 
     def verify_batch(self, proofs, rand):
-        """CurdleproofsProof::verify for every loaded instance; returns a list of CPX_* verdicts."""
+        """CurdleproofsProof::verify for every loaded instance; returns a list of CPX_* verdicts.
+        `proofs`: list of serialized proofs, or the raw buffer prove_batch(raw=True) returned."""
         B = self.batch
         psz = self.proof_size
-        blob = b"".join(proofs)
-        assert len(blob) == B * psz and len(rand) == B * 8 * FR
+        blob = proofs if isinstance(proofs, ctypes.Array) else b"".join(proofs)
+        assert _len(blob) == B * psz and _len(rand) == B * 8 * FR
         verdict = (ctypes.c_int * B)()
         self._check(self._L.cpx_batch_verify(self._h, _in(blob), _in(rand), verdict))
         return list(verdict)

@@ -100,27 +100,85 @@ void Engine::flush_timers() {
   pending_.clear();
 }
 
+WorkerPool::WorkerPool(size_t threads) {
+  for (size_t i = 1; i < threads; i++) threads_.emplace_back([this] { worker(); });
+}
+WorkerPool::~WorkerPool() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_.notify_all();
+  for (auto& t : threads_) t.join();
+}
+void WorkerPool::worker() {
+  uint64_t seen = 0;
+  for (;;) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && job_); });
+    if (stop_) return;
+    seen = epoch_;
+    active_++;
+    while (next_ < n_) {
+      const size_t i = next_++;
+      lk.unlock();
+      try {
+        (*job_)(i);
+      } catch (...) {
+        lk.lock();
+        if (!err_) err_ = std::current_exception();
+        next_ = n_;
+        lk.unlock();
+      }
+      lk.lock();
+    }
+    active_--;
+    if (active_ == 0) done_cv_.notify_all();
+  }
+}
+void WorkerPool::run(size_t n, const std::function<void(size_t)>& f) {
+  if (!n) return;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    job_ = &f;
+    n_ = n;
+    next_ = 0;
+    err_ = nullptr;
+    epoch_++;
+  }
+  cv_.notify_all();
+  std::unique_lock<std::mutex> lk(mu_);
+  active_++;
+  while (next_ < n_) {
+    const size_t i = next_++;
+    lk.unlock();
+    try {
+      f(i);
+    } catch (...) {
+      lk.lock();
+      if (!err_) err_ = std::current_exception();
+      next_ = n_;
+      lk.unlock();
+    }
+    lk.lock();
+  }
+  active_--;
+  done_cv_.wait(lk, [&] { return active_ == 0; });
+  job_ = nullptr;
+  if (err_) std::rethrow_exception(err_);
+}
+
 template <class F> void Engine::parallel_for(size_t n, F&& f) {
-  size_t T = host_threads_ > 0 ? (size_t)host_threads_ : std::min<size_t>(std::thread::hardware_concurrency(), 64);
-  T = std::max<size_t>(1, std::min(T, n));
-  if (T == 1) {
+  if (n <= 1) {
     for (size_t i = 0; i < n; i++) f(i);
     return;
   }
-  std::atomic<size_t> next{0};
-  std::vector<std::thread> th;
-  std::exception_ptr err;
-  std::atomic<bool> failed{false};
-  for (size_t t = 0; t < T; t++)
-    th.emplace_back([&]() {
-      try {
-        for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
-      } catch (...) {
-        if (!failed.exchange(true)) err = std::current_exception();
-      }
-    });
-  for (auto& x : th) x.join();
-  if (failed) std::rethrow_exception(err);
+  if (!pool_) {
+    size_t T = host_threads_ > 0 ? (size_t)host_threads_ : std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 64);
+    pool_.reset(new WorkerPool(T));
+  }
+  const std::function<void(size_t)> fn = [&](size_t i) { f(i); };
+  pool_->run(n, fn);
 }
 
 const uint32_t* Engine::idx_list(const std::vector<uint32_t>& v) {

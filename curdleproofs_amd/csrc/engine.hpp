@@ -7,7 +7,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
+#include <thread>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -64,6 +69,28 @@ struct KernelStat {
 };
 
 
+// Persistent host worker pool: the per-phase Fiat-Shamir / Fr work of a batch is spread over these threads
+// (spawning threads per phase cost ~100 ms per step at 50 phases x 64 threads).
+class WorkerPool {
+ public:
+  explicit WorkerPool(size_t threads);
+  ~WorkerPool();
+  size_t size() const { return threads_.size() + 1; }
+  // runs f(i) for i in [0, n); the calling thread participates; exceptions are rethrown
+  void run(size_t n, const std::function<void(size_t)>& f);
+
+ private:
+  void worker();
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(size_t)>* job_ = nullptr;
+  size_t n_ = 0, next_ = 0, active_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+  std::exception_ptr err_;
+};
+
 class Engine {
  public:
   explicit Engine(int device);
@@ -98,7 +125,10 @@ class Engine {
   void reset_stats() { stats_.clear(); }
   const std::map<std::string, KernelStat>& stats() const { return stats_; }
   double bench_fpmul(int blocks, int iters, int reps);   // returns Fp products per second
-  void set_host_threads(int t) { host_threads_ = t; }
+  void set_host_threads(int t) {
+    host_threads_ = t;
+    pool_.reset();
+  }
   hipStream_t stream() const { return stream_; }
   void sync() { CPX_HIP(hipStreamSynchronize(stream_)); }
 
@@ -147,6 +177,7 @@ class Engine {
   hipStream_t stream_ = nullptr;
   bool profiling_ = false;
   int host_threads_ = 0;
+  std::unique_ptr<WorkerPool> pool_;
   std::map<std::string, KernelStat> stats_;
   std::vector<Timed> pending_;
 

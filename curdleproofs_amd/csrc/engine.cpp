@@ -3,6 +3,7 @@
 #include "engine.hpp"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -111,29 +112,39 @@ WorkerPool::~WorkerPool() {
   cv_.notify_all();
   for (auto& t : threads_) t.join();
 }
+// Items are claimed through an atomic counter in small chunks (no lock on the hot path); the mutex only
+// guards job hand-off and completion.
+void WorkerPool::drain() {
+  const size_t n = n_, chunk = chunk_;
+  for (;;) {
+    const size_t b = next_.fetch_add(chunk, std::memory_order_relaxed);
+    if (b >= n) break;
+    const size_t e = std::min(n, b + chunk);
+    try {
+      for (size_t i = b; i < e; i++) (*job_)(i);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!err_) err_ = std::current_exception();
+      next_.store(n, std::memory_order_relaxed);
+    }
+  }
+}
 void WorkerPool::worker() {
   uint64_t seen = 0;
   for (;;) {
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && job_); });
-    if (stop_) return;
-    seen = epoch_;
-    active_++;
-    while (next_ < n_) {
-      const size_t i = next_++;
-      lk.unlock();
-      try {
-        (*job_)(i);
-      } catch (...) {
-        lk.lock();
-        if (!err_) err_ = std::current_exception();
-        next_ = n_;
-        lk.unlock();
-      }
-      lk.lock();
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && job_); });
+      if (stop_) return;
+      seen = epoch_;
+      active_++;
     }
-    active_--;
-    if (active_ == 0) done_cv_.notify_all();
+    drain();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      active_--;
+      if (active_ == 0) done_cv_.notify_all();
+    }
   }
 }
 void WorkerPool::run(size_t n, const std::function<void(size_t)>& f) {
@@ -142,26 +153,15 @@ void WorkerPool::run(size_t n, const std::function<void(size_t)>& f) {
     std::lock_guard<std::mutex> lk(mu_);
     job_ = &f;
     n_ = n;
-    next_ = 0;
+    chunk_ = std::max<size_t>(1, n / (8 * size()));
+    next_.store(0, std::memory_order_relaxed);
     err_ = nullptr;
     epoch_++;
+    active_++;
   }
   cv_.notify_all();
+  drain();
   std::unique_lock<std::mutex> lk(mu_);
-  active_++;
-  while (next_ < n_) {
-    const size_t i = next_++;
-    lk.unlock();
-    try {
-      f(i);
-    } catch (...) {
-      lk.lock();
-      if (!err_) err_ = std::current_exception();
-      next_ = n_;
-      lk.unlock();
-    }
-    lk.lock();
-  }
   active_--;
   done_cv_.wait(lk, [&] { return active_ == 0; });
   job_ = nullptr;
@@ -178,7 +178,13 @@ template <class F> void Engine::parallel_for(size_t n, F&& f) {
     pool_.reset(new WorkerPool(T));
   }
   const std::function<void(size_t)> fn = [&](size_t i) { f(i); };
+  const auto t0 = std::chrono::steady_clock::now();
   pool_->run(n, fn);
+  if (profiling_) {
+    KernelStat& st = stats_["host_parallel_for"];
+    st.launches++;
+    st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
 }
 
 const uint32_t* Engine::idx_list(const std::vector<uint32_t>& v) {
@@ -318,7 +324,13 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   if (comp_out) {
     h_comp_.ensure(nt * 48);
     CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, nt * 48, hipMemcpyDeviceToHost, stream_));
+    const auto t0 = std::chrono::steady_clock::now();
     CPX_HIP(hipStreamSynchronize(stream_));
+    if (profiling_) {
+      KernelStat& st = stats_["host_wait_device"];
+      st.launches++;
+      st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     comp_out->assign(h_comp_.p, h_comp_.p + nt * 48);
   }
 }

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -81,11 +82,13 @@ class WorkerPool {
 
  private:
   void worker();
+  void drain();
   std::vector<std::thread> threads_;
   std::mutex mu_;
   std::condition_variable cv_, done_cv_;
   const std::function<void(size_t)>* job_ = nullptr;
-  size_t n_ = 0, next_ = 0, active_ = 0;
+  size_t n_ = 0, chunk_ = 1, active_ = 0;
+  std::atomic<size_t> next_{0};
   uint64_t epoch_ = 0;
   bool stop_ = false;
   std::exception_ptr err_;

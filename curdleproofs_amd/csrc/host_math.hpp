@@ -14,6 +14,51 @@
 namespace cpx {
 namespace host {
 
+// ---- host-speed Fr: the same Montgomery residues (R = 2^256) handled as 4 x u64 limbs with 128-bit products.
+// The 8 x u32 little-endian limb array of cpx::Fr and 4 x u64 limbs are the same bytes on a little-endian host.
+namespace fr64 {
+typedef unsigned __int128 u128;
+static constexpr uint64_t P[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+static constexpr uint64_t INV = 0xfffffffeffffffffULL;   // -r^-1 mod 2^64
+inline void mul(const uint32_t* a32, const uint32_t* b32, uint32_t* out32) {
+  uint64_t a[4], b[4], t[6] = {0, 0, 0, 0, 0, 0};
+  memcpy(a, a32, 32);
+  memcpy(b, b32, 32);
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) {
+      c += (u128)a[j] * b[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * INV;
+    c = (u128)m * P[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) {
+      c += (u128)m * P[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  // conditional subtraction
+  uint64_t s[4];
+  u128 bw = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)t[i] - P[i] - (uint64_t)bw;
+    s[i] = (uint64_t)d;
+    bw = (d >> 64) & 1;
+  }
+  const bool ge = t[4] || !bw;
+  memcpy(out32, ge ? s : t, 32);
+}
+}  // namespace fr64
+
 // ---- Fr sugar ----
 struct S {   // a scalar in Montgomery form
   Fr f;
@@ -29,17 +74,33 @@ struct S {   // a scalar in Montgomery form
   }
   S operator+(const S& o) const { return S(fe_add(f, o.f)); }
   S operator-(const S& o) const { return S(fe_sub(f, o.f)); }
-  S operator*(const S& o) const { return S(fe_mul(f, o.f)); }
+  S operator*(const S& o) const {
+    S r;
+    fr64::mul(f.v, o.f.v, r.f.v);
+    return r;
+  }
   S operator-() const { return S(fe_neg(f)); }
   S& operator+=(const S& o) { return *this = *this + o; }
   S& operator*=(const S& o) { return *this = *this * o; }
   bool is_zero() const { return f.is_zero(); }
   bool operator==(const S& o) const { return f.eq(o.f); }
-  S inverse() const { return S(fe_inv(f)); }
-  S pow_u64(uint64_t e) const {
-    uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
-    return S(fe_pow(f, w, 2));
+  S pow_limbs(const uint64_t* e, int nl) const {
+    S r = one();
+    bool started = false;
+    for (int i = nl * 64 - 1; i >= 0; i--) {
+      if (started) r = r * r;
+      if ((e[i >> 6] >> (i & 63)) & 1) {
+        r = started ? r * *this : *this;
+        started = true;
+      }
+    }
+    return r;
   }
+  S inverse() const {   // Fermat, a^(r-2); 0 -> 0
+    const uint64_t e[4] = {fr64::P[0] - 2, fr64::P[1], fr64::P[2], fr64::P[3]};
+    return pow_limbs(e, 4);
+  }
+  S pow_u64(uint64_t e) const { return pow_limbs(&e, 1); }
   void to_le_bytes(uint8_t out[32]) const {   // canonical little-endian (ark-serialize)
     Fr c = fe_from_mont(f);
     memcpy(out, c.v, 32);
@@ -89,20 +150,36 @@ inline void keccak_f1600(uint64_t* a) {
                                   0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
                                   0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
                                   0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-  // rho offsets indexed [x + 5y]
-  static const unsigned RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  uint64_t a00 = a[0], a01 = a[1], a02 = a[2], a03 = a[3], a04 = a[4], a05 = a[5], a06 = a[6], a07 = a[7], a08 = a[8], a09 = a[9],
+           a10 = a[10], a11 = a[11], a12 = a[12], a13 = a[13], a14 = a[14], a15 = a[15], a16 = a[16], a17 = a[17], a18 = a[18],
+           a19 = a[19], a20 = a[20], a21 = a[21], a22 = a[22], a23 = a[23], a24 = a[24];
   for (int r = 0; r < 24; r++) {
-    uint64_t c[5], d[5], b[25];
-    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
-    for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
-    // rho + pi: B[y, 2x+3y] = rot(A[x,y])
-    for (int x = 0; x < 5; x++)
-      for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = RHO[x + 5 * y] ? rol64(a[x + 5 * y], RHO[x + 5 * y]) : a[x + 5 * y];
-    for (int y = 0; y < 5; y++)
-      for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-    a[0] ^= RC[r];
+    // theta
+    const uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,
+                   c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
+    const uint64_t d0 = c4 ^ rol64(c1, 1), d1 = c0 ^ rol64(c2, 1), d2 = c1 ^ rol64(c3, 1), d3 = c2 ^ rol64(c4, 1), d4 = c3 ^ rol64(c0, 1);
+    a00 ^= d0; a05 ^= d0; a10 ^= d0; a15 ^= d0; a20 ^= d0;
+    a01 ^= d1; a06 ^= d1; a11 ^= d1; a16 ^= d1; a21 ^= d1;
+    a02 ^= d2; a07 ^= d2; a12 ^= d2; a17 ^= d2; a22 ^= d2;
+    a03 ^= d3; a08 ^= d3; a13 ^= d3; a18 ^= d3; a23 ^= d3;
+    a04 ^= d4; a09 ^= d4; a14 ^= d4; a19 ^= d4; a24 ^= d4;
+    // rho + pi: B[y + 5*((2x+3y)%5)] = rot(A[x+5y], r[x][y])
+    const uint64_t b00 = a00, b10 = rol64(a01, 1), b20 = rol64(a02, 62), b05 = rol64(a03, 28), b15 = rol64(a04, 27);
+    const uint64_t b16 = rol64(a05, 36), b01 = rol64(a06, 44), b11 = rol64(a07, 6), b21 = rol64(a08, 55), b06 = rol64(a09, 20);
+    const uint64_t b07 = rol64(a10, 3), b17 = rol64(a11, 10), b02 = rol64(a12, 43), b12 = rol64(a13, 25), b22 = rol64(a14, 39);
+    const uint64_t b23 = rol64(a15, 41), b08 = rol64(a16, 45), b18 = rol64(a17, 15), b03 = rol64(a18, 21), b13 = rol64(a19, 8);
+    const uint64_t b14 = rol64(a20, 18), b24 = rol64(a21, 2), b09 = rol64(a22, 61), b19 = rol64(a23, 56), b04 = rol64(a24, 14);
+    // chi
+    a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
+    a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06);
+    a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11);
+    a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);
+    a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);
+    a00 ^= RC[r];
   }
+  a[0] = a00; a[1] = a01; a[2] = a02; a[3] = a03; a[4] = a04; a[5] = a05; a[6] = a06; a[7] = a07; a[8] = a08; a[9] = a09;
+  a[10] = a10; a[11] = a11; a[12] = a12; a[13] = a13; a[14] = a14; a[15] = a15; a[16] = a16; a[17] = a17; a[18] = a18; a[19] = a19;
+  a[20] = a20; a[21] = a21; a[22] = a22; a[23] = a23; a[24] = a24;
 }
 
 class Transcript {   // merlin::Transcript specialised to the operations the protocol performs

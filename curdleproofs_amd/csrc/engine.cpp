@@ -58,6 +58,10 @@ Engine::Engine(int device) : device_(device) {
   CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   if (const char* e = getenv("CPX_PROVER")) use_tables_ = std::string(e) != "fold";
   if (const char* e = getenv("CPX_WAVE_MSM")) wave_msm_ = atoi(e) != 0;
+  if (const char* e = getenv("CPX_FIX_BITS")) {
+    int c = atoi(e);
+    if (c == 0 || c == 8 || c == 16) fix_bits_ = c;
+  }
   if (const char* e = getenv("CPX_TBL_COPIES")) {
     int c = atoi(e);
     if (c == 8 || c == 16 || c == 32 || c == 64) copies_ = c;
@@ -275,45 +279,107 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
 void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out) {
   const size_t nt = reqs.size();
   if (!nt) return;
-  size_t total = 0;
-  for (auto& r : reqs) total += r.seg0.n + r.seg1.n;
-  d_scal_.ensure(total);
-  d_ttasks_.ensure(nt);
-  d_res_.ensure(nt);
-  d_comp_.ensure(nt * 48);
-  h_stage_.ensure(total * sizeof(Fr) + nt * sizeof(TblTask));
-  Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
-  TblTask* ht = reinterpret_cast<TblTask*>(h_stage_.p + total * sizeof(Fr));
-  std::vector<size_t> offs(nt);
-  size_t off = 0;
+  const bool fix = fix_bits_ && d_fixtab_.p && copies_ == 64 && wave_msm_;
+  const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / 8) : 0;
+  const Aff* c_lo = d_ctab_.p;
+  const Aff* c_hi = d_ctab_.p + (size_t)copies_ * (n_ + 3);
+  auto is_crs = [&](const TblSeg& sg) { return fix && sg.n && sg.base >= c_lo && sg.base < c_hi; };
+  // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
+  std::vector<size_t> soff(nt);
+  std::vector<uint32_t> pfirst(nt), pcount(nt), tt_index(nt, ~0u), ft_index(nt * 2, ~0u);
+  size_t total = 0, ntt = 0, nft = 0, nparts = 0;
+  double pts_tbl = 0, pts_fix = 0;
   for (size_t i = 0; i < nt; i++) {
-    offs[i] = off;
-    off += reqs[i].seg0.n + reqs[i].seg1.n;
+    const TblReq& r = reqs[i];
+    soff[i] = total;
+    total += r.seg0.n + r.seg1.n;
+    pfirst[i] = (uint32_t)nparts;
+    const bool f0 = is_crs(r.seg0), f1 = is_crs(r.seg1);
+    const bool need_tbl = (r.seg0.n && !f0) || (r.seg1.n && !f1);
+    if (need_tbl || !fix) {
+      tt_index[i] = (uint32_t)ntt++;
+      nparts += 8;
+    }
+    if (f0) {
+      ft_index[2 * i] = (uint32_t)nft++;
+      nparts += fix_parts;
+    }
+    if (f1) {
+      ft_index[2 * i + 1] = (uint32_t)nft++;
+      nparts += fix_parts;
+    }
+    pcount[i] = (uint32_t)nparts - pfirst[i];
+    pts_fix += (f0 ? r.seg0.n : 0) + (f1 ? r.seg1.n : 0);
+    pts_tbl += (f0 ? 0 : r.seg0.n) + (f1 ? 0 : r.seg1.n);
   }
+  d_scal_.ensure(total);
+  d_ttasks_.ensure(std::max<size_t>(ntt, 1));
+  d_ftasks_.ensure(std::max<size_t>(nft, 1));
+  d_part_.ensure(nparts);
+  d_pfirst_.ensure(nt);
+  d_pcount_.ensure(nt);
+  d_comp_.ensure(nt * 48);
+  const size_t b_scal = total * sizeof(Fr), b_tt = ntt * sizeof(TblTask), b_ft = nft * sizeof(FixTask);
+  h_stage_.ensure(b_scal + b_tt + b_ft + 2 * nt * sizeof(uint32_t));
+  Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
+  TblTask* ht = reinterpret_cast<TblTask*>(h_stage_.p + b_scal);
+  FixTask* hf = reinterpret_cast<FixTask*>(h_stage_.p + b_scal + b_tt);
+  uint32_t* hp = reinterpret_cast<uint32_t*>(h_stage_.p + b_scal + b_tt + b_ft);
+  const TblSeg none{nullptr, nullptr, 0, 0};
   parallel_for(nt, [&](size_t i) {
     const TblReq& r = reqs[i];
-    Fr* d = hs + offs[i];
+    Fr* d = hs + soff[i];
     for (uint32_t j = 0; j < r.seg0.n; j++) d[j] = r.s0[j].f;
     for (uint32_t j = 0; j < r.seg1.n; j++) d[r.seg0.n + j] = r.s1[j].f;
-    TblTask t;
-    t.seg[0] = r.seg0;
-    t.seg[1] = r.seg1;
-    t.scalars = d_scal_.p + offs[i];
-    t.flags = 0;
-    t.pad = 0;
-    ht[i] = t;
+    const bool f0 = is_crs(r.seg0), f1 = is_crs(r.seg1);
+    uint32_t slot = pfirst[i];
+    if (tt_index[i] != ~0u) {
+      TblTask t;
+      // the shifted-table task keeps the scalar layout of the request; fixed-base segments are emptied
+      t.seg[0] = f0 ? TblSeg{r.seg0.base, r.seg0.idx, r.seg0.copy_stride, 0} : r.seg0;
+      t.seg[1] = f1 ? none : r.seg1;
+      t.scalars = d_scal_.p + soff[i] + (f0 ? r.seg0.n : 0);
+      if (f0) {   // seg0 removed: its scalars are skipped, seg1 becomes the only segment
+        t.seg[0] = f1 ? none : r.seg1;
+        t.seg[1] = none;
+      }
+      t.flags = 0;
+      t.pad = slot;
+      ht[tt_index[i]] = t;
+      slot += 8;
+    }
+    if (f0) {
+      hf[ft_index[2 * i]] = FixTask{r.seg0.idx, d_scal_.p + soff[i], (uint32_t)(r.seg0.base - c_lo), r.seg0.n, 0, slot};
+      slot += fix_parts;
+    }
+    if (f1) {
+      hf[ft_index[2 * i + 1]] = FixTask{r.seg1.idx, d_scal_.p + soff[i] + r.seg0.n, (uint32_t)(r.seg1.base - c_lo), r.seg1.n, 0, slot};
+      slot += fix_parts;
+    }
+    hp[i] = pfirst[i];
+    hp[nt + i] = pcount[i];
   });
-  CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, total * sizeof(Fr), hipMemcpyHostToDevice, stream_));
-  CPX_HIP(hipMemcpyAsync(d_ttasks_.p, ht, nt * sizeof(TblTask), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
+  if (ntt) CPX_HIP(hipMemcpyAsync(d_ttasks_.p, ht, b_tt, hipMemcpyHostToDevice, stream_));
+  if (nft) CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_pfirst_.p, hp, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   if (copies_ == 64 && wave_msm_) {
-    d_part_.ensure(nt * 8);
-    tick("k_msm_tblw", 128.0 * total, (double)total);
-    launch_msm_tblw(d_ttasks_.p, (int)nt, d_part_.p, stream_);
-    tock();
-    tick("k_finalize_sum", 0, (double)nt);
-    launch_finalize_sum(d_part_.p, 8, (int)nt, nullptr, nullptr, d_comp_.p, stream_);
+    if (nft) {
+      tick("k_msm_fix", 128.0 * pts_fix, pts_fix);
+      launch_msm_fix(d_ftasks_.p, (int)nft, d_fixtab_.p, fix_bits_, (int)(n_ + 3), d_part_.p, stream_);
+      tock();
+    }
+    if (ntt) {
+      tick("k_msm_tblw", 128.0 * pts_tbl, pts_tbl);
+      launch_msm_tblw(d_ttasks_.p, (int)ntt, d_part_.p, stream_);
+      tock();
+    }
+    tick("k_finalize_ranges", 0, (double)nt);
+    launch_finalize_ranges(d_part_.p, d_pfirst_.p, d_pcount_.p, (int)nt, nullptr, nullptr, d_comp_.p, stream_);
     tock();
   } else {
+    d_res_.ensure(nt);
     tick("k_msm_tbl", 128.0 * total, (double)total);
     launch_msm_tbl(d_ttasks_.p, (int)nt, copies_, d_res_.p, stream_);
     tock();
@@ -391,6 +457,22 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
     d_tbltmp_.ensure(NC * (size_t)(copies_ - 1));
     launch_table_build(d_ctab_.p, 1, 0, (int)NC, (int)NC, copies_, d_tbltmp_.p, stream_);
     CPX_HIP(hipStreamSynchronize(stream_));
+    if (fix_bits_ && use_tables_ && copies_ == 64 && wave_msm_) {
+      // fixed-base table of multiples m * 2^(c w) * P, m <= 2^(c-1): shifted copies first, then the multiples
+      const int W = 256 / fix_bits_;
+      const size_t M = size_t(1) << (fix_bits_ - 1);
+      DevBuf<Aff> d_shift;
+      d_shift.ensure((size_t)W * NC);
+      CPX_HIP(hipMemcpy(d_shift.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
+      d_tbltmp_.ensure(NC * (size_t)(W - 1));
+      launch_table_build(d_shift.p, 1, 0, (int)NC, (int)NC, W, d_tbltmp_.p, stream_);
+      d_fixtab_.ensure((size_t)W * M * NC);
+      const int chunk = (int)std::min<size_t>(256, M);
+      const size_t threads = ((size_t)W * NC + 63) / 64 * 64;
+      d_tbltmp_.ensure(threads * chunk);
+      launch_fix_build(d_shift.p, (int)NC, fix_bits_, d_fixtab_.p, d_tbltmp_.p, chunk, stream_);
+      CPX_HIP(hipStreamSynchronize(stream_));
+    }
   }
 }
 void Engine::crs_sums(uint8_t* g_sum, uint8_t* h_sum) const {

@@ -199,6 +199,10 @@ class Engine {
   DevBuf<Aff> d_ptab_;       // per-proof tables [B][copies][NP]
   DevBuf<TblTmp> d_tbltmp_;
   DevBuf<TblTask> d_ttasks_;
+  int fix_bits_ = 16;        // fixed-base CRS table of multiples: radix 2^16 (13 GB at ell = 252), 2^8 (0.1 GB) or 0 = off
+  DevBuf<Aff> d_fixtab_;     // [256/c][2^(c-1)][n+3]
+  DevBuf<FixTask> d_ftasks_;
+  DevBuf<uint32_t> d_pfirst_, d_pcount_;
 
   // batch
   size_t B_ = 0;

@@ -49,8 +49,28 @@ struct TblTmp {   // table-build scratch: a Jacobian copy and the running produc
 };
 // one work-group per task -> d_out[task] (Jacobian)
 void launch_msm_tbl(const TblTask* d_tasks, int ntasks, int copies, Jac* d_out, hipStream_t s);
+// ---- fixed-base MSM over a table of multiples (CRS bases) ----
+// fix_tab[(w*M + (m-1))*nc + i] = m * 2^(c*w) * P_i  (affine), w < W = 256/c windows, m = 1..M = 2^(c-1), i < nc.
+// A scalar is W signed radix-2^c digits; digit d of window w selects entry |d| directly: one mixed addition per
+// (point, window), no buckets.  One wave handles 8 windows of a task (lane = window x 8 point slices): every lane
+// performs the same number of additions.
+struct FixTask {
+  const uint32_t* idx;      // optional gather list of base indices (< nc)
+  const Fr* scalars;
+  uint32_t off;             // first base index when idx == nullptr
+  uint32_t n;
+  uint32_t flags;
+  uint32_t out_first;       // first partial slot of this task; it writes W/8 partials
+};
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const Aff* d_fix_tab, int cbits, int nc, Jac* d_part, hipStream_t s);
+// shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
+void launch_fix_build(const Aff* d_shift, int nc, int cbits, Aff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
+// output o = sum of partials [first[o], first[o] + count[o]) -> normalised + compressed (+ optional affine scatter)
+void launch_finalize_ranges(const Jac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
+                            uint8_t* d_comp, hipStream_t s);
+
 // 64-copy tables only: single-wave work-groups, 8 per task -> d_part[task*8 + j]; sum them with launch_finalize_sum
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, Jac* d_part, hipStream_t s);
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, Jac* d_part, hipStream_t s);   // task t writes d_part[task.pad + j], j < 8
 void launch_finalize_sum(const Jac* d_part, int group, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
 // In place: for `rows` rows of `npts` points (row r at table + r*row_stride, copy 0 filled by the caller) writes
 // copies 1..C-1.  d_tmp: rows*npts*(C-1) TblTmp scratch.

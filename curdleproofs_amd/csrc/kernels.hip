@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ 
     }
     __syncthreads();
   }
-  if (lane == 0) part[blockIdx.x] = acc;
+  if (lane == 0) part[task.pad + w8] = acc;   // task.pad = first partial slot of the task
 }
 
 // Thread per task: add the `group` partial sums of the task, then normalise + compress as k_finalize does.
@@ -388,6 +388,141 @@ __global__ __launch_bounds__(256) void k_finalize_sum(const Jac* __restrict__ pa
     const Jac* src = part + (size_t)g * group;
     p = src[0];
     for (int j = 1; j < group; j++) p = jac_add_fn(p, src[j]);
+  }
+  const bool inf = p.is_identity();
+  Fp zinv = block_batch_inverse(p.z, buf);
+  if (g >= n) return;
+  Aff a = inf ? Aff::identity() : jac_to_affine_with_zinv(p, zinv);
+  if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
+  if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
+}
+
+// ------------------------------------------------------------------ fixed-base MSM over multiples tables
+constexpr int FIX_CHUNK = 256;
+
+// signed radix-2^c digits (c = 8 or 16) of a canonical scalar; writes the 8 digits of windows [w0, w0+8)
+template <int CB> __device__ __forceinline__ void fix_digits8(const uint32_t* k, int w0, int16_t* out, int stride) {
+  constexpr int W = 256 / CB;
+  constexpr uint32_t HALF = 1u << (CB - 1), FULL = 1u << CB;
+  uint32_t carry = 0;
+  for (int w = 0; w < W; w++) {
+    const uint32_t chunk = (k[(w * CB) >> 5] >> ((w * CB) & 31)) & (FULL - 1);
+    const uint32_t v = chunk + carry;
+    // digits in [-2^(c-1), 2^(c-1) - 1]: |d| <= 2^(c-1) indexes the table, and -2^15 still fits int16_t.
+    // No carry leaves the top window: scalars are < r < 2^255, so the top chunk is < 2^(c-1) - 1.
+    const int d = (v >= HALF) ? (int)v - (int)FULL : (int)v;
+    carry = (v >= HALF) ? 1u : 0u;
+    if (w >= w0 && w < w0 + 8) out[(w - w0) * stride] = (int16_t)d;
+  }
+}
+
+template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const Aff* __restrict__ tab, int nc,
+                                                                     Jac* __restrict__ part) {
+  constexpr int W = 256 / CB, WG = W / 8;          // waves per task
+  constexpr uint32_t M = 1u << (CB - 1);
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int16_t* digits = reinterpret_cast<int16_t*>(smem);   // [8][FIX_CHUNK]
+  Jac* red = reinterpret_cast<Jac*>(smem);              // [64] afterwards
+  const FixTask task = tasks[blockIdx.x / WG];
+  const int wg = blockIdx.x % WG;
+  const int lane = threadIdx.x;
+  const int wl = lane >> 3, sl = lane & 7;
+  const uint32_t w = (uint32_t)(wg * 8 + wl);
+  const Aff* wtab = tab + (size_t)w * M * nc;
+  Jac acc = Jac::identity();
+
+  for (uint32_t base = 0; base < task.n; base += FIX_CHUNK) {
+    const int m = min((uint32_t)FIX_CHUNK, task.n - base);
+    __syncthreads();
+    for (int t = lane; t < m; t += 64) {
+      Fr k = task.scalars[base + t];
+      if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
+      fix_digits8<CB>(k.v, wg * 8, digits + t, FIX_CHUNK);
+    }
+    __syncthreads();
+    const int16_t* row = digits + wl * FIX_CHUNK;
+    // every lane walks its slice i = sl, sl+8, ...: same trip count for all lanes; points fetched two at a time
+    for (int i = sl; i < m; i += 16) {
+      const int d0 = row[i];
+      const bool h1 = i + 8 < m;
+      const int d1 = h1 ? row[i + 8] : 0;
+      const uint32_t g0 = base + i, g1 = base + i + 8;
+      Aff p0 = Aff::identity(), p1 = Aff::identity();
+      if (d0) p0 = wtab[(size_t)((d0 < 0 ? -d0 : d0) - 1) * nc + task.off + (task.idx ? task.idx[g0] : g0)];
+      if (d1) p1 = wtab[(size_t)((d1 < 0 ? -d1 : d1) - 1) * nc + task.off + (task.idx ? task.idx[g1] : g1)];
+      if (d0) acc = jac_add_mixed(acc, aff_cneg(p0, d0 < 0));
+      if (d1) acc = jac_add_mixed(acc, aff_cneg(p1, d1 < 0));
+    }
+  }
+  __syncthreads();
+  red[lane] = acc;
+  __syncthreads();
+  for (int sft = 32; sft >= 1; sft >>= 1) {   // plain tree: all entries carry weight 1
+    const bool has = lane < sft;
+    Jac other;
+    if (has) other = red[lane + sft];
+    __syncthreads();
+    if (has) {
+      acc = jac_add(acc, other);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) part[task.out_first + wg] = acc;
+}
+
+// Table of multiples from the shifted copies: thread per (window, base) walks m = 1..M with mixed additions and
+// normalises `chunk` entries at a time (own Montgomery trick + one inversion per work-group).
+template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const Aff* __restrict__ shift, int nc, Aff* __restrict__ tab, TblTmp* __restrict__ tmp, int chunk) {
+  constexpr int W = 256 / CB;
+  constexpr uint32_t M = 1u << (CB - 1);
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  Fp* buf = reinterpret_cast<Fp*>(smem);
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = g < W * nc;
+  const int w = live ? g / nc : 0, i = live ? g % nc : 0;
+  const Aff S = live ? shift[(size_t)w * nc + i] : Aff::identity();
+  const bool inf = S.is_identity();
+  TblTmp* my = tmp + (size_t)g * chunk;
+  Aff* out = tab + (size_t)w * M * nc + i;
+  Jac acc = Jac::identity();
+  for (uint32_t m0 = 0; m0 < M; m0 += chunk) {
+    Fp prod = Fp::one();
+    if (live) {
+      for (int j = 0; j < chunk; j++) {
+        acc = jac_add_mixed_fn(acc, S);          // (m0 + j + 1) * S
+        my[j].p = acc;
+        my[j].pre = prod;
+        if (!inf) prod = fe_mul(prod, acc.z);
+      }
+    }
+    Fp inv = block_batch_inverse(prod, buf);
+    if (live) {
+      for (int j = chunk - 1; j >= 0; j--) {
+        Aff a = Aff::identity();
+        if (!inf) {
+          const Jac p = my[j].p;
+          const Fp zinv = fe_mul(inv, my[j].pre);
+          inv = fe_mul(inv, p.z);
+          a = jac_to_affine_with_zinv(p, zinv);
+        }
+        out[(size_t)(m0 + j) * nc] = a;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_finalize_ranges(const Jac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
+                                                         int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  Fp* buf = reinterpret_cast<Fp*>(smem);
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  Jac p = Jac::identity();
+  if (g < n) {
+    const Jac* src = part + first[g];
+    const uint32_t c = count[g];
+    if (c) p = src[0];
+    for (uint32_t j = 1; j < c; j++) p = jac_add_fn(p, src[j]);
   }
   const bool inf = p.is_identity();
   Fp zinv = block_batch_inverse(p.z, buf);
@@ -639,6 +774,23 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, Jac* d_part, hipStream_
 void launch_finalize_sum(const Jac* d_part, int group, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_finalize_sum, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(Fp), s, d_part, group, n, d_aff, d_dst_index, d_comp);
+}
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const Aff* d_fix_tab, int cbits, int nc, Jac* d_part, hipStream_t s) {
+  if (ntasks <= 0) return;
+  const size_t lds = 64 * sizeof(Jac);
+  if (cbits == 16) hipLaunchKernelGGL(k_msm_fix<16>, dim3(ntasks * 2), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
+  else hipLaunchKernelGGL(k_msm_fix<8>, dim3(ntasks * 4), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
+}
+void launch_fix_build(const Aff* d_shift, int nc, int cbits, Aff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
+  const int W = 256 / cbits, total = W * nc;
+  const size_t lds = 2 * 64 * sizeof(Fp);
+  if (cbits == 16) hipLaunchKernelGGL(k_fix_build<16>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
+  else hipLaunchKernelGGL(k_fix_build<8>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
+}
+void launch_finalize_ranges(const Jac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
+                            uint8_t* d_comp, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(Fp), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp);
 }
 void launch_table_build(Aff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, TblTmp* d_tmp, hipStream_t s) {
   const long total = (long)rows * npts;

@@ -56,6 +56,8 @@ static inline S S_from_wire(const uint8_t* b) {
 Engine::Engine(int device) : device_(device) {
   CPX_HIP(hipSetDevice(device_));
   CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  CPX_HIP(hipStreamCreateWithFlags(&side_.stream, hipStreamNonBlocking));
+  CPX_HIP(hipEventCreateWithFlags(&side_.ev, hipEventDisableTiming));
   if (const char* e = getenv("CPX_PROVER")) use_tables_ = std::string(e) != "fold";
   if (const char* e = getenv("CPX_WAVE_MSM")) wave_msm_ = atoi(e) != 0;
   if (const char* e = getenv("CPX_FIX_BITS")) {
@@ -69,6 +71,8 @@ Engine::Engine(int device) : device_(device) {
 }
 Engine::~Engine() {
   for (auto p : idx_allocs_) (void)hipFree(p);
+  if (side_.ev) (void)hipEventDestroy(side_.ev);
+  if (side_.stream) (void)hipStreamDestroy(side_.stream);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -320,7 +324,9 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   d_pcount_.ensure(nt);
   d_comp_.ensure(nt * 48);
   const size_t b_scal = total * sizeof(Fr), b_tt = ntt * sizeof(TblTask), b_ft = nft * sizeof(FixTask);
-  h_stage_.ensure(b_scal + b_tt + b_ft + 2 * nt * sizeof(uint32_t));
+  h_stage_.ensure(b_scal + b_tt + b_ft + 3 * nt * sizeof(uint32_t));
+  d_dst_.ensure(nt);
+  const uint32_t dummy_dst = slot_index(0, SlotMap(L_).TMP(7));   // results nobody reads land in a scratch slot
   Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
   TblTask* ht = reinterpret_cast<TblTask*>(h_stage_.p + b_scal);
   FixTask* hf = reinterpret_cast<FixTask*>(h_stage_.p + b_scal + b_tt);
@@ -358,12 +364,14 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     }
     hp[i] = pfirst[i];
     hp[nt + i] = pcount[i];
+    hp[2 * nt + i] = r.dst != ~0u ? r.dst : dummy_dst;
   });
   CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
   if (ntt) CPX_HIP(hipMemcpyAsync(d_ttasks_.p, ht, b_tt, hipMemcpyHostToDevice, stream_));
   if (nft) CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_pfirst_.p, hp, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   if (copies_ == 64 && wave_msm_) {
     if (nft) {
       tick("k_msm_fix", 128.0 * pts_fix, pts_fix);
@@ -376,7 +384,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
       tock();
     }
     tick("k_finalize_ranges", 0, (double)nt);
-    launch_finalize_ranges(d_part_.p, d_pfirst_.p, d_pcount_.p, (int)nt, nullptr, nullptr, d_comp_.p, stream_);
+    launch_finalize_ranges(d_part_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
     tock();
   } else {
     d_res_.ensure(nt);
@@ -639,7 +647,7 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
   }
   CPX_HIP(hipMemcpyAsync(d_Mjac_.p, M, batch * sizeof(Jac), hipMemcpyHostToDevice, stream_));
   if (use_tables_) {
-    // copy 0 of the per-proof tables: M (filled at prove time) | R | S | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
+    // copy 0 of the per-proof tables: M (filled at prove time) | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
     const size_t NP = np();
     d_ptab_.ensure(batch * (size_t)copies_ * NP);
     d_tbltmp_.ensure(std::max(batch * NP, n_ + 3) * (size_t)(copies_ - 1));
@@ -648,12 +656,10 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
     tails[7] = crs_single_[0];
     for (size_t p = 0; p < batch; p++) {
       Aff* t = ptab(p);
-      CPX_HIP(hipMemcpyAsync(t + 1, vec_R + p * vb, vb, hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + ell_, vec_S + p * vb, vb, hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_, vec_T + p * vb, vb, hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_ + ell_, tails.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_ + n_, vec_U + p * vb, vb, hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + 2 * ell_ + n_ + ell_, tails.data() + 4, 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1, vec_T + p * vb, vb, hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + ell_, tails.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + n_, vec_U + p * vb, vb, hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemcpyAsync(t + 1 + n_ + ell_, tails.data() + 4, 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
     }
   }
   CPX_HIP(hipStreamSynchronize(stream_));
@@ -1156,7 +1162,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   const size_t I_AB = 0, I_CB = 2, I_IR = 6, I_IZ = 6 + n, I_RT = 2 * n + 4, I_RU = 2 * n + 5, I_RA = 2 * n + 6, I_RB = 2 * n + 7,
                I_RK = 2 * n + 8, I_VR = 2 * n + 9;
   // table offsets inside a per-proof row
-  const size_t O_M = 0, O_R = 1, O_S = 1 + ell, O_T = 1 + 2 * ell, O_U = 1 + 2 * ell + n;
+  const size_t O_M = 0, O_T = 1, O_U = 1 + n;
   // CRS table indices: G | Hvec at 0..n-1, H at n, G_t at n+1, G_u at n+2
   const uint32_t* iH = idx_list({(uint32_t)n});
   const uint32_t* iGt = idx_list({(uint32_t)(n + 1)});
@@ -1217,15 +1223,48 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       s.scal[1].resize(n);                                    // vec_r of SameMSM: B_a, B_t, B_u
       for (size_t i = 0; i < n; i++) s.scal[1][i] = s.draw(I_VR + i);
       s.scal[2] = {s.draw(I_RT), s.draw(I_RU), s.draw(I_RA), s.draw(I_RB)};
-      s.scal[3].resize(ell);                                  // k * a   : cm_T.T_2 = k R + r_t H with R = a x vec_R
-      s.scal[4].resize(ell);                                  // r_k * a : cm_A.T_2 = r_k R + r_a H
-      for (size_t i = 0; i < ell; i++) {
-        s.scal[3][i] = kk * s.vec_a[i];
-        s.scal[4][i] = r_k * s.vec_a[i];
-      }
+      s.scal[3] = {kk, r_k};                                   // scalars of the four T_2 scalar multiplications
     });
   }
   auto take = [&](size_t p, int slot_id, size_t req_index) { memcpy(&st[p].comp[(size_t)slot_id * 48], &comp[req_index * 48], 48); };
+
+  // -- side stream: R = a x vec_R and S = a x vec_S (curdleproofs.rs:112-113).  The instance points R_i, S_i are
+  //    used by exactly these two MSMs, so they get no table: plain Pippenger (k_msm_accum + tails) off the
+  //    critical path; the affine results land in the slots SL_R / SL_S.
+  const int CW0 = SL_CMT1, CWN = sm.CMB2() - SL_CMT1 + 1;   // slot window compressed on the side stream
+  {
+    const size_t nt = 2 * B, total = B * ell;
+    side_.scal.ensure(total + 2 * B);
+    side_.tasks.ensure(nt);
+    side_.stasks.ensure(4 * B);
+    side_.wsum.ensure(nt * 64);
+    side_.part.ensure(nt * 8);
+    side_.res.ensure(nt);
+    side_.dst.ensure(nt);
+    side_.comp.ensure(B * (size_t)CWN * 48);
+    side_.hcomp.ensure(B * (size_t)CWN * 48);
+    const size_t o_tasks = (total + 2 * B) * sizeof(Fr), o_dst = o_tasks + nt * sizeof(MsmTask), o_st = o_dst + nt * sizeof(uint32_t);
+    side_.stage.ensure(o_st + 4 * B * sizeof(SmulTask));
+    Fr* hs = reinterpret_cast<Fr*>(side_.stage.p);
+    MsmTask* ht = reinterpret_cast<MsmTask*>(side_.stage.p + o_tasks);
+    uint32_t* hd = reinterpret_cast<uint32_t*>(side_.stage.p + o_dst);
+    parallel_for(B, [&](size_t p) {
+      for (size_t i = 0; i < ell; i++) hs[p * ell + i] = st[p].vec_a[i].f;
+      hs[total + 2 * p] = st[p].scal[3][0].f;       // k
+      hs[total + 2 * p + 1] = st[p].scal[3][1].f;   // r_k
+      ht[2 * p] = MsmTask{pp(p), nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0};
+      ht[2 * p + 1] = MsmTask{pp(p) + ell, nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0};
+      hd[2 * p] = slot_index(p, SL_R);
+      hd[2 * p + 1] = slot_index(p, SL_S);
+    });
+    CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, (total + 2 * B) * sizeof(Fr), hipMemcpyHostToDevice, side_.stream));
+    CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, side_.stream));
+    CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, side_.stream));
+    launch_msm_accum(side_.tasks.p, (int)nt, side_.wsum.p, side_.stream);
+    launch_msm_tail(side_.wsum.p, side_.part.p, (int)nt * 8, 8, 4, side_.stream);
+    launch_msm_tail(side_.part.p, side_.res.p, (int)nt, 8, 32, side_.stream);
+    launch_finalize(side_.res.p, (int)nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
+  }
 
   // -- P1: everything that depends only on vec_a and the prover's randomness
   {
@@ -1237,8 +1276,6 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       const S* ra = &s.scal[2][2];
       const S* rb = &s.scal[2][3];
       reqs.push_back({cseg(0, (uint32_t)n), s.scal[0].data(), none, nullptr});                       // A
-      reqs.push_back({pseg(p, O_R, (uint32_t)ell), s.vec_a.data(), none, nullptr});                   // R  (curdleproofs.rs:112)
-      reqs.push_back({pseg(p, O_S, (uint32_t)ell), s.vec_a.data(), none, nullptr});                   // S
       reqs.push_back({cseg(0, (uint32_t)n, iGb), s.scal[1].data(), none, nullptr});                   // B_a (same_multiscalar_argument.rs:80)
       reqs.push_back({pseg(p, O_T, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_t
       reqs.push_back({pseg(p, O_U, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_u
@@ -1246,17 +1283,19 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       reqs.push_back({cseg(0, 1, iGu), ru, none, nullptr});                                           // cm_U.T_1
       reqs.push_back({cseg(0, 1, iGt), ra, none, nullptr});                                           // cm_A.T_1
       reqs.push_back({cseg(0, 1, iGu), rb, none, nullptr});                                           // cm_B.T_1
-      reqs.push_back({pseg(p, O_R, (uint32_t)ell), s.scal[3].data(), cseg(0, 1, iH), rt});            // cm_T.T_2
-      reqs.push_back({pseg(p, O_S, (uint32_t)ell), s.scal[3].data(), cseg(0, 1, iH), ru});            // cm_U.T_2
-      reqs.push_back({pseg(p, O_R, (uint32_t)ell), s.scal[4].data(), cseg(0, 1, iH), ra});            // cm_A.T_2
-      reqs.push_back({pseg(p, O_S, (uint32_t)ell), s.scal[4].data(), cseg(0, 1, iH), rb});            // cm_B.T_2
+      // r * H halves of the four T_2 commitments, kept as affine points for the side-stream scalar multiplications
+      reqs.push_back({cseg(0, 1, iH), rt, none, nullptr, slot_index(p, sm.TMP(0))});
+      reqs.push_back({cseg(0, 1, iH), ru, none, nullptr, slot_index(p, sm.TMP(1))});
+      reqs.push_back({cseg(0, 1, iH), ra, none, nullptr, slot_index(p, sm.TMP(2))});
+      reqs.push_back({cseg(0, 1, iH), rb, none, nullptr, slot_index(p, sm.TMP(3))});
       reqs.push_back({cseg(0, (uint32_t)(n + 2), iAp), s.scal[0].data(), none, nullptr});             // A'
     }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      const int ids[15] = {SL_A, SL_R, SL_S, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2(), sm.APRIME()};
-      for (int i = 0; i < 15; i++) take(p, ids[i], p * 15 + i);
+      const int ids[13] = {SL_A, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), -1, -1, -1, -1, sm.APRIME()};
+      for (int i = 0; i < 13; i++)
+        if (ids[i] >= 0) take(p, ids[i], p * 13 + i);
       // same_permutation_argument.rs:60-83
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_A * 48]);
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_M * 48]);
@@ -1279,6 +1318,27 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       s.scal[5][ell + 3] = S::zero();
       s.scal[6] = {s.alpha_sp};
     });
+  }
+
+  // -- side stream: cm_T.T_2 = k R + r_t H, cm_U.T_2 = k S + r_u H (curdleproofs.rs:115-116), cm_A.T_2 = r_k R + r_a H,
+  //    cm_B.T_2 = r_k S + r_b H (same_scalar_argument.rs:60-61): four scalar multiplications of R / S per proof
+  //    (k_smul) on top of the r*H points phase 1 left in TMP0..3; needed only at the SameScalar transcript step.
+  {
+    const size_t total = B * ell;
+    const size_t o_st = (total + 2 * B) * sizeof(Fr) + 2 * B * sizeof(MsmTask) + 2 * B * sizeof(uint32_t);
+    SmulTask* hst = reinterpret_cast<SmulTask*>(side_.stage.p + o_st);
+    for (size_t p = 0; p < B; p++) {
+      const Fr* kk = side_.scal.p + total + 2 * p;
+      hst[4 * p + 0] = SmulTask{slot(p, sm.TMP(0)), slot(p, SL_R), slot(p, SL_CMT2), kk, 0, 0};
+      hst[4 * p + 1] = SmulTask{slot(p, sm.TMP(1)), slot(p, SL_S), slot(p, SL_CMU2), kk, 0, 0};
+      hst[4 * p + 2] = SmulTask{slot(p, sm.TMP(2)), slot(p, SL_R), slot(p, sm.CMA2()), kk + 1, 0, 0};
+      hst[4 * p + 3] = SmulTask{slot(p, sm.TMP(3)), slot(p, SL_S), slot(p, sm.CMB2()), kk + 1, 0, 0};
+    }
+    CPX_HIP(hipMemcpyAsync(side_.stasks.p, hst, 4 * B * sizeof(SmulTask), hipMemcpyHostToDevice, side_.stream));
+    launch_smul(side_.stasks.p, (int)(4 * B), 1, side_.stream);
+    launch_compress(d_pp_.p + 4 * ell + CW0, CWN, (int)pp_stride_, (int)B, side_.comp.p, side_.stream);
+    CPX_HIP(hipMemcpyAsync(side_.hcomp.p, side_.comp.p, B * (size_t)CWN * 48, hipMemcpyDeviceToHost, side_.stream));
+    CPX_HIP(hipEventRecord(side_.ev, side_.stream));
   }
 
   // -- P2: B
@@ -1444,10 +1504,13 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   {
     std::vector<uint8_t> id_comp(48, 0);
     id_comp[0] = 0xc0;
+    CPX_HIP(hipEventSynchronize(side_.ev));   // R, S and the four T_2 commitments from the side stream
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       s.c_final = s.c[0];
       s.d_final = s.d[0];
+      const int side_slots[6] = {SL_R, SL_S, SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2()};
+      for (int q : side_slots) memcpy(&s.comp[(size_t)q * 48], side_.hcomp.p + (p * (size_t)CWN + (q - CW0)) * 48, 48);
       const int pts[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
       for (int q : pts) s.tr.append_point_bytes("sameexp_points", &s.comp[(size_t)q * 48]);
       const S alpha = s.tr.get_and_append_challenge("same_scalar_alpha");

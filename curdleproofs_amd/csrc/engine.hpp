@@ -149,7 +149,21 @@ class Engine {
     const host::S* s0;
     TblSeg seg1;
     const host::S* s1;
+    uint32_t dst = ~0u;       // optional: index into d_pp_ receiving the affine result
   };
+  // second stream + private staging for work that is off the critical path of the phase sequence
+  struct SideBufs {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    DevBuf<MsmTask> tasks;
+    DevBuf<SmulTask> stasks;
+    DevBuf<Fr> scal;
+    DevBuf<Jac> wsum, part, res;
+    DevBuf<uint32_t> dst;
+    DevBuf<uint8_t> comp;
+    PinBuf<uint8_t> stage, hcomp;
+  };
+  SideBufs side_;
   struct Timed {
     hipEvent_t a, b;
     std::string name;
@@ -167,8 +181,8 @@ class Engine {
   void flush_timers();
   template <class F> void parallel_for(size_t n, F&& f);
 
-  // per-proof table row: copy-major [copies][NP], NP = 1 + 2 ell + 2 n : M | R | S | T_b | U_b
-  size_t np() const { return 1 + 2 * ell_ + 2 * n_; }
+  // per-proof table row: copy-major [copies][NP]
+  size_t np() const { return 1 + 2 * n_; }   // M | T_b | U_b   (R and S are used once: no table)
   Aff* ptab(size_t p) const { return d_ptab_.p + p * (size_t)copies_ * np(); }
   TblSeg pseg(size_t p, size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ptab(p) + off, idx, (uint32_t)np(), cnt}; }
   TblSeg cseg(size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{d_ctab_.p + off, idx, (uint32_t)(n_ + 3), cnt}; }

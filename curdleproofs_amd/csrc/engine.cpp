@@ -1928,10 +1928,11 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     const uint32_t* e3 = idx_list({(uint32_t)sm.CMB1(), (uint32_t)SL_CMU1, (uint32_t)SL_GU});
     const uint32_t* e4 = idx_list({(uint32_t)sm.CMB2(), (uint32_t)SL_CMU2, (uint32_t)SL_S, (uint32_t)SL_H});
     const uint32_t* ecomb = idx_list({(uint32_t)sm.TMP(0), (uint32_t)sm.TMP(1), (uint32_t)sm.TMP(2), (uint32_t)sm.TMP(3)});
+    const bool fix_crs = fix_bits_ && d_fixtab_.p && copies_ == 64 && wave_msm_ && use_tables_;
     std::vector<MsmReq> reqs;
     for (size_t p = 0; p < B; p++) {
       VState& s = st[p];
-      reqs.push_back({d_crs_.p, nullptr, s.scal[0].data(), (uint32_t)n, slot_index(p, sm.TMP(0))});
+      if (!fix_crs) reqs.push_back({d_crs_.p, nullptr, s.scal[0].data(), (uint32_t)n, slot_index(p, sm.TMP(0))});
       reqs.push_back({pp(p), nullptr, s.scal[1].data(), (uint32_t)(2 * ell), slot_index(p, sm.TMP(1))});
       reqs.push_back({pp(p) + 2 * ell, nullptr, s.scal[1].data() + 2 * ell, (uint32_t)(2 * ell), slot_index(p, sm.TMP(2))});
       reqs.push_back({slot(p, 0), d_misc, s.scal[2].data(), (uint32_t)NM, slot_index(p, sm.TMP(3))});
@@ -1939,6 +1940,13 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
       reqs.push_back({slot(p, 0), e2, s.scal[4].data(), 4, slot_index(p, sm.TMP(5))});
       reqs.push_back({slot(p, 0), e3, s.scal[5].data(), 3, slot_index(p, sm.TMP(6))});
       reqs.push_back({slot(p, 0), e4, s.scal[6].data(), 4, slot_index(p, sm.TMP(7))});
+    }
+    if (fix_crs) {   // CRS shard of the accumulated check on the fixed-base table (no buckets, no tail)
+      std::vector<TblReq> treqs;
+      const TblSeg none{nullptr, nullptr, 0, 0};
+      for (size_t p = 0; p < B; p++) treqs.push_back({cseg(0, (uint32_t)n), st[p].scal[0].data(), none, nullptr, slot_index(p, sm.TMP(0))});
+      std::vector<uint8_t> unused;
+      run_tbl_phase(treqs, &unused);   // synchronises: the staging buffers are reused by the next phase
     }
     std::vector<uint8_t> comp2;
     run_msm_phase(reqs, &comp2);
@@ -1949,7 +1957,8 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     for (size_t p = 0; p < B; p++) {
       VState& s = st[p];
       bool ok = comp3[p * 48] == ID0;
-      for (int e = 4; e < 8; e++) ok = ok && comp2[(p * 8 + e) * 48] == ID0;
+      const size_t per = fix_crs ? 7 : 8, first_eq = fix_crs ? 3 : 4;
+      for (size_t e = first_eq; e < per; e++) ok = ok && comp2[(p * per + e) * 48] == ID0;
       verdict[p] = s.bad ? CPX_ERR_DESERIALIZE : ((s.reject || !ok) ? CPX_ERR_VERIFY : CPX_OK);
     }
   }

@@ -59,14 +59,9 @@ Engine::Engine(int device) : device_(device) {
   CPX_HIP(hipStreamCreateWithFlags(&side_.stream, hipStreamNonBlocking));
   CPX_HIP(hipEventCreateWithFlags(&side_.ev, hipEventDisableTiming));
   if (const char* e = getenv("CPX_PROVER")) use_tables_ = std::string(e) != "fold";
-  if (const char* e = getenv("CPX_WAVE_MSM")) wave_msm_ = atoi(e) != 0;
   if (const char* e = getenv("CPX_FIX_BITS")) {
     int c = atoi(e);
     if (c == 0 || c == 8 || c == 16) fix_bits_ = c;
-  }
-  if (const char* e = getenv("CPX_TBL_COPIES")) {
-    int c = atoi(e);
-    if (c == 8 || c == 16 || c == 32 || c == 64) copies_ = c;
   }
 }
 Engine::~Engine() {
@@ -283,10 +278,10 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
 void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out) {
   const size_t nt = reqs.size();
   if (!nt) return;
-  const bool fix = fix_bits_ && d_fixtab_.p && copies_ == 64 && wave_msm_;
+  const bool fix = fix_bits_ && d_fixtab_.p;
   const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / 8) : 0;
-  const Aff* c_lo = d_ctab_.p;
-  const Aff* c_hi = d_ctab_.p + (size_t)copies_ * (n_ + 3);
+  const TAff* c_lo = d_ctab_.p;
+  const TAff* c_hi = d_ctab_.p + (size_t)copies_ * (n_ + 3);
   auto is_crs = [&](const TblSeg& sg) { return fix && sg.n && sg.base >= c_lo && sg.base < c_hi; };
   // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
   std::vector<size_t> soff(nt);
@@ -319,7 +314,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   d_scal_.ensure(total);
   d_ttasks_.ensure(std::max<size_t>(ntt, 1));
   d_ftasks_.ensure(std::max<size_t>(nft, 1));
-  d_part_.ensure(nparts);
+  d_tpart_.ensure(nparts);
   d_pfirst_.ensure(nt);
   d_pcount_.ensure(nt);
   d_comp_.ensure(nt * 48);
@@ -372,29 +367,19 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_pfirst_.p, hp, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-  if (copies_ == 64 && wave_msm_) {
-    if (nft) {
-      tick("k_msm_fix", 128.0 * pts_fix, pts_fix);
-      launch_msm_fix(d_ftasks_.p, (int)nft, d_fixtab_.p, fix_bits_, (int)(n_ + 3), d_part_.p, stream_);
-      tock();
-    }
-    if (ntt) {
-      tick("k_msm_tblw", 128.0 * pts_tbl, pts_tbl);
-      launch_msm_tblw(d_ttasks_.p, (int)ntt, d_part_.p, stream_);
-      tock();
-    }
-    tick("k_finalize_ranges", 0, (double)nt);
-    launch_finalize_ranges(d_part_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
-    tock();
-  } else {
-    d_res_.ensure(nt);
-    tick("k_msm_tbl", 128.0 * total, (double)total);
-    launch_msm_tbl(d_ttasks_.p, (int)nt, copies_, d_res_.p, stream_);
-    tock();
-    tick("k_finalize", 0, (double)nt);
-    launch_finalize(d_res_.p, (int)nt, nullptr, nullptr, d_comp_.p, stream_);
+  if (nft) {
+    tick("k_msm_fix", 128.0 * pts_fix, pts_fix);
+    launch_msm_fix(d_ftasks_.p, (int)nft, d_fixtab_.p, fix_bits_, (int)(n_ + 3), d_tpart_.p, stream_);
     tock();
   }
+  if (ntt) {
+    tick("k_msm_tblw", 128.0 * pts_tbl, pts_tbl);
+    launch_msm_tblw(d_ttasks_.p, (int)ntt, d_tpart_.p, stream_);
+    tock();
+  }
+  tick("k_finalize_ranges", 0, (double)nt);
+  launch_finalize_ranges(d_tpart_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
+  tock();
   if (comp_out) {
     h_comp_.ensure(nt * 48);
     CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, nt * 48, hipMemcpyDeviceToHost, stream_));
@@ -461,19 +446,20 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
     row[n] = pts[n];
     row[n + 1] = pts[n + 1];
     row[n + 2] = pts[n + 2];
-    CPX_HIP(hipMemcpy(d_ctab_.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
+    DevBuf<Aff> d_row;
+    d_row.ensure(NC);
+    CPX_HIP(hipMemcpy(d_row.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
     d_tbltmp_.ensure(NC * (size_t)(copies_ - 1));
-    launch_table_build(d_ctab_.p, 1, 0, (int)NC, (int)NC, copies_, d_tbltmp_.p, stream_);
+    launch_table_build(d_row.p, 0, d_ctab_.p, 1, 0, (int)NC, (int)NC, copies_, d_tbltmp_.p, stream_);
     CPX_HIP(hipStreamSynchronize(stream_));
-    if (fix_bits_ && use_tables_ && copies_ == 64 && wave_msm_) {
+    if (fix_bits_ && use_tables_) {
       // fixed-base table of multiples m * 2^(c w) * P, m <= 2^(c-1): shifted copies first, then the multiples
       const int W = 256 / fix_bits_;
       const size_t M = size_t(1) << (fix_bits_ - 1);
-      DevBuf<Aff> d_shift;
+      DevBuf<TAff> d_shift;
       d_shift.ensure((size_t)W * NC);
-      CPX_HIP(hipMemcpy(d_shift.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
       d_tbltmp_.ensure(NC * (size_t)(W - 1));
-      launch_table_build(d_shift.p, 1, 0, (int)NC, (int)NC, W, d_tbltmp_.p, stream_);
+      launch_table_build(d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, d_tbltmp_.p, stream_);
       d_fixtab_.ensure((size_t)W * M * NC);
       const int chunk = (int)std::min<size_t>(256, M);
       const size_t threads = ((size_t)W * NC + 63) / 64 * 64;
@@ -615,9 +601,11 @@ double Engine::bench_fpmul(int blocks, int iters, int reps) {
   hipEvent_t a, b;
   CPX_HIP(hipEventCreate(&a));
   CPX_HIP(hipEventCreate(&b));
-  launch_bench_fpmul(d.p, blocks, iters, stream_);   // warm-up
+  const char* fld = getenv("CPX_BENCH_FIELD");
+  auto launch = (fld && atoi(fld) == 28) ? launch_bench_f28mul : launch_bench_fpmul;
+  launch(d.p, blocks, iters, stream_);   // warm-up
   CPX_HIP(hipEventRecord(a, stream_));
-  for (int r = 0; r < reps; r++) launch_bench_fpmul(d.p, blocks, iters, stream_);
+  for (int r = 0; r < reps; r++) launch(d.p, blocks, iters, stream_);
   CPX_HIP(hipEventRecord(b, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
   float ms = 0;
@@ -650,12 +638,13 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
     // copy 0 of the per-proof tables: M (filled at prove time) | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
     const size_t NP = np();
     d_ptab_.ensure(batch * (size_t)copies_ * NP);
+    d_psrc_.ensure(batch * NP);
     d_tbltmp_.ensure(std::max(batch * NP, n_ + 3) * (size_t)(copies_ - 1));
     std::vector<Aff> tails(8, Aff::identity());
     tails[2] = crs_single_[0];
     tails[7] = crs_single_[0];
     for (size_t p = 0; p < batch; p++) {
-      Aff* t = ptab(p);
+      Aff* t = d_psrc_.p + p * NP;
       CPX_HIP(hipMemcpyAsync(t + 1, vec_T + p * vb, vb, hipMemcpyHostToDevice, stream_));
       CPX_HIP(hipMemcpyAsync(t + 1 + ell_, tails.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
       CPX_HIP(hipMemcpyAsync(t + 1 + n_, vec_U + p * vb, vb, hipMemcpyHostToDevice, stream_));
@@ -1189,11 +1178,11 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     d_dst_.ensure(B);
     d_comp_.ensure(B * 48);
     std::vector<uint32_t> dst(B);
-    for (size_t p = 0; p < B; p++) dst[p] = (uint32_t)(p * (size_t)copies_ * NP + O_M);
+    for (size_t p = 0; p < B; p++) dst[p] = (uint32_t)(p * NP + O_M);
     CPX_HIP(hipMemcpyAsync(d_dst_.p, dst.data(), B * 4, hipMemcpyHostToDevice, stream_));
-    launch_finalize(d_Mjac_.p, (int)B, d_ptab_.p, d_dst_.p, d_comp_.p, stream_);
+    launch_finalize(d_Mjac_.p, (int)B, d_psrc_.p, d_dst_.p, d_comp_.p, stream_);
     tick("k_table_build", 0, (double)(B * NP));
-    launch_table_build(d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, d_tbltmp_.p, stream_);
+    launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, d_tbltmp_.p, stream_);
     tock();
     std::vector<uint8_t> mcomp(B * 48);
     CPX_HIP(hipMemcpyAsync(inst_comp.data(), d_bytes_.p, inst_comp.size(), hipMemcpyDeviceToHost, stream_));
@@ -1928,7 +1917,7 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     const uint32_t* e3 = idx_list({(uint32_t)sm.CMB1(), (uint32_t)SL_CMU1, (uint32_t)SL_GU});
     const uint32_t* e4 = idx_list({(uint32_t)sm.CMB2(), (uint32_t)SL_CMU2, (uint32_t)SL_S, (uint32_t)SL_H});
     const uint32_t* ecomb = idx_list({(uint32_t)sm.TMP(0), (uint32_t)sm.TMP(1), (uint32_t)sm.TMP(2), (uint32_t)sm.TMP(3)});
-    const bool fix_crs = fix_bits_ && d_fixtab_.p && copies_ == 64 && wave_msm_ && use_tables_;
+    const bool fix_crs = fix_bits_ && d_fixtab_.p && use_tables_;
     std::vector<MsmReq> reqs;
     for (size_t p = 0; p < B; p++) {
       VState& s = st[p];

@@ -183,7 +183,7 @@ class Engine {
 
   // per-proof table row: copy-major [copies][NP]
   size_t np() const { return 1 + 2 * n_; }   // M | T_b | U_b   (R and S are used once: no table)
-  Aff* ptab(size_t p) const { return d_ptab_.p + p * (size_t)copies_ * np(); }
+  TAff* ptab(size_t p) const { return d_ptab_.p + p * (size_t)copies_ * np(); }
   TblSeg pseg(size_t p, size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ptab(p) + off, idx, (uint32_t)np(), cnt}; }
   TblSeg cseg(size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{d_ctab_.p + off, idx, (uint32_t)(n_ + 3), cnt}; }
   Aff* pp(size_t p) const { return d_pp_.p + p * pp_stride_; }
@@ -206,15 +206,15 @@ class Engine {
   uint8_t crs_H_comp_[48];
 
   // shifted-base tables (all-MSM prover)
-  int copies_ = 64;          // table copies per base: 2^(256/copies * c) P, c < copies
-  bool wave_msm_ = true;     // 64-copy tables: barrier-free one-wave-per-8-windows MSM kernel
+  static constexpr int copies_ = 64;   // table copies per base: 2^(4c) P, one per radix-16 window
   bool use_tables_ = true;
-  DevBuf<Aff> d_ctab_;       // CRS table [copies][n+3] : G | Hvec | H | G_t | G_u
-  DevBuf<Aff> d_ptab_;       // per-proof tables [B][copies][NP]
+  DevBuf<TAff> d_ctab_;      // CRS table [copies][n+3] : G | Hvec | H | G_t | G_u   (table representation)
+  DevBuf<TAff> d_ptab_;      // per-proof tables [B][copies][NP]
+  DevBuf<Aff> d_psrc_;       // their standard-form sources [B][NP] : M | T_b | U_b
   DevBuf<TblTmp> d_tbltmp_;
   DevBuf<TblTask> d_ttasks_;
   int fix_bits_ = 16;        // fixed-base CRS table of multiples: radix 2^16 (13 GB at ell = 252), 2^8 (0.1 GB) or 0 = off
-  DevBuf<Aff> d_fixtab_;     // [256/c][2^(c-1)][n+3]
+  DevBuf<TAff> d_fixtab_;    // [256/c][2^(c-1)][n+3]
   DevBuf<FixTask> d_ftasks_;
   DevBuf<uint32_t> d_pfirst_, d_pcount_;
 
@@ -230,6 +230,7 @@ class Engine {
   DevBuf<SmulTask> d_stasks_;
   DevBuf<Fr> d_scal_;
   DevBuf<Jac> d_wsum_, d_part_, d_res_;
+  DevBuf<TJac> d_tpart_;     // partial sums of the table kernels
   DevBuf<uint32_t> d_dst_;
   DevBuf<uint8_t> d_comp_;
   PinBuf<uint8_t> h_stage_;

@@ -1,0 +1,176 @@
+// BLS12-381 Fp on 14 signed 28-bit limbs — the carry-free field of the table kernels (product code).
+//
+// Why: on gfx950 the carry instructions are as expensive as the multiplier (measured, profiles/r01_mac_micro.txt:
+// v_mad_u64_u32 ~4.5 cycles per wave, v_addc_co_u32 ~4.5 cycles, both "half rate"), so a saturated 32-bit-limb
+// Montgomery product costs ~9 cycles per limb product.  With 28-bit limbs a whole column of the product-scanning
+// Montgomery multiplication (<= 28 limb products of < 2^56) accumulates in ONE 64-bit register with plain
+// v_mad_i64_i32 and no carry handling at all: 392 multiply-accumulates at ~4.5-5.5 cycles instead of 288 at ~9.
+//
+// Representation: value = sum v[i] * 2^(28 i), v[0..12] in [0, 2^28) after normalisation, v[13] signed (the
+// value itself may be negative).  Montgomery radix R = 2^392.  Values are LAZY: additions and subtractions are
+// limb-wise with a carry pass and NO modular reduction; a product returns a value in (-0.81 p, 1.81 p) provided
+// |a| * |b| < 2^11.3 * p^2, which the point formulas keep with a wide margin (worst case 38 p * 38 p, see g1_28).
+// Exact zero is all-limbs-zero; a product is = 0 mod p iff it equals 0 or p (it cannot reach -p).
+#pragma once
+#include "mont32.cuh"
+
+namespace cpx {
+
+struct F28 {
+  int32_t v[14];
+  static CPX_HD F28 zero() {
+    F28 r;
+    CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = 0;
+    return r;
+  }
+  CPX_HD bool is_zero_exact() const {
+    int32_t o = 0;
+    CPX_UNROLL for (int i = 0; i < 14; i++) o |= v[i];
+    return o == 0;
+  }
+};
+
+struct F28Cfg {
+  static constexpr int32_t MASK = 0x0fffffff;
+  static constexpr int32_t P[14] = {0xfffaaab, 0xfefffff, 0x3ffffb9, 0xfffeb15, 0x6241eab, 0xa0f6b0f, 0xf6730d2,
+                                    0xf38512b, 0x4774b84, 0x4bacd76, 0xba7b643, 0xe69a4b1, 0x1ea397f, 0x001a011};
+  static constexpr uint32_t INV = 0xffcfffd;   // -p^-1 mod 2^28
+  // 2^392 mod p (Montgomery one), 2^400 mod p (standard -> internal), 2^384 mod p (internal -> standard)
+  static constexpr int32_t ONE[14] = {0x347fcb8, 0xd800000, 0x002b119, 0x0cde6d2, 0xc7212e0, 0x83a2090, 0x037669f,
+                                      0xda0f73e, 0x9b09b42, 0x1297bb0, 0x515d98f, 0x012ca7c, 0x659fcfa, 0x000577a};
+  static constexpr int32_t C_IN[14] = {0x80e6299, 0x3500034, 0xeb12856, 0xdeb2699, 0xc988670, 0x4ef6697, 0x70983e8,
+                                       0xa4e6fe9, 0x3e8a053, 0xecf271e, 0xc20d323, 0x6eb6385, 0x47f1286, 0x00156da};
+  static constexpr int32_t C_OUT[14] = {0x002fffd, 0x0900000, 0xc000276, 0x000bc40, 0x8baebf4, 0x5753c75, 0x55f4898,
+                                        0x7052574, 0x7ce5853, 0x56ec6d7, 0x71a97a2, 0xe4935c0, 0xec3fa80, 0x0015f65};
+};
+
+// carry pass: limbs 0..12 into [0, 2^28), the top limb absorbs the (signed) rest
+CPX_HD void f28_normalize(F28& a) {
+  CPX_UNROLL for (int i = 0; i < 13; i++) {
+    const int32_t c = a.v[i] >> 28;   // arithmetic shift
+    a.v[i] &= F28Cfg::MASK;
+    a.v[i + 1] += c;
+  }
+}
+CPX_HD F28 f28_add(const F28& a, const F28& b) {
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = a.v[i] + b.v[i];
+  f28_normalize(r);
+  return r;
+}
+CPX_HD F28 f28_sub(const F28& a, const F28& b) {
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i];
+  f28_normalize(r);
+  return r;
+}
+CPX_HD F28 f28_neg(const F28& a) {
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = -a.v[i];
+  f28_normalize(r);
+  return r;
+}
+// a * 2^k for tiny k (limbs < 2^28 -> < 2^31 for k <= 3 before the carry pass; the top limb stays small)
+template <int K> CPX_HD F28 f28_shl(const F28& a) {
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = a.v[i] << K;
+  f28_normalize(r);
+  return r;
+}
+CPX_HD F28 f28_cneg(const F28& a, bool neg) {
+  F28 n = f28_neg(a), r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = neg ? n.v[i] : a.v[i];
+  return r;
+}
+
+// Montgomery product a * b / 2^392 mod p (lazy range).  Product scanning: column k gathers a_i b_(k-i) and
+// m_i p_(k-i) into one signed 64-bit accumulator (|sum| < 2^62), emits one limb, shifts by 28 bits.
+CPX_HD F28 f28_mul_body(const F28& a, const F28& b) {
+  int32_t m[14];
+  F28 t;
+  int64_t acc = 0;
+  CPX_UNROLL for (int k = 0; k < 14; k++) {
+    CPX_UNROLL for (int i = 0; i < k; i++) {
+      acc += (int64_t)a.v[i] * b.v[k - i];
+      acc += (int64_t)m[i] * F28Cfg::P[k - i];
+    }
+    acc += (int64_t)a.v[k] * b.v[0];
+    m[k] = (int32_t)(((uint32_t)acc * F28Cfg::INV) & (uint32_t)F28Cfg::MASK);
+    acc += (int64_t)m[k] * F28Cfg::P[0];
+    acc >>= 28;
+  }
+  CPX_UNROLL for (int k = 14; k < 27; k++) {
+    CPX_UNROLL for (int i = k - 13; i < 14; i++) {
+      acc += (int64_t)a.v[i] * b.v[k - i];
+      acc += (int64_t)m[i] * F28Cfg::P[k - i];
+    }
+    t.v[k - 14] = (int32_t)acc & F28Cfg::MASK;
+    acc >>= 28;
+  }
+  t.v[13] = (int32_t)acc;
+  return t;
+}
+// out-of-line entry with scalar register arguments (same calling-convention reasoning as fe_mul_regs12)
+#define CPX_L14(p) p##0, p##1, p##2, p##3, p##4, p##5, p##6, p##7, p##8, p##9, p##10, p##11, p##12, p##13
+#define CPX_A14(p) int32_t p##0, int32_t p##1, int32_t p##2, int32_t p##3, int32_t p##4, int32_t p##5, int32_t p##6, int32_t p##7, int32_t p##8, int32_t p##9, int32_t p##10, int32_t p##11, int32_t p##12, int32_t p##13
+CPX_HD_FN F28 f28_mul_regs(CPX_A14(a), CPX_A14(b)) {
+  const F28 x{{CPX_L14(a)}}, y{{CPX_L14(b)}};
+  return f28_mul_body(x, y);
+}
+CPX_HD F28 f28_mul(const F28& a, const F28& b) {
+  return f28_mul_regs(a.v[0], a.v[1], a.v[2], a.v[3], a.v[4], a.v[5], a.v[6], a.v[7], a.v[8], a.v[9], a.v[10], a.v[11], a.v[12], a.v[13],
+                      b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7], b.v[8], b.v[9], b.v[10], b.v[11], b.v[12], b.v[13]);
+}
+CPX_HD F28 f28_sqr(const F28& a) { return f28_mul(a, a); }
+
+CPX_HD F28 f28_const(const int32_t* c) {
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = c[i];
+  return r;
+}
+CPX_HD F28 f28_one() { return f28_const(F28Cfg::ONE); }
+
+// a PRODUCT (value in (-0.81p, 1.81p), normalised limbs) is zero mod p iff it is 0 or p
+CPX_HD bool f28_product_is_zero(const F28& a) {
+  int32_t z = 0, e = 0;
+  CPX_UNROLL for (int i = 0; i < 14; i++) {
+    z |= a.v[i];
+    e |= a.v[i] ^ F28Cfg::P[i];
+  }
+  return z == 0 || e == 0;
+}
+
+// standard wire form (12 x u32 Montgomery, R = 2^384, canonical) <-> internal
+CPX_HD F28 f28_from_std(const Fp& s) {
+  F28 u;
+  CPX_UNROLL for (int i = 0; i < 14; i++) {
+    const int bit = 28 * i, w = bit >> 5, o = bit & 31;
+    uint64_t x = s.v[w];
+    if (w + 1 < 12) x |= (uint64_t)s.v[w + 1] << 32;
+    u.v[i] = (int32_t)((x >> o) & (uint32_t)F28Cfg::MASK);
+  }
+  return f28_mul(u, f28_const(F28Cfg::C_IN));   // X * 2^400 / 2^392 = X * 2^8 = x * 2^392
+}
+CPX_HD Fp f28_to_std(const F28& a) {
+  F28 t = f28_mul(a, f28_const(F28Cfg::C_OUT));   // x * 2^384, in (-0.81p, 1.81p)
+  // canonicalise: add p if negative, then subtract p if >= p
+  const bool neg = t.v[13] < 0;
+  CPX_UNROLL for (int i = 0; i < 14; i++) t.v[i] += neg ? F28Cfg::P[i] : 0;
+  f28_normalize(t);
+  F28 d;
+  CPX_UNROLL for (int i = 0; i < 14; i++) d.v[i] = t.v[i] - F28Cfg::P[i];
+  f28_normalize(d);
+  const bool ge = d.v[13] >= 0;
+  CPX_UNROLL for (int i = 0; i < 14; i++) t.v[i] = ge ? d.v[i] : t.v[i];
+  Fp r;
+  CPX_UNROLL for (int w = 0; w < 12; w++) {
+    const int bit = 32 * w, i = bit / 28, o = bit % 28;
+    uint64_t x = (uint64_t)(uint32_t)t.v[i] >> o;
+    if (i + 1 < 14) x |= (uint64_t)(uint32_t)t.v[i + 1] << (28 - o);
+    if (i + 2 < 14 && 56 - o < 32) x |= (uint64_t)(uint32_t)t.v[i + 2] << (56 - o);
+    r.v[w] = (uint32_t)x;
+  }
+  return r;
+}
+
+}  // namespace cpx

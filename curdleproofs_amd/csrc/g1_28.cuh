@@ -1,0 +1,132 @@
+// BLS12-381 G1 on the carry-free 28-bit-limb field (fp28.cuh) — product code, host + device.
+// Same formulas as g1.cuh, arranged so that every quantity that must be tested for zero is a PRODUCT
+// (Z3 = 2 * (Z1 * H) instead of (Z1 + H)^2 - Z1Z1 - HH), because a lazy value can only be zero-tested cheaply
+// right after a Montgomery multiplication.
+// Magnitude bookkeeping (units of p, |.|): stored coordinates stay within |X|,|Y| <= 15.4, |Z| <= 3.6; the
+// largest multiplication operands are rr (<= 34.2) squared = 1170 < 2^11.3 = 2521, so every product is in range.
+#pragma once
+#include "fp28.cuh"
+#include "g1.cuh"
+
+namespace cpx {
+
+struct Aff28 {
+  F28 x, y;
+  CPX_HD bool is_identity() const { return x.is_zero_exact() && y.is_zero_exact(); }
+  static CPX_HD Aff28 identity() { return Aff28{F28::zero(), F28::zero()}; }
+};
+struct Jac28 {
+  F28 x, y, z;
+  CPX_HD bool is_identity() const { return z.is_zero_exact(); }
+  static CPX_HD Jac28 identity() { return Jac28{f28_one(), f28_one(), F28::zero()}; }
+  static CPX_HD Jac28 from_affine(const Aff28& a) {
+    if (a.is_identity()) return identity();
+    return Jac28{a.x, a.y, f28_one()};
+  }
+};
+
+CPX_HD Aff28 aff28_cneg(const Aff28& p, bool neg) { return Aff28{p.x, f28_cneg(p.y, neg)}; }
+
+// 7 multiplications; D = 4 X Y^2 as a product instead of 2((X+B)^2 - A - C)
+CPX_PT_FN Jac28 jac28_dbl(const Jac28& p) {
+  const F28 A = f28_sqr(p.x), B = f28_sqr(p.y), C = f28_sqr(B);
+  const F28 D = f28_shl<2>(f28_mul(p.x, B));
+  const F28 E = f28_add(f28_shl<1>(A), A), F = f28_sqr(E);
+  Jac28 r;
+  r.x = f28_sub(F, f28_shl<1>(D));
+  r.y = f28_sub(f28_mul(E, f28_sub(D, r.x)), f28_shl<3>(C));
+  r.z = f28_shl<1>(f28_mul(p.y, p.z));   // exact zero stays exact zero
+  return r;
+}
+
+// 11 multiplications; complete
+CPX_PT_FN Jac28 jac28_add_mixed(const Jac28& p, const Aff28& q) {
+  if (q.is_identity()) return p;
+  if (p.is_identity()) return Jac28::from_affine(q);
+  const F28 z1z1 = f28_sqr(p.z);
+  const F28 u2 = f28_mul(q.x, z1z1);
+  const F28 s2 = f28_mul(f28_mul(q.y, p.z), z1z1);
+  const F28 h = f28_sub(u2, p.x);
+  const F28 zh = f28_mul(p.z, h);
+  F28 rr = f28_sub(s2, p.y);
+  if (f28_product_is_zero(zh)) {   // H = 0 mod p: P = +-Q
+    if (f28_product_is_zero(f28_mul(rr, f28_one()))) return jac28_dbl(p);
+    return Jac28::identity();
+  }
+  rr = f28_shl<1>(rr);
+  const F28 i = f28_shl<2>(f28_sqr(h));
+  const F28 j = f28_mul(h, i);
+  const F28 v = f28_mul(p.x, i);
+  Jac28 r;
+  r.x = f28_sub(f28_sub(f28_sqr(rr), j), f28_shl<1>(v));
+  r.y = f28_sub(f28_mul(rr, f28_sub(v, r.x)), f28_shl<1>(f28_mul(p.y, j)));
+  r.z = f28_shl<1>(zh);
+  return r;
+}
+
+// 16 multiplications; complete
+CPX_PT_FN Jac28 jac28_add(const Jac28& p, const Jac28& q) {
+  if (p.is_identity()) return q;
+  if (q.is_identity()) return p;
+  const F28 z1z1 = f28_sqr(p.z), z2z2 = f28_sqr(q.z);
+  const F28 u1 = f28_mul(p.x, z2z2), u2 = f28_mul(q.x, z1z1);
+  const F28 s1 = f28_mul(f28_mul(p.y, q.z), z2z2), s2 = f28_mul(f28_mul(q.y, p.z), z1z1);
+  const F28 h = f28_sub(u2, u1);
+  const F28 zzh = f28_mul(f28_mul(p.z, q.z), h);
+  F28 rr = f28_sub(s2, s1);
+  if (f28_product_is_zero(zzh)) {
+    if (f28_product_is_zero(f28_mul(rr, f28_one()))) return jac28_dbl(p);
+    return Jac28::identity();
+  }
+  rr = f28_shl<1>(rr);
+  const F28 i = f28_sqr(f28_shl<1>(h));
+  const F28 j = f28_mul(h, i);
+  const F28 v = f28_mul(u1, i);
+  Jac28 r;
+  r.x = f28_sub(f28_sub(f28_sqr(rr), j), f28_shl<1>(v));
+  r.y = f28_sub(f28_mul(rr, f28_sub(v, r.x)), f28_shl<1>(f28_mul(s1, j)));
+  r.z = f28_shl<1>(zzh);
+  return r;
+}
+CPX_HD_FN Jac28 jac28_dbl_fn(const Jac28& p) { return jac28_dbl(p); }
+CPX_HD_FN Jac28 jac28_add_mixed_fn(const Jac28& p, const Aff28& q) { return jac28_add_mixed(p, q); }
+CPX_HD_FN Jac28 jac28_add_fn(const Jac28& p, const Jac28& q) { return jac28_add(p, q); }
+
+CPX_HD Aff28 jac28_to_affine_with_zinv(const Jac28& p, const F28& zinv) {
+  const F28 zi2 = f28_sqr(zinv);
+  return Aff28{f28_mul(p.x, zi2), f28_mul(f28_mul(p.y, zi2), zinv)};
+}
+
+// conversions at the edge of the table kernels
+CPX_HD Aff28 aff28_from_std(const Aff& a) {
+  if (a.is_identity()) return Aff28::identity();
+  return Aff28{f28_from_std(a.x), f28_from_std(a.y)};
+}
+CPX_HD Aff aff28_to_std(const Aff28& a) {
+  if (a.is_identity()) return Aff::identity();
+  return Aff{f28_to_std(a.x), f28_to_std(a.y)};
+}
+CPX_HD Jac jac28_to_std(const Jac28& p) {
+  if (p.is_identity()) return Jac::identity();
+  return Jac{f28_to_std(p.x), f28_to_std(p.y), f28_to_std(p.z)};
+}
+
+// Fermat inverse in the lazy Montgomery domain
+CPX_HD F28 f28_inv(const F28& a) {
+  F28 r = f28_one();
+  bool started = false;
+  for (int l = 11; l >= 0; l--) {
+    uint32_t w = FpCfg::P[l];
+    if (l == 0) w -= 2;
+    for (int b = 31; b >= 0; b--) {
+      if (started) r = f28_sqr(r);
+      if ((w >> b) & 1u) {
+        r = started ? f28_mul(r, a) : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+
+}  // namespace cpx

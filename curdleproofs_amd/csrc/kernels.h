@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "g1.cuh"
+#include "tarith.cuh"
 
 namespace cpx {
 
@@ -28,27 +29,33 @@ struct SmulTask {
 };
 
 // ---- table-backed MSM (no doubling tails) ----
-// A table holds, for every base point P_i, the affine copies 2^(sb*c) * P_i, c = 0..C-1, sb = 256/C,
-// copy-major: entry (c, i) at base + c*copy_stride + i.  With C copies a 256-bit scalar splits into C chunks
-// of sb bits, so the 64 radix-16 windows need only q = 64/C in-kernel Horner steps (none at C = 64).
+// Tables and partial sums are in the table kernels' representation (tarith.cuh: TAff / TJac, 28-bit limbs).
+// A table holds, for every base point P_i, the affine copies 2^(4c) * P_i, c = 0..63, copy-major: entry (c, i)
+// at base + c*copy_stride + i.  Every radix-16 window of a scalar has its own copy, so all window sums carry
+// weight 1 and no doubling is left in the MSM.
 struct TblSeg {
-  const Aff* base;          // copy 0
+  const TAff* base;         // copy 0
   const uint32_t* idx;      // optional gather list (indices within a copy)
-  uint32_t copy_stride;     // in Aff units
+  uint32_t copy_stride;     // in TAff units
   uint32_t n;
 };
 struct TblTask {
   TblSeg seg[2];            // bases = seg[0] followed by seg[1]
   const Fr* scalars;        // seg[0].n + seg[1].n scalars
   uint32_t flags;
-  uint32_t pad;
+  uint32_t pad;             // first partial slot of the task; it writes 8 partials
 };
 struct TblTmp {   // table-build scratch: a Jacobian copy and the running product of the previous copies' Z
-  Jac p;
-  Fp pre;
+  TJac p;
+  TF pre;
 };
-// one work-group per task -> d_out[task] (Jacobian)
-void launch_msm_tbl(const TblTask* d_tasks, int ntasks, int copies, Jac* d_out, hipStream_t s);
+// single-wave work-groups, 8 per task -> d_part[task.pad + j], j < 8
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, TJac* d_part, hipStream_t s);
+// For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
+// table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
+void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
+                        TblTmp* d_tmp, hipStream_t s);
+
 // ---- fixed-base MSM over a table of multiples (CRS bases) ----
 // fix_tab[(w*M + (m-1))*nc + i] = m * 2^(c*w) * P_i  (affine), w < W = 256/c windows, m = 1..M = 2^(c-1), i < nc.
 // A scalar is W signed radix-2^c digits; digit d of window w selects entry |d| directly: one mixed addition per
@@ -62,19 +69,12 @@ struct FixTask {
   uint32_t flags;
   uint32_t out_first;       // first partial slot of this task; it writes W/8 partials
 };
-void launch_msm_fix(const FixTask* d_tasks, int ntasks, const Aff* d_fix_tab, int cbits, int nc, Jac* d_part, hipStream_t s);
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int nc, TJac* d_part, hipStream_t s);
 // shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
-void launch_fix_build(const Aff* d_shift, int nc, int cbits, Aff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
-// output o = sum of partials [first[o], first[o] + count[o]) -> normalised + compressed (+ optional affine scatter)
-void launch_finalize_ranges(const Jac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
+void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
+// output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)
+void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s);
-
-// 64-copy tables only: single-wave work-groups, 8 per task -> d_part[task*8 + j]; sum them with launch_finalize_sum
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, Jac* d_part, hipStream_t s);   // task t writes d_part[task.pad + j], j < 8
-void launch_finalize_sum(const Jac* d_part, int group, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
-// In place: for `rows` rows of `npts` points (row r at table + r*row_stride, copy 0 filled by the caller) writes
-// copies 1..C-1.  d_tmp: rows*npts*(C-1) TblTmp scratch.
-void launch_table_build(Aff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, TblTmp* d_tmp, hipStream_t s);
 
 // ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian) ...
 void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream_t s);
@@ -88,5 +88,6 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s);
 void launch_bench_fpmul(Fp* d_data, int blocks, int iters, hipStream_t s);
+void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s);
 
 }  // namespace cpx

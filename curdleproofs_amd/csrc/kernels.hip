@@ -20,6 +20,7 @@
 //    inversion per work-group (LDS product scans) instead of the reference's one inversion per point.
 #include <hip/hip_runtime.h>
 #include "g1.cuh"
+#include "tarith.cuh"
 #include "recode.cuh"
 #include "kernels.h"
 
@@ -79,6 +80,40 @@ __device__ __forceinline__ Fp block_batch_inverse(Fp z, Fp* buf) {
   __syncthreads();
   tinv = pre[0];
   return fe_mul(fe_mul(tinv, left), right);
+}
+
+// The same for the table kernels' field (tarith.cuh): 28-bit-limb lazy values.
+__device__ __noinline__ TF t_inv_device(const TF& a) { return t_inv(a); }
+__device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
+  const int tid = threadIdx.x, n = blockDim.x;
+  if (t_is_zero_raw(z)) z = t_one();
+  TF* pre = buf;
+  TF* suf = buf + n;
+  TF p = z, s = z;
+  pre[tid] = p;
+  suf[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < n; off <<= 1) {
+    TF pl, sr;
+    const bool hp = tid >= off, hs = tid + off < n;
+    if (hp) pl = pre[tid - off];
+    if (hs) sr = suf[tid + off];
+    __syncthreads();
+    if (hp) p = t_mul(p, pl);
+    if (hs) s = t_mul(s, sr);
+    pre[tid] = p;
+    suf[tid] = s;
+    __syncthreads();
+  }
+  const TF left = (tid > 0) ? pre[tid - 1] : t_one();
+  const TF right = (tid + 1 < n) ? suf[tid + 1] : t_one();
+  TF tinv = t_one();
+  if (tid < 64) tinv = t_inv_device(pre[n - 1]);
+  __syncthreads();
+  if (tid == 0) pre[0] = tinv;
+  __syncthreads();
+  tinv = pre[0];
+  return t_mul(t_mul(tinv, left), right);
 }
 
 // ------------------------------------------------------------------ MSM: bucket accumulation
@@ -166,147 +201,36 @@ __global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const 
   if (b == 0) wsum[(size_t)blockIdx.x * 64 + w] = acc;
 }
 
-// ------------------------------------------------------------------ table-backed MSM
-// Same thread <-> (window, bucket) ownership as k_msm_accum, but window w reads the pre-shifted copy
-// c = w / q of each base (q = 64 / copies windows share a copy), so the 64 window sums need only q-1 Horner
-// steps of 4 doublings — none at 64 copies — instead of the 252-doubling tail.  Points come straight from the
-// table in HBM/L2 (one 96-byte gather per digit addition, prefetched one match ahead); only the digit rows
-// are staged in LDS.  The reduction (copies tree -> bucket suffix-sum/tree -> short Horner) runs in-kernel.
-constexpr int TBL_CHUNK = 256;
+// ------------------------------------------------------------------ table-backed MSM, one wave per 8 windows
+// Barrier-free variant for 64-copy tables (every radix-16 window has its own pre-shifted copy, so all window
+// sums carry weight 1): a single-wave work-group owns windows [8*w8, 8*w8+8) of one task, lane = (window,
+// bucket).  Waves never wait for each other, and the CU scheduler backfills a finished wave's slot with the
+// next one of the grid, which is what keeps both wave slots of a SIMD issuing (PMC: the 8-wave group version
+// idles 67 % of its wave-cycles at barriers / s_waitcnt).  Output: one partial sum per wave; k_finalize_ranges
+// adds the partials of a request.  Window w reads the pre-shifted copy w of each base straight from the table
+// in HBM/L2 (one gather per digit addition); only the digit rows are staged in LDS.
+constexpr int TBW_CHUNK = 256;
+constexpr int TBW_LDS = 64 * (int)sizeof(TJac);   // >= 8 * 256 digit bytes
 
-__device__ __forceinline__ const Aff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
+__device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
   const uint32_t n0 = t.seg[0].n;
   const TblSeg& sg = (g < n0) ? t.seg[0] : t.seg[1];
   const uint32_t i = (g < n0) ? g : g - n0;
   return sg.base + (size_t)copy * sg.copy_stride + (sg.idx ? sg.idx[i] : i);
 }
 
-__global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_tbl(const TblTask* __restrict__ tasks, int q, Jac* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [64][TBL_CHUNK]
-  Jac* buckets = reinterpret_cast<Jac*>(smem);        // [512] (aliases the digits later)
-  const TblTask task = tasks[blockIdx.x];
-  const int tid = threadIdx.x;
-  const int w = tid >> 3, mag = (tid & 7) + 1;
-  const uint32_t copy = (uint32_t)(w / q);
-  const uint32_t ntot = task.seg[0].n + task.seg[1].n;
-  Jac acc = Jac::identity();
 
-  for (uint32_t base = 0; base < ntot; base += TBL_CHUNK) {
-    const int m = min((uint32_t)TBL_CHUNK, ntot - base);
-    __syncthreads();
-    if (tid < m) {
-      Fr k = task.scalars[base + tid];
-      if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
-      recode_signed16(k.v, digits + tid, TBL_CHUNK);
-    }
-    __syncthreads();
-    const int8_t* row = digits + w * TBL_CHUNK;
-    // software pipeline: locate + fetch the next matching point while the current addition runs
-    int i = 0, d = 0;
-    while (i < m) {
-      d = row[i];
-      if (d == mag || d == -mag) break;
-      i++;
-    }
-    bool have = i < m;
-    Aff cur = Aff::identity();
-    bool cur_neg = false;
-    if (have) {
-      cur = *tbl_point(task, base + i, copy);
-      cur_neg = d < 0;
-      i++;
-    }
-    while (__any(have)) {
-      int d2 = 0;
-      while (i < m) {
-        d2 = row[i];
-        if (d2 == mag || d2 == -mag) break;
-        i++;
-      }
-      const bool have2 = have && i < m;
-      Aff nxt = Aff::identity();
-      if (have2) nxt = *tbl_point(task, base + i, copy);
-      if (have) acc = jac_add_mixed(acc, aff_cneg(cur, cur_neg));
-      cur = nxt;
-      cur_neg = d2 < 0;
-      have = have2;
-      i++;
-    }
-  }
-  __syncthreads();
-  buckets[tid] = acc;
-  __syncthreads();
-  // (1) sum the copies: threads (copy, w', b) with the same (w', b) are q*8 apart
-  const int lane_span = q * 8;                      // threads per copy
-  for (int half = (MSM_THREADS / lane_span) >> 1; half >= 1; half >>= 1) {
-    const bool has = tid < half * lane_span;
-    Jac other;
-    if (has) other = buckets[tid + half * lane_span];
-    __syncthreads();
-    if (has) {
-      acc = jac_add(acc, other);
-      buckets[tid] = acc;
-    }
-    __syncthreads();
-  }
-  // (2) per remaining window w' < q: sum_b b * B_b  (suffix scan + tree over the 8 bucket lanes)
-  const int b = tid & 7;
-  const bool in_q = tid < lane_span;
-  for (int sft = 1; sft < 8; sft <<= 1) {
-    const bool has = in_q && (b + sft < 8);
-    Jac other;
-    if (has) other = buckets[tid + sft];
-    __syncthreads();
-    if (has) {
-      acc = jac_add(acc, other);
-      buckets[tid] = acc;
-    }
-    __syncthreads();
-  }
-  for (int sft = 4; sft >= 1; sft >>= 1) {
-    const bool has = in_q && (b < sft);
-    Jac other;
-    if (has) other = buckets[tid + sft];
-    __syncthreads();
-    if (has) {
-      acc = jac_add(acc, other);
-      buckets[tid] = acc;
-    }
-    __syncthreads();
-  }
-  // (3) Horner over the q window sums (buckets[w' * 8]), 4 doublings per step
-  if (tid == 0) {
-    Jac r = buckets[(q - 1) * 8];
-    for (int wq = q - 2; wq >= 0; wq--) {
-      for (int s4 = 0; s4 < 4; s4++) r = jac_dbl(r);
-      r = jac_add(r, buckets[wq * 8]);
-    }
-    out[blockIdx.x] = r;
-  }
-}
-
-// ------------------------------------------------------------------ table-backed MSM, one wave per 8 windows
-// Barrier-free variant for 64-copy tables (every radix-16 window has its own pre-shifted copy, so all window
-// sums carry weight 1): a single-wave work-group owns windows [8*w8, 8*w8+8) of one task, lane = (window,
-// bucket).  Waves never wait for each other, and the CU scheduler backfills a finished wave's slot with the
-// next one of the grid, which is what keeps both wave slots of a SIMD issuing (PMC: the 8-wave group version
-// idles 67 % of its wave-cycles at barriers / s_waitcnt).  Output: one partial sum per wave; k_finalize_sum
-// adds the 8 partials of a task.
-constexpr int TBW_CHUNK = 256;
-constexpr int TBW_LDS = 64 * (int)sizeof(Jac);   // 9216 B >= 8 * 256 digit bytes
-
-__global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, Jac* __restrict__ part) {
+__global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, TJac* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [8][TBW_CHUNK]
-  Jac* red = reinterpret_cast<Jac*>(smem);            // [64] (aliases the digits afterwards)
+  TJac* red = reinterpret_cast<TJac*>(smem);            // [64] (aliases the digits afterwards)
   const TblTask task = tasks[blockIdx.x >> 3];
   const int w8 = blockIdx.x & 7;
   const int lane = threadIdx.x;
   const int wl = lane >> 3, mag = (lane & 7) + 1;
   const uint32_t copy = (uint32_t)(w8 * 8 + wl);
   const uint32_t ntot = task.seg[0].n + task.seg[1].n;
-  Jac acc = Jac::identity();
+  TJac acc = TJac::identity();
 
   for (uint32_t base = 0; base < ntot; base += TBW_CHUNK) {
     const int m = min((uint32_t)TBW_CHUNK, ntot - base);
@@ -331,8 +255,8 @@ __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ 
       const bool have = i < m;
       if (!__any(have)) break;
       if (have) {
-        const Aff q = *tbl_point(task, base + i, copy);
-        acc = jac_add_mixed(acc, aff_cneg(q, d < 0));
+        const TAff q = *tbl_point(task, base + i, copy);
+        acc = t_add_mixed(acc, t_cneg(q, d < 0));
         i++;
       }
     }
@@ -343,58 +267,38 @@ __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ 
   const int b = lane & 7;
   for (int sft = 1; sft < 8; sft <<= 1) {           // suffix sums over the 8 bucket lanes of a window
     const bool has = b + sft < 8;
-    Jac other;
+    TJac other;
     if (has) other = red[lane + sft];
     __syncthreads();
     if (has) {
-      acc = jac_add(acc, other);
+      acc = t_add(acc, other);
       red[lane] = acc;
     }
     __syncthreads();
   }
   for (int sft = 4; sft >= 1; sft >>= 1) {          // ... summed: sum_b b * B_b in lane b == 0
     const bool has = b < sft;
-    Jac other;
+    TJac other;
     if (has) other = red[lane + sft];
     __syncthreads();
     if (has) {
-      acc = jac_add(acc, other);
+      acc = t_add(acc, other);
       red[lane] = acc;
     }
     __syncthreads();
   }
   for (int sft = 32; sft >= 8; sft >>= 1) {         // the wave's 8 window sums (weight 1 each)
     const bool has = (b == 0) && lane < sft;
-    Jac other;
+    TJac other;
     if (has) other = red[lane + sft];
     __syncthreads();
     if (has) {
-      acc = jac_add(acc, other);
+      acc = t_add(acc, other);
       red[lane] = acc;
     }
     __syncthreads();
   }
   if (lane == 0) part[task.pad + w8] = acc;   // task.pad = first partial slot of the task
-}
-
-// Thread per task: add the `group` partial sums of the task, then normalise + compress as k_finalize does.
-__global__ __launch_bounds__(256) void k_finalize_sum(const Jac* __restrict__ part, int group, int n, Aff* __restrict__ out_aff,
-                                                      const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  Fp* buf = reinterpret_cast<Fp*>(smem);
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  Jac p = Jac::identity();
-  if (g < n) {
-    const Jac* src = part + (size_t)g * group;
-    p = src[0];
-    for (int j = 1; j < group; j++) p = jac_add_fn(p, src[j]);
-  }
-  const bool inf = p.is_identity();
-  Fp zinv = block_batch_inverse(p.z, buf);
-  if (g >= n) return;
-  Aff a = inf ? Aff::identity() : jac_to_affine_with_zinv(p, zinv);
-  if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
-  if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
 }
 
 // ------------------------------------------------------------------ fixed-base MSM over multiples tables
@@ -416,20 +320,20 @@ template <int CB> __device__ __forceinline__ void fix_digits8(const uint32_t* k,
   }
 }
 
-template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const Aff* __restrict__ tab, int nc,
-                                                                     Jac* __restrict__ part) {
+template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TAff* __restrict__ tab, int nc,
+                                                                     TJac* __restrict__ part) {
   constexpr int W = 256 / CB, WG = W / 8;          // waves per task
   constexpr uint32_t M = 1u << (CB - 1);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int16_t* digits = reinterpret_cast<int16_t*>(smem);   // [8][FIX_CHUNK]
-  Jac* red = reinterpret_cast<Jac*>(smem);              // [64] afterwards
+  TJac* red = reinterpret_cast<TJac*>(smem);              // [64] afterwards
   const FixTask task = tasks[blockIdx.x / WG];
   const int wg = blockIdx.x % WG;
   const int lane = threadIdx.x;
   const int wl = lane >> 3, sl = lane & 7;
   const uint32_t w = (uint32_t)(wg * 8 + wl);
-  const Aff* wtab = tab + (size_t)w * M * nc;
-  Jac acc = Jac::identity();
+  const TAff* wtab = tab + (size_t)w * M * nc;
+  TJac acc = TJac::identity();
 
   for (uint32_t base = 0; base < task.n; base += FIX_CHUNK) {
     const int m = min((uint32_t)FIX_CHUNK, task.n - base);
@@ -447,11 +351,11 @@ template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTa
       const bool h1 = i + 8 < m;
       const int d1 = h1 ? row[i + 8] : 0;
       const uint32_t g0 = base + i, g1 = base + i + 8;
-      Aff p0 = Aff::identity(), p1 = Aff::identity();
+      TAff p0 = TAff::identity(), p1 = TAff::identity();
       if (d0) p0 = wtab[(size_t)((d0 < 0 ? -d0 : d0) - 1) * nc + task.off + (task.idx ? task.idx[g0] : g0)];
       if (d1) p1 = wtab[(size_t)((d1 < 0 ? -d1 : d1) - 1) * nc + task.off + (task.idx ? task.idx[g1] : g1)];
-      if (d0) acc = jac_add_mixed(acc, aff_cneg(p0, d0 < 0));
-      if (d1) acc = jac_add_mixed(acc, aff_cneg(p1, d1 < 0));
+      if (d0) acc = t_add_mixed(acc, t_cneg(p0, d0 < 0));
+      if (d1) acc = t_add_mixed(acc, t_cneg(p1, d1 < 0));
     }
   }
   __syncthreads();
@@ -459,11 +363,11 @@ template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTa
   __syncthreads();
   for (int sft = 32; sft >= 1; sft >>= 1) {   // plain tree: all entries carry weight 1
     const bool has = lane < sft;
-    Jac other;
+    TJac other;
     if (has) other = red[lane + sft];
     __syncthreads();
     if (has) {
-      acc = jac_add(acc, other);
+      acc = t_add(acc, other);
       red[lane] = acc;
     }
     __syncthreads();
@@ -473,38 +377,38 @@ template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTa
 
 // Table of multiples from the shifted copies: thread per (window, base) walks m = 1..M with mixed additions and
 // normalises `chunk` entries at a time (own Montgomery trick + one inversion per work-group).
-template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const Aff* __restrict__ shift, int nc, Aff* __restrict__ tab, TblTmp* __restrict__ tmp, int chunk) {
+template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* __restrict__ shift, int nc, TAff* __restrict__ tab, TblTmp* __restrict__ tmp, int chunk) {
   constexpr int W = 256 / CB;
   constexpr uint32_t M = 1u << (CB - 1);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  Fp* buf = reinterpret_cast<Fp*>(smem);
+  TF* buf = reinterpret_cast<TF*>(smem);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = g < W * nc;
   const int w = live ? g / nc : 0, i = live ? g % nc : 0;
-  const Aff S = live ? shift[(size_t)w * nc + i] : Aff::identity();
+  const TAff S = live ? shift[(size_t)w * nc + i] : TAff::identity();
   const bool inf = S.is_identity();
   TblTmp* my = tmp + (size_t)g * chunk;
-  Aff* out = tab + (size_t)w * M * nc + i;
-  Jac acc = Jac::identity();
+  TAff* out = tab + (size_t)w * M * nc + i;
+  TJac acc = TJac::identity();
   for (uint32_t m0 = 0; m0 < M; m0 += chunk) {
-    Fp prod = Fp::one();
+    TF prod = t_one();
     if (live) {
       for (int j = 0; j < chunk; j++) {
-        acc = jac_add_mixed_fn(acc, S);          // (m0 + j + 1) * S
+        acc = t_add_mixed_fn(acc, S);          // (m0 + j + 1) * S
         my[j].p = acc;
         my[j].pre = prod;
-        if (!inf) prod = fe_mul(prod, acc.z);
+        if (!inf) prod = t_mul(prod, acc.z);
       }
     }
-    Fp inv = block_batch_inverse(prod, buf);
+    TF inv = t_block_batch_inverse(prod, buf);
     if (live) {
       for (int j = chunk - 1; j >= 0; j--) {
-        Aff a = Aff::identity();
+        TAff a = TAff::identity();
         if (!inf) {
-          const Jac p = my[j].p;
-          const Fp zinv = fe_mul(inv, my[j].pre);
-          inv = fe_mul(inv, p.z);
-          a = jac_to_affine_with_zinv(p, zinv);
+          const TJac p = my[j].p;
+          const TF zinv = t_mul(inv, my[j].pre);
+          inv = t_mul(inv, p.z);
+          a = t_to_affine(p, zinv);
         }
         out[(size_t)(m0 + j) * nc] = a;
       }
@@ -512,64 +416,68 @@ template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const Aff* _
   }
 }
 
-__global__ __launch_bounds__(256) void k_finalize_ranges(const Jac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
+// Thread per request: add its partial sums [first, first + count), normalise (one inversion per work-group),
+// convert to the standard form, scatter the affine point and emit the 48-byte compressed encoding.
+__global__ __launch_bounds__(256) void k_finalize_ranges(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
                                                          int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  Fp* buf = reinterpret_cast<Fp*>(smem);
+  TF* buf = reinterpret_cast<TF*>(smem);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  Jac p = Jac::identity();
+  TJac p = TJac::identity();
   if (g < n) {
-    const Jac* src = part + first[g];
+    const TJac* src = part + first[g];
     const uint32_t c = count[g];
     if (c) p = src[0];
-    for (uint32_t j = 1; j < c; j++) p = jac_add_fn(p, src[j]);
+    for (uint32_t j = 1; j < c; j++) p = t_add_fn(p, src[j]);
   }
   const bool inf = p.is_identity();
-  Fp zinv = block_batch_inverse(p.z, buf);
+  const TF zinv = t_block_batch_inverse(p.z, buf);
   if (g >= n) return;
-  Aff a = inf ? Aff::identity() : jac_to_affine_with_zinv(p, zinv);
+  const Aff a = inf ? Aff::identity() : t_to_std(t_to_affine(p, zinv));
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
   if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
 }
 
 // ------------------------------------------------------------------ table construction
-// Thread per base point: a chain of 256 - sb doublings, storing every sb-th value; the C-1 Jacobian copies
-// are normalised with the thread's own Montgomery trick plus one inversion per work-group.
-__global__ __launch_bounds__(256) void k_table_build(Aff* __restrict__ table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
-                                                     TblTmp* __restrict__ tmp) {
+// Thread per base point: reads the standard-form source point, writes copy 0 in table form, then runs a chain
+// of 256 - sb doublings storing every sb-th value; the C-1 Jacobian copies are normalised with the thread's own
+// Montgomery trick plus one inversion per work-group.
+__global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
+                                                     int npts, int copy_stride, int copies, TblTmp* __restrict__ tmp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  Fp* buf = reinterpret_cast<Fp*>(smem);
+  TF* buf = reinterpret_cast<TF*>(smem);
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)rows * npts;
   const bool live = g < total;
   const int sb = 256 / copies;
-  Aff* col = nullptr;
+  TAff* col = nullptr;
   TblTmp* mytmp = nullptr;
-  Fp prod = Fp::one();
+  TF prod = t_one();
   bool inf = true;
   if (live) {
     const long r = g / npts, i = g % npts;
     col = table + r * row_stride + i;
     mytmp = tmp + g * (copies - 1);
-    const Aff P = *col;
+    const TAff P = t_from_std(src[r * src_row_stride + i]);
+    col[0] = P;
     inf = P.is_identity();
-    Jac acc = Jac::from_affine(P);
+    TJac acc = TJac::from_affine(P);
     for (int c = 1; c < copies; c++) {
-      for (int s = 0; s < sb; s++) acc = jac_dbl_fn(acc);
+      for (int s = 0; s < sb; s++) acc = t_dbl_fn(acc);
       mytmp[c - 1].p = acc;
       mytmp[c - 1].pre = prod;               // z_1 ... z_{c-1}
-      if (!inf) prod = fe_mul(prod, acc.z);
+      if (!inf) prod = t_mul(prod, acc.z);
     }
   }
-  Fp inv = block_batch_inverse(prod, buf);   // 1 / (z_1 ... z_{C-1})
+  TF inv = t_block_batch_inverse(prod, buf);   // 1 / (z_1 ... z_{C-1})
   if (!live) return;
   for (int c = copies - 1; c >= 1; c--) {
-    Aff a = Aff::identity();
+    TAff a = TAff::identity();
     if (!inf) {
-      const Jac p = mytmp[c - 1].p;
-      const Fp zinv = fe_mul(inv, mytmp[c - 1].pre);   // inv = 1/(z_1..z_c)
-      inv = fe_mul(inv, p.z);
-      a = jac_to_affine_with_zinv(p, zinv);
+      const TJac p = mytmp[c - 1].p;
+      const TF zinv = t_mul(inv, mytmp[c - 1].pre);   // inv = 1/(z_1..z_c)
+      inv = t_mul(inv, p.z);
+      a = t_to_affine(p, zinv);
     }
     col[(size_t)c * copy_stride] = a;
   }
@@ -753,6 +661,16 @@ __global__ __launch_bounds__(256) void k_bench_fpmul(Fp* data, int iters) {
   }
   data[g] = fe_add(x, y);
 }
+// the same chain on the 28-bit-limb field (fp28.cuh)
+__global__ __launch_bounds__(256) void k_bench_f28mul(Fp* data, int iters) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  F28 x = f28_from_std(data[g]), y = f28_from_std(data[g + gridDim.x * blockDim.x]);
+  for (int i = 0; i < iters; i++) {
+    x = f28_mul(x, y);
+    y = f28_mul(y, x);
+  }
+  data[g] = f28_to_std(f28_add(x, y));
+}
 
 // ------------------------------------------------------------------ host-callable launchers
 void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream_t s) {
@@ -763,39 +681,33 @@ void launch_msm_tail(const Jac* d_in, Jac* d_out, int nout, int group, int shift
   if (nout <= 0) return;
   hipLaunchKernelGGL(k_msm_tail, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, nout, group, shift);
 }
-void launch_msm_tbl(const TblTask* d_tasks, int ntasks, int copies, Jac* d_out, hipStream_t s) {
-  if (ntasks <= 0) return;
-  hipLaunchKernelGGL(k_msm_tbl, dim3(ntasks), dim3(MSM_THREADS), MSM_LDS_BYTES, s, d_tasks, 64 / copies, d_out);
-}
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, Jac* d_part, hipStream_t s) {
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;
   hipLaunchKernelGGL(k_msm_tblw, dim3(ntasks * 8), dim3(64), TBW_LDS, s, d_tasks, d_part);
 }
-void launch_finalize_sum(const Jac* d_part, int group, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_finalize_sum, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(Fp), s, d_part, group, n, d_aff, d_dst_index, d_comp);
-}
-void launch_msm_fix(const FixTask* d_tasks, int ntasks, const Aff* d_fix_tab, int cbits, int nc, Jac* d_part, hipStream_t s) {
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int nc, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;
-  const size_t lds = 64 * sizeof(Jac);
+  const size_t lds = 64 * sizeof(TJac);
   if (cbits == 16) hipLaunchKernelGGL(k_msm_fix<16>, dim3(ntasks * 2), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
   else hipLaunchKernelGGL(k_msm_fix<8>, dim3(ntasks * 4), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
 }
-void launch_fix_build(const Aff* d_shift, int nc, int cbits, Aff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
+void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
   const int W = 256 / cbits, total = W * nc;
-  const size_t lds = 2 * 64 * sizeof(Fp);
+  const size_t lds = 2 * 64 * sizeof(TF);
   if (cbits == 16) hipLaunchKernelGGL(k_fix_build<16>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
   else hipLaunchKernelGGL(k_fix_build<8>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
 }
-void launch_finalize_ranges(const Jac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
+void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(Fp), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp);
+  hipLaunchKernelGGL(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp);
 }
-void launch_table_build(Aff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, TblTmp* d_tmp, hipStream_t s) {
+void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
+                        TblTmp* d_tmp, hipStream_t s) {
   const long total = (long)rows * npts;
   if (total <= 0) return;
-  hipLaunchKernelGGL(k_table_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 2 * 256 * sizeof(Fp), s, d_table, rows, row_stride, npts, copy_stride, copies, d_tmp);
+  hipLaunchKernelGGL(k_table_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 2 * 256 * sizeof(TF), s, d_src, src_row_stride, d_table, rows, row_stride, npts,
+                     copy_stride, copies, d_tmp);
 }
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
   if (n <= 0) return;
@@ -814,6 +726,9 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in, n, d_out, d_dst_index, d_status, check_subgroup);
+}
+void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s) {
+  hipLaunchKernelGGL(k_bench_f28mul, dim3(blocks), dim3(256), 0, s, d_data, iters);
 }
 void launch_bench_fpmul(Fp* d_data, int blocks, int iters, hipStream_t s) {
   hipLaunchKernelGGL(k_bench_fpmul, dim3(blocks), dim3(256), 0, s, d_data, iters);

@@ -2,9 +2,11 @@
 // host_math.hpp) for the CPU so that `pytest -m "not gpu"` can check the exact limb arithmetic,
 // point formulas, scalar recodings and the engine's transcript against the oracle without a GPU.
 // This is NOT a product path: nothing in curdleproofs_amd/ links or loads it.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "../../curdleproofs_amd/csrc/g1.cuh"
+#include "../../curdleproofs_amd/csrc/g1_28.cuh"
 #include "../../curdleproofs_amd/csrc/recode.cuh"
 #include "../../curdleproofs_amd/csrc/host_math.hpp"
 
@@ -143,5 +145,90 @@ void emul_challenges(const uint8_t* msg, size_t len, uint8_t out[64]) {
   memcpy(out + 32, b.f.v, 32);
 }
 void emul_keccak(uint64_t* st) { host::keccak_f1600(st); }
+
+// ---- 28-bit-limb lazy field (fp28.cuh / g1_28.cuh) ----
+static double f28_mag(const F28& a) {   // |value| / p, approximately
+  long double v = 0, pp = 0;
+  for (int i = 13; i >= 0; i--) {
+    v = v * 268435456.0L + a.v[i];
+    pp = pp * 268435456.0L + F28Cfg::P[i];
+  }
+  return (double)(v < 0 ? -v / pp : v / pp);
+}
+void emul_f28_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    Fp x, y;
+    memcpy(x.v, a + 48 * i, 48);
+    memcpy(y.v, b + 48 * i, 48);
+    Fp z = f28_to_std(f28_mul(f28_from_std(x), f28_from_std(y)));
+    memcpy(out + 48 * i, z.v, 48);
+  }
+}
+// lazy chain: ((x + y) * 8 - y * 2) * (x - y) - x * x, and the inverse of x
+void emul_f28_lazy(const uint8_t* a, const uint8_t* b, uint8_t* out /*2*48*/) {
+  Fp x, y;
+  memcpy(x.v, a, 48);
+  memcpy(y.v, b, 48);
+  const F28 X = f28_from_std(x), Y = f28_from_std(y);
+  const F28 t = f28_sub(f28_shl<3>(f28_add(X, Y)), f28_shl<1>(Y));
+  const F28 r = f28_sub(f28_mul(t, f28_sub(X, Y)), f28_sqr(X));
+  Fp o0 = f28_to_std(f28_mul(r, f28_one())), o1 = f28_to_std(f28_inv(f28_neg(X)));
+  memcpy(out, o0.v, 48);
+  memcpy(out + 48, o1.v, 48);
+}
+// sum k_i P_i by per-point double-and-add (mixed adds of table entries), then a Jacobian add chain; returns
+// the affine result in standard form and the largest coordinate magnitude seen (units of p) in mags[3]
+void emul_f28_msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out, double* mags) {
+  const Aff* P = reinterpret_cast<const Aff*>(bases);
+  Jac28 total = Jac28::identity();
+  double mx = 0, my = 0, mz = 0;
+  auto track = [&](const Jac28& j) {
+    mx = std::max(mx, f28_mag(j.x)); my = std::max(my, f28_mag(j.y)); mz = std::max(mz, f28_mag(j.z));
+  };
+  for (size_t i = 0; i < n; i++) {
+    Fr k;
+    memcpy(k.v, scalars + 32 * i, 32);
+    const Fr ks = fe_from_mont(k);
+    const Aff28 q = aff28_from_std(P[i]);
+    Jac28 acc = Jac28::identity();
+    for (int b = 254; b >= 0; b--) {
+      acc = jac28_dbl(acc);
+      track(acc);
+      if ((ks.v[b >> 5] >> (b & 31)) & 1u) {
+        acc = jac28_add_mixed(acc, (b & 1) ? aff28_cneg(aff28_cneg(q, true), true) : q);
+        track(acc);
+      }
+    }
+    total = jac28_add(total, acc);
+    track(total);
+  }
+  Aff r = Aff::identity();
+  if (!total.is_identity()) r = aff28_to_std(jac28_to_affine_with_zinv(total, f28_inv(total.z)));
+  memcpy(out, &r, 96);
+  mags[0] = mx; mags[1] = my; mags[2] = mz;
+}
+// exceptional cases of the complete formulas: P+P, P+(-P), P+O, O+P in mixed and Jacobian form -> 8 affine outputs
+void emul_f28_edges(const uint8_t* base, uint8_t* out /*8*96*/) {
+  Aff p;
+  memcpy(&p, base, 96);
+  const Aff28 q = aff28_from_std(p), nq = aff28_cneg(q, true);
+  Jac28 j = jac28_dbl(jac28_dbl(Jac28::from_affine(q)));           // 4P with Z != 1
+  const Jac28 j3 = jac28_add_mixed(j, nq);                           // 3P
+  const Jac28 j4b = jac28_add_mixed(j3, q);                          // 4P via another route (different Z)
+  Jac28 res[8] = {
+      jac28_add_mixed(Jac28::from_affine(q), q),                     // 2P via mixed doubling branch
+      jac28_add_mixed(Jac28::from_affine(q), nq),                    // O
+      jac28_add_mixed(j, Aff28::identity()),                         // 4P
+      jac28_add_mixed(Jac28::identity(), q),                         // P
+      jac28_add(j, j4b),                                             // 8P via Jacobian doubling branch
+      jac28_add(j, Jac28{j4b.x, f28_neg(j4b.y), j4b.z}),             // O
+      jac28_add(j, Jac28::identity()),                               // 4P
+      jac28_add(Jac28::identity(), j3)};                             // 3P
+  for (int i = 0; i < 8; i++) {
+    Aff r = Aff::identity();
+    if (!res[i].is_identity()) r = aff28_to_std(jac28_to_affine_with_zinv(res[i], f28_inv(res[i].z)));
+    memcpy(out + 96 * i, &r, 96);
+  }
+}
 
 }  // extern "C"

@@ -17,7 +17,7 @@ FR, AFF, JAC = 32, 96, 144
 
 @pytest.fixture(scope="module")
 def emul():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp", "fp28.cuh", "g1_28.cuh")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC])
     L = ctypes.CDLL(LIB)
@@ -27,6 +27,8 @@ def emul():
     L.emul_msm.argtypes = [vp, vp, sz, vp]
     L.emul_smul.argtypes = [vp, vp, vp, vp]
     L.emul_challenges.argtypes = [vp, sz, vp]
+    L.emul_f28_mul.argtypes = [vp, vp, vp, sz]
+    L.emul_f28_msm.argtypes = [vp, vp, sz, vp, vp]
     return L
 
 
@@ -121,3 +123,59 @@ def test_engine_transcript(emul, orc):
     b = _b(st)
     emul.emul_keccak(b)
     assert bytes(b) == orc.keccak_f1600(st)
+
+
+R_MONT = 1 << 384
+
+
+def _to_mont(x):
+    return (x * R_MONT % P).to_bytes(48, "little")
+
+
+def _from_mont(b):
+    return int.from_bytes(b, "little") * pow(R_MONT, -1, P) % P
+
+
+def test_f28_field_matches_oracle(emul, orc):
+    """The signed 28-bit-limb lazy field: conversions, products, lazy add/sub/shift chains, inversion."""
+    vals = [int.from_bytes(os.urandom(48), "little") % P for _ in range(200)] + [0, 1, P - 1, P - 2, 1 << 380, (P - 1) // 2]
+    a = b"".join(v.to_bytes(48, "little") for v in vals)
+    b = b"".join(v.to_bytes(48, "little") for v in reversed(vals))
+    o = _o(len(a))
+    emul.emul_f28_mul(_b(a), _b(b), o, len(vals))
+    assert bytes(o) == orc.fp_mul(a, b)
+    for x, y in zip(vals[:30] + vals[-6:], list(reversed(vals))[:30] + vals[-5:] + [7]):
+        if x == 0:
+            continue
+        r = _o(96)
+        emul.emul_f28_lazy(_b(_to_mont(x)), _b(_to_mont(y)), r)
+        assert _from_mont(bytes(r)[:48]) == (((x + y) * 8 - 2 * y) * (x - y) - x * x) % P
+        assert _from_mont(bytes(r)[48:]) == pow(-x, -1, P)
+
+
+def test_f28_point_formulas(emul, orc):
+    """Point arithmetic on the lazy field against the oracle, with the magnitude bounds of g1_28.cuh checked."""
+    n = 6
+    rng = orc.rng(77)
+    bases = bytearray(rng.g1_affine(n))
+    scalars = bytearray(rng.fr(n))
+    bases[AFF:2 * AFF] = bytes(AFF)
+    scalars[2 * FR:3 * FR] = bytes(FR)
+    rm1 = (0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001 - 1).to_bytes(32, "little")
+    scalars[3 * FR:4 * FR] = orc.fr_from_canonical_bytes(rm1)
+    o = _o(AFF)
+    mags = (ctypes.c_double * 3)()
+    emul.emul_f28_msm(_b(bytes(bases)), _b(bytes(scalars)), n, o, mags)
+    want = orc.g1_to_affine(orc.g1_msm(bytes(bases), bytes(scalars), naive=True))
+    assert bytes(o) == want
+    assert mags[0] <= 15.4 and mags[1] <= 15.4 and mags[2] <= 3.6, list(mags)
+    # exceptional branches of the complete formulas
+    g = rng.g1_affine(1)
+    one = orc.fr_from_u64
+
+    def mult(k):
+        return orc.g1_to_affine(orc.g1_msm(g, one(k), naive=True))
+    e = _o(8 * AFF)
+    emul.emul_f28_edges(_b(g), e)
+    got = [bytes(e)[i * AFF:(i + 1) * AFF] for i in range(8)]
+    assert got == [mult(2), bytes(AFF), mult(4), mult(1), mult(8), bytes(AFF), mult(4), mult(3)]

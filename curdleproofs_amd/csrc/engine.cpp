@@ -238,10 +238,10 @@ void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>
   launch_msm_accum(d_tasks_.p, (int)nt, d_wsum_.p, stream_);
   tock();
   tick("k_msm_tail", 0, (double)nt * 8);
-  launch_msm_tail(d_wsum_.p, d_part_.p, (int)nt * 8, 8, 4, stream_);
+  launch_msm_tail(d_wsum_.p, d_part_.p, nullptr, (int)nt * 8, 8, 4, stream_);
   tock();
   tick("k_msm_tail", 0, (double)nt);
-  launch_msm_tail(d_part_.p, d_res_.p, (int)nt, 8, 32, stream_);
+  launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)nt, 8, 32, stream_);
   tock();
   tick("k_finalize", 0, (double)nt);
   launch_finalize(d_res_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
@@ -480,7 +480,8 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   DevBuf<Aff> db;
   DevBuf<Fr> ds;
   DevBuf<MsmTask> dt;
-  DevBuf<Jac> w, pt, res;
+  DevBuf<TJac> w, pt;
+  DevBuf<Jac> res;
   db.ensure(std::max<size_t>(n, 1));
   ds.ensure(std::max<size_t>(n, 1));
   dt.ensure(1);
@@ -496,8 +497,8 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   tick("k_msm_accum", 128.0 * n, (double)n);
   launch_msm_accum(dt.p, 1, w.p, stream_);
   tock();
-  launch_msm_tail(w.p, pt.p, 8, 8, 4, stream_);
-  launch_msm_tail(pt.p, res.p, 1, 8, 32, stream_);
+  launch_msm_tail(w.p, pt.p, nullptr, 8, 8, 4, stream_);
+  launch_msm_tail(pt.p, nullptr, res.p, 1, 8, 32, stream_);
   CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
   flush_timers();
@@ -1250,8 +1251,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, side_.stream));
     CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, side_.stream));
     launch_msm_accum(side_.tasks.p, (int)nt, side_.wsum.p, side_.stream);
-    launch_msm_tail(side_.wsum.p, side_.part.p, (int)nt * 8, 8, 4, side_.stream);
-    launch_msm_tail(side_.part.p, side_.res.p, (int)nt, 8, 32, side_.stream);
+    launch_msm_tail(side_.wsum.p, side_.part.p, nullptr, (int)nt * 8, 8, 4, side_.stream);
+    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 8, 32, side_.stream);
     launch_finalize(side_.res.p, (int)nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
   }
 

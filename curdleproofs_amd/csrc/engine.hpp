@@ -158,7 +158,8 @@ class Engine {
     DevBuf<MsmTask> tasks;
     DevBuf<SmulTask> stasks;
     DevBuf<Fr> scal;
-    DevBuf<Jac> wsum, part, res;
+    DevBuf<TJac> wsum, part;
+    DevBuf<Jac> res;
     DevBuf<uint32_t> dst;
     DevBuf<uint8_t> comp;
     PinBuf<uint8_t> stage, hcomp;
@@ -229,8 +230,9 @@ class Engine {
   DevBuf<MsmTask> d_tasks_;
   DevBuf<SmulTask> d_stasks_;
   DevBuf<Fr> d_scal_;
-  DevBuf<Jac> d_wsum_, d_part_, d_res_;
-  DevBuf<TJac> d_tpart_;     // partial sums of the table kernels
+  DevBuf<TJac> d_wsum_, d_part_;   // window sums / Horner partials of the bucket MSM (table representation)
+  DevBuf<Jac> d_res_;
+  DevBuf<TJac> d_tpart_;           // partial sums of the table kernels
   DevBuf<uint32_t> d_dst_;
   DevBuf<uint8_t> d_comp_;
   PinBuf<uint8_t> h_stage_;

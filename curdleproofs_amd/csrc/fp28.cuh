@@ -121,7 +121,38 @@ CPX_HD F28 f28_mul(const F28& a, const F28& b) {
   return f28_mul_regs(a.v[0], a.v[1], a.v[2], a.v[3], a.v[4], a.v[5], a.v[6], a.v[7], a.v[8], a.v[9], a.v[10], a.v[11], a.v[12], a.v[13],
                       b.v[0], b.v[1], b.v[2], b.v[3], b.v[4], b.v[5], b.v[6], b.v[7], b.v[8], b.v[9], b.v[10], b.v[11], b.v[12], b.v[13]);
 }
-CPX_HD F28 f28_sqr(const F28& a) { return f28_mul(a, a); }
+// Squaring: the 91 off-diagonal limb products are taken once against the doubled operand (301 multiply-adds
+// instead of 392).
+CPX_HD F28 f28_sqr_body(const F28& a) {
+  int32_t m[14], d[14];
+  CPX_UNROLL for (int i = 0; i < 14; i++) d[i] = a.v[i] * 2;   // |limb| < 2^29
+  F28 t;
+  int64_t acc = 0;
+  CPX_UNROLL for (int k = 0; k < 14; k++) {
+    CPX_UNROLL for (int i = 0; 2 * i < k; i++) acc += (int64_t)d[i] * a.v[k - i];
+    if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+    CPX_UNROLL for (int i = 0; i < k; i++) acc += (int64_t)m[i] * F28Cfg::P[k - i];
+    m[k] = (int32_t)(((uint32_t)acc * F28Cfg::INV) & (uint32_t)F28Cfg::MASK);
+    acc += (int64_t)m[k] * F28Cfg::P[0];
+    acc >>= 28;
+  }
+  CPX_UNROLL for (int k = 14; k < 27; k++) {
+    CPX_UNROLL for (int i = k - 13; 2 * i < k; i++) acc += (int64_t)d[i] * a.v[k - i];
+    if ((k & 1) == 0) acc += (int64_t)a.v[k / 2] * a.v[k / 2];
+    CPX_UNROLL for (int i = k - 13; i < 14; i++) acc += (int64_t)m[i] * F28Cfg::P[k - i];
+    t.v[k - 14] = (int32_t)acc & F28Cfg::MASK;
+    acc >>= 28;
+  }
+  t.v[13] = (int32_t)acc;
+  return t;
+}
+CPX_HD_FN F28 f28_sqr_regs(CPX_A14(a)) {
+  const F28 x{{CPX_L14(a)}};
+  return f28_sqr_body(x);
+}
+CPX_HD F28 f28_sqr(const F28& a) {
+  return f28_sqr_regs(a.v[0], a.v[1], a.v[2], a.v[3], a.v[4], a.v[5], a.v[6], a.v[7], a.v[8], a.v[9], a.v[10], a.v[11], a.v[12], a.v[13]);
+}
 
 CPX_HD F28 f28_const(const int32_t* c) {
   F28 r;

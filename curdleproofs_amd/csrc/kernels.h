@@ -76,10 +76,11 @@ void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, T
 void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s);
 
-// ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian) ...
-void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream_t s);
-// ... then Horner tails: out[t] = sum_{j<group} 2^(shift*j) in[t*group+j]; (8,4) then (8,32) gives the MSM results
-void launch_msm_tail(const Jac* d_in, Jac* d_out, int nout, int group, int shift, hipStream_t s);
+// ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian, table representation) ...
+void launch_msm_accum(const MsmTask* d_tasks, int ntasks, TJac* d_wsum, hipStream_t s);
+// ... then Horner tails: out[t] = sum_{j<group} 2^(shift*j) in[t*group+j]; (8,4) then (8,32) gives the MSM results.
+// Exactly one of d_out (table representation) / d_out_std (standard form, last stage) is non-null.
+void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s);
 // Jacobian -> affine (+ optional scatter through dst_index) and optional 48-byte compressed form.
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
 // `batch` rows of n points, row r starting at d_in + r*stride; output dense [batch][n][48]

@@ -118,25 +118,25 @@ __device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
 
 // ------------------------------------------------------------------ MSM: bucket accumulation
 // One work-group per task.  Thread t owns bucket (window w = t / 8, magnitude b = t % 8 + 1).
-// LDS: digit rows [64][MSM_CHUNK] int8, staged points [MSM_CHUNK] Aff; afterwards the same LDS is
-// reused for the 512 bucket sums (Jacobian) that wave 0 folds into 64 window sums.
+// LDS: digit rows [64][MSM_CHUNK] int8, staged points [MSM_CHUNK] (converted to the 28-bit-limb table form
+// while staging); afterwards the same LDS is reused for the 512 bucket sums that are folded into 64 window sums.
 constexpr int MSM_THREADS = 512;
 constexpr int MSM_CHUNK = 256;
-constexpr int MSM_LDS_BYTES = 512 * (int)sizeof(Jac);   // 73,728 B >= 64*256 + 256*96 = 40,960 B
+constexpr int MSM_LDS_BYTES = 512 * (int)sizeof(TJac);   // 86,016 B >= 64*256 + 256*112 = 45,056 B
 
 #ifndef CPX_MSM_WAVES
 #define CPX_MSM_WAVES 2   // waves per SIMD the register allocator must leave room for (2 = one 512-thread group per CU)
 #endif
-__global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const MsmTask* __restrict__ tasks, Jac* __restrict__ wsum) {
+__global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const MsmTask* __restrict__ tasks, TJac* __restrict__ wsum) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int8_t* digits = reinterpret_cast<int8_t*>(smem);                       // [64][MSM_CHUNK]
-  Aff* pts = reinterpret_cast<Aff*>(smem + 64 * MSM_CHUNK);               // [MSM_CHUNK]
-  Jac* buckets = reinterpret_cast<Jac*>(smem);                            // [512] (aliases the above later)
+  TAff* pts = reinterpret_cast<TAff*>(smem + 64 * MSM_CHUNK);             // [MSM_CHUNK], table representation
+  TJac* buckets = reinterpret_cast<TJac*>(smem);                          // [512] (aliases the above later)
 
   const MsmTask task = tasks[blockIdx.x];
   const int tid = threadIdx.x;
   const int w = tid >> 3, mag = (tid & 7) + 1;
-  Jac acc = Jac::identity();
+  TJac acc = TJac::identity();
 
   for (uint32_t base = 0; base < task.n; base += MSM_CHUNK) {
     const int m = min((uint32_t)MSM_CHUNK, task.n - base);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const 
       recode_signed16(k.v, digits + tid, MSM_CHUNK);
     } else if (tid >= 256 && tid - 256 < m) {
       const uint32_t j = base + tid - 256;
-      pts[tid - 256] = task.bases[task.idx ? task.idx[j] : j];
+      pts[tid - 256] = t_from_std(task.bases[task.idx ? task.idx[j] : j]);   // converted once, used by 64 windows
     }
     __syncthreads();
     const int8_t* row = digits + w * MSM_CHUNK;
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const 
       const bool have = i < m;
       if (!__any(have)) break;
       if (have) {
-        Aff q = pts[i];
-        acc = jac_add_mixed(acc, aff_cneg(q, d < 0));
+        const TAff q = pts[i];
+        acc = t_add_mixed(acc, t_cneg(q, d < 0));
         i++;
       }
     }
@@ -178,22 +178,22 @@ __global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const 
   const int b = tid & 7;
   for (int sft = 1; sft < 8; sft <<= 1) {
     const bool has = b + sft < 8;
-    Jac other;
+    TJac other;
     if (has) other = buckets[tid + sft];
     __syncthreads();
     if (has) {
-      acc = jac_add(acc, other);
+      acc = t_add(acc, other);
       buckets[tid] = acc;
     }
     __syncthreads();
   }
   for (int sft = 4; sft >= 1; sft >>= 1) {
     const bool has = b < sft;
-    Jac other;
+    TJac other;
     if (has) other = buckets[tid + sft];
     __syncthreads();
     if (has) {
-      acc = jac_add(acc, other);
+      acc = t_add(acc, other);
       buckets[tid] = acc;
     }
     __syncthreads();
@@ -484,17 +484,20 @@ __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src
 }
 
 // ------------------------------------------------------------------ MSM: Horner tails
-// out[t] = sum_{j < group} 2^(shift*j) in[t*group + j], one lane per output.
-__global__ __launch_bounds__(64) void k_msm_tail(const Jac* __restrict__ in, Jac* __restrict__ out, int nout, int group, int shift) {
+// out[t] = sum_{j < group} 2^(shift*j) in[t*group + j], one lane per output; the last stage hands the result
+// over in the standard form.
+template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const TJac* __restrict__ in, TJac* __restrict__ out, Jac* __restrict__ out_std, int nout,
+                                                                         int group, int shift) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nout) return;
-  const Jac* src = in + (size_t)t * group;
-  Jac acc = src[group - 1];
+  const TJac* src = in + (size_t)t * group;
+  TJac acc = src[group - 1];
   for (int j = group - 2; j >= 0; j--) {
-    for (int s = 0; s < shift; s++) acc = jac_dbl(acc);
-    acc = jac_add(acc, src[j]);
+    for (int s = 0; s < shift; s++) acc = t_dbl(acc);
+    acc = t_add(acc, src[j]);
   }
-  out[t] = acc;
+  if (STD_OUT) out_std[t] = t_jac_to_std(acc);
+  else out[t] = acc;
 }
 
 // ------------------------------------------------------------------ normalise + compress
@@ -673,13 +676,14 @@ __global__ __launch_bounds__(256) void k_bench_f28mul(Fp* data, int iters) {
 }
 
 // ------------------------------------------------------------------ host-callable launchers
-void launch_msm_accum(const MsmTask* d_tasks, int ntasks, Jac* d_wsum, hipStream_t s) {
+void launch_msm_accum(const MsmTask* d_tasks, int ntasks, TJac* d_wsum, hipStream_t s) {
   if (ntasks <= 0) return;
   hipLaunchKernelGGL(k_msm_accum, dim3(ntasks), dim3(MSM_THREADS), MSM_LDS_BYTES, s, d_tasks, d_wsum);
 }
-void launch_msm_tail(const Jac* d_in, Jac* d_out, int nout, int group, int shift, hipStream_t s) {
+void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s) {
   if (nout <= 0) return;
-  hipLaunchKernelGGL(k_msm_tail, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, nout, group, shift);
+  if (d_out_std) hipLaunchKernelGGL(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift);
+  else hipLaunchKernelGGL(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift);
 }
 void launch_msm_tblw(const TblTask* d_tasks, int ntasks, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;

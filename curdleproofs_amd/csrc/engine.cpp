@@ -181,13 +181,21 @@ template <class F> void Engine::parallel_for(size_t n, F&& f) {
     pool_.reset(new WorkerPool(T));
   }
   const std::function<void(size_t)> fn = [&](size_t i) { f(i); };
-  const auto t0 = std::chrono::steady_clock::now();
+  HostSpan w(this, "host_parallel_for");
   pool_->run(n, fn);
-  if (profiling_) {
-    KernelStat& st = stats_["host_parallel_for"];
-    st.launches++;
-    st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  }
+}
+
+// wall-clock spans of host work, reported next to the kernel statistics when profiling is on
+Engine::HostSpan::HostSpan(Engine* e, const char* name) : e_(e), name_(name), t0_(std::chrono::steady_clock::now()) {}
+Engine::HostSpan::~HostSpan() {
+  if (!e_->profiling_) return;
+  KernelStat& st = e_->stats_[name_];
+  st.launches++;
+  st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
+}
+void Engine::wait_stream() {
+  HostSpan w(this, "host_wait_device");
+  CPX_HIP(hipStreamSynchronize(stream_));
 }
 
 const uint32_t* Engine::idx_list(const std::vector<uint32_t>& v) {
@@ -221,16 +229,20 @@ void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>
   Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
   MsmTask* ht = reinterpret_cast<MsmTask*>(h_stage_.p + total * sizeof(Fr));
   uint32_t* hd = reinterpret_cast<uint32_t*>(h_stage_.p + total * sizeof(Fr) + nt * sizeof(MsmTask));
+  std::vector<size_t> soff(nt);
   size_t off = 0;
-  double alg = 0;
   for (size_t i = 0; i < nt; i++) {
-    const MsmReq& r = reqs[i];
-    for (uint32_t j = 0; j < r.n; j++) hs[off + j] = r.scalars[j].f;
-    ht[i] = MsmTask{r.bases, r.idx, d_scal_.p + off, r.n, 0};
-    hd[i] = r.dst;
-    off += r.n;
-    alg += 128.0 * r.n;   // 96 B affine base + 32 B scalar per MSM point
+    soff[i] = off;
+    off += reqs[i].n;
   }
+  const double alg = 128.0 * (double)total;   // 96 B affine base + 32 B scalar per MSM point
+  parallel_for(nt, [&](size_t i) {
+    const MsmReq& r = reqs[i];
+    Fr* d = hs + soff[i];
+    for (uint32_t j = 0; j < r.n; j++) d[j] = r.scalars[j].f;
+    ht[i] = MsmTask{r.bases, r.idx, d_scal_.p + soff[i], r.n, 0};
+    hd[i] = r.dst;
+  });
   CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, total * sizeof(Fr), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_tasks_.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
@@ -249,7 +261,7 @@ void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>
   if (comp_out) {
     h_comp_.ensure(nt * 48);
     CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, nt * 48, hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipStreamSynchronize(stream_));
+    wait_stream();
     comp_out->assign(h_comp_.p, h_comp_.p + nt * 48);
   }
 }
@@ -271,7 +283,7 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
   tick("k_smul", alg_bytes, (double)tasks.size() * cnt);
   launch_smul(d_stasks_.p, (int)tasks.size(), cnt, stream_);
   tock();
-  CPX_HIP(hipStreamSynchronize(stream_));   // staging buffer reuse safety
+  wait_stream();   // staging buffer reuse safety
 }
 
 // Table-backed MSM phase: every request is one work-group of k_msm_tbl; results are normalised + compressed.
@@ -383,13 +395,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   if (comp_out) {
     h_comp_.ensure(nt * 48);
     CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, nt * 48, hipMemcpyDeviceToHost, stream_));
-    const auto t0 = std::chrono::steady_clock::now();
-    CPX_HIP(hipStreamSynchronize(stream_));
-    if (profiling_) {
-      KernelStat& st = stats_["host_wait_device"];
-      st.launches++;
-      st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
+    wait_stream();
     comp_out->assign(h_comp_.p, h_comp_.p + nt * 48);
   }
 }
@@ -627,30 +633,34 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
   for (DevBuf<Aff>* w : {&d_wGi_, &d_wGp_, &d_wGm_, &d_wT_, &d_wU_}) w->ensure(batch * (n_ + 1));
   B_ = batch;
   const size_t vb = ell_ * sizeof(Aff);
-  for (size_t p = 0; p < batch; p++) {
-    CPX_HIP(hipMemcpyAsync(pp(p), vec_R + p * vb, vb, hipMemcpyHostToDevice, stream_));
-    CPX_HIP(hipMemcpyAsync(pp(p) + ell_, vec_S + p * vb, vb, hipMemcpyHostToDevice, stream_));
-    CPX_HIP(hipMemcpyAsync(pp(p) + 2 * ell_, vec_T + p * vb, vb, hipMemcpyHostToDevice, stream_));
-    CPX_HIP(hipMemcpyAsync(pp(p) + 3 * ell_, vec_U + p * vb, vb, hipMemcpyHostToDevice, stream_));
-    CPX_HIP(hipMemcpyAsync(slot(p, SL_H), crs_single_, 5 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
-  }
+  // strided 2-D copies: one per instance vector instead of one per proof
+  const size_t pitch = pp_stride_ * sizeof(Aff);
+  auto rows = [&](Aff* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width) {
+    CPX_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, batch, hipMemcpyHostToDevice, stream_));
+  };
+  rows(pp(0), pitch, vec_R, vb, vb);
+  rows(pp(0) + ell_, pitch, vec_S, vb, vb);
+  rows(pp(0) + 2 * ell_, pitch, vec_T, vb, vb);
+  rows(pp(0) + 3 * ell_, pitch, vec_U, vb, vb);
+  std::vector<Aff> rep(batch * 5);   // the same constants for every proof (a pitch of 0 is not a valid 2-D copy)
+  for (size_t p = 0; p < batch; p++) memcpy(&rep[5 * p], crs_single_, 5 * sizeof(Aff));
+  rows(slot(0, SL_H), pitch, reinterpret_cast<const uint8_t*>(rep.data()), 5 * sizeof(Aff), 5 * sizeof(Aff));
   CPX_HIP(hipMemcpyAsync(d_Mjac_.p, M, batch * sizeof(Jac), hipMemcpyHostToDevice, stream_));
+  std::vector<Aff> tails;   // outlives the asynchronous copies below (synchronised at the end of this function)
   if (use_tables_) {
     // copy 0 of the per-proof tables: M (filled at prove time) | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
     const size_t NP = np();
     d_ptab_.ensure(batch * (size_t)copies_ * NP);
     d_psrc_.ensure(batch * NP);
     d_tbltmp_.ensure(std::max(batch * NP, n_ + 3) * (size_t)(copies_ - 1));
-    std::vector<Aff> tails(8, Aff::identity());
-    tails[2] = crs_single_[0];
-    tails[7] = crs_single_[0];
-    for (size_t p = 0; p < batch; p++) {
-      Aff* t = d_psrc_.p + p * NP;
-      CPX_HIP(hipMemcpyAsync(t + 1, vec_T + p * vb, vb, hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + ell_, tails.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + n_, vec_U + p * vb, vb, hipMemcpyHostToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(t + 1 + n_ + ell_, tails.data() + 4, 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
-    }
+    tails.assign(batch * 8, Aff::identity());
+    for (size_t p = 0; p < batch; p++) tails[8 * p + 2] = tails[8 * p + 7] = crs_single_[0];
+    const size_t spitch = NP * sizeof(Aff);
+    Aff* t = d_psrc_.p;
+    rows(t + 1, spitch, vec_T, vb, vb);
+    rows(t + 1 + ell_, spitch, reinterpret_cast<const uint8_t*>(tails.data()), 8 * sizeof(Aff), 4 * sizeof(Aff));
+    rows(t + 1 + n_, spitch, vec_U, vb, vb);
+    rows(t + 1 + n_ + ell_, spitch, reinterpret_cast<const uint8_t*>(tails.data() + 4), 8 * sizeof(Aff), 4 * sizeof(Aff));
   }
   CPX_HIP(hipStreamSynchronize(stream_));
 }
@@ -1141,6 +1151,7 @@ void Engine::batch_prove_fold(const uint32_t* permutation, const uint8_t* k_in, 
 // commitment (B, D, cm_T, cm_A, A', ...) expands into an MSM over CRS / instance points.  Hence: no basis
 // folds, no per-round normalisation, every MSM runs on pre-shifted tables (k_msm_tbl) without a doubling tail.
 void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
+  HostSpan wall(this, "host_prove_wall");
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;
   const SlotMap sm(L);
@@ -1170,25 +1181,28 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   const TblSeg none{nullptr, nullptr, 0, 0};
 
   // -- P0: compressed instance vectors, M -> affine (into table slot 0), then the per-proof tables
-  std::vector<uint8_t> inst_comp(B * 4 * ell * 48);
+  h_inst_comp_.ensure(B * 4 * ell * 48);   // pinned and persistent: no page faults, true async copies
+  h_mcomp_.ensure(B * 48);
+  h_u32_.ensure(B);
+  const uint8_t* inst_comp = h_inst_comp_.p;
   {
     d_bytes_.ensure(B * 4 * ell * 48);
-    tick("k_compress", 0, (double)(4 * ell * B));
+      tick("k_compress", 0, (double)(4 * ell * B));
     launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
     tock();
     d_dst_.ensure(B);
     d_comp_.ensure(B * 48);
-    std::vector<uint32_t> dst(B);
+    uint32_t* dst = h_u32_.p;
     for (size_t p = 0; p < B; p++) dst[p] = (uint32_t)(p * NP + O_M);
-    CPX_HIP(hipMemcpyAsync(d_dst_.p, dst.data(), B * 4, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_dst_.p, dst, B * 4, hipMemcpyHostToDevice, stream_));
     launch_finalize(d_Mjac_.p, (int)B, d_psrc_.p, d_dst_.p, d_comp_.p, stream_);
     tick("k_table_build", 0, (double)(B * NP));
     launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, d_tbltmp_.p, stream_);
     tock();
-    std::vector<uint8_t> mcomp(B * 48);
-    CPX_HIP(hipMemcpyAsync(inst_comp.data(), d_bytes_.p, inst_comp.size(), hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipMemcpyAsync(mcomp.data(), d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipStreamSynchronize(stream_));
+    const uint8_t* mcomp = h_mcomp_.p;
+    CPX_HIP(hipMemcpyAsync(h_inst_comp_.p, d_bytes_.p, B * 4 * ell * 48, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(h_mcomp_.p, d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
+    wait_stream();
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       s.rnd = rand + p * nrand * 32;
@@ -1494,7 +1508,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   {
     std::vector<uint8_t> id_comp(48, 0);
     id_comp[0] = 0xc0;
-    CPX_HIP(hipEventSynchronize(side_.ev));   // R, S and the four T_2 commitments from the side stream
+    { HostSpan w(this, "host_wait_device"); CPX_HIP(hipEventSynchronize(side_.ev)); }   // R, S and the four T_2 commitments from the side stream
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       s.c_final = s.c[0];
@@ -1613,6 +1627,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
 
 // ---------------------------------------------------------------- verifier
 void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdict) {
+  HostSpan wall(this, "host_verify_wall");
   if (!B_) throw std::logic_error("batch_load first");
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;
@@ -1663,24 +1678,30 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
   }
 
   // -- V0: decompress proof points into their slots; M -> affine; compressed instance vectors
-  std::vector<uint8_t> inst_comp(B * 4 * ell * 48), mcomp(B * 48);
+  h_inst_comp_.ensure(B * 4 * ell * 48);
+  h_mcomp_.ensure(B * 48);
+  const uint8_t* inst_comp = h_inst_comp_.p;
+  const uint8_t* mcomp = h_mcomp_.p;
   {
-    std::vector<uint8_t> pts((size_t)B * NPP * 48);
-    std::vector<uint32_t> dst((size_t)B * NPP);
-    for (size_t p = 0; p < B; p++)
+    const size_t npts = (size_t)B * NPP;
+    h_pts_.ensure(npts * 48);
+    h_u32_.ensure(npts + B);
+    h_status_.ensure(npts);
+    uint8_t* pts = h_pts_.p;
+    uint32_t* dst = h_u32_.p;
+    parallel_for(B, [&](size_t p) {
       for (int q = 0; q < NPP; q++) {
         memcpy(&pts[(p * NPP + q) * 48], proofs + p * psz + pt_off[q], 48);
         dst[p * NPP + q] = slot_index(p, SL_A + q);
       }
-    DevBuf<uint8_t> d_in;
-    DevBuf<uint32_t> d_dst;
-    d_in.ensure(pts.size());
-    d_dst.ensure(dst.size());
-    d_status_.ensure(dst.size());
-    CPX_HIP(hipMemcpyAsync(d_in.p, pts.data(), pts.size(), hipMemcpyHostToDevice, stream_));
-    CPX_HIP(hipMemcpyAsync(d_dst.p, dst.data(), dst.size() * 4, hipMemcpyHostToDevice, stream_));
-    tick("k_decompress", 0, (double)dst.size());
-    launch_decompress(d_in.p, (int)dst.size(), d_pp_.p, d_dst.p, d_status_.p, 1, stream_);
+    });
+    d_vin_.ensure(npts * 48);
+    d_vdst_.ensure(npts);
+    d_status_.ensure(npts);
+      CPX_HIP(hipMemcpyAsync(d_vin_.p, pts, npts * 48, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_vdst_.p, dst, npts * 4, hipMemcpyHostToDevice, stream_));
+    tick("k_decompress", 0, (double)npts);
+    launch_decompress(d_vin_.p, (int)npts, d_pp_.p, d_vdst_.p, d_status_.p, 1, stream_);
     tock();
     d_bytes_.ensure(B * 4 * ell * 48);
     tick("k_compress", 0, (double)(4 * ell * B));
@@ -1688,15 +1709,15 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     tock();
     d_dst_.ensure(B);
     d_comp_.ensure(B * 48);
-    std::vector<uint32_t> mdst(B);
+    uint32_t* mdst = h_u32_.p + npts;
     for (size_t p = 0; p < B; p++) mdst[p] = slot_index(p, SL_M);
-    CPX_HIP(hipMemcpyAsync(d_dst_.p, mdst.data(), B * 4, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_dst_.p, mdst, B * 4, hipMemcpyHostToDevice, stream_));
     launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
-    std::vector<uint8_t> status(dst.size());
-    CPX_HIP(hipMemcpyAsync(status.data(), d_status_.p, status.size(), hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipMemcpyAsync(inst_comp.data(), d_bytes_.p, inst_comp.size(), hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipMemcpyAsync(mcomp.data(), d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipStreamSynchronize(stream_));
+    const uint8_t* status = h_status_.p;
+    CPX_HIP(hipMemcpyAsync(h_status_.p, d_status_.p, npts, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(h_inst_comp_.p, d_bytes_.p, B * 4 * ell * 48, hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(h_mcomp_.p, d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
+    wait_stream();
     for (size_t p = 0; p < B; p++)
       for (int q = 0; q < NPP; q++)
         if (status[p * NPP + q]) st[p].bad = true;

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -181,6 +182,14 @@ class Engine {
   void tock();
   void flush_timers();
   template <class F> void parallel_for(size_t n, F&& f);
+  struct HostSpan {
+    HostSpan(Engine* e, const char* name);
+    ~HostSpan();
+    Engine* e_;
+    const char* name_;
+    std::chrono::steady_clock::time_point t0_;
+  };
+  void wait_stream();
 
   // per-proof table row: copy-major [copies][NP]
   size_t np() const { return 1 + 2 * n_; }   // M | T_b | U_b   (R and S are used once: no table)
@@ -237,6 +246,10 @@ class Engine {
   DevBuf<uint8_t> d_comp_;
   PinBuf<uint8_t> h_stage_;
   PinBuf<uint8_t> h_comp_;
+  PinBuf<uint8_t> h_inst_comp_, h_mcomp_, h_pts_, h_status_;   // compressed instance vectors / M, proof points in, decompression status
+  PinBuf<uint32_t> h_u32_;
+  DevBuf<uint8_t> d_vin_;
+  DevBuf<uint32_t> d_vdst_;
   std::map<std::vector<uint32_t>, uint32_t*> idx_cache_;
   std::vector<uint32_t*> idx_allocs_;
   DevBuf<uint8_t> d_bytes_;

@@ -83,12 +83,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (BASELINE configs[3] batch size)")
+    ap.add_argument("--batch", type=int, default=2048, help="instances per GPU per step (2 x the BASELINE configs[3] batch, split over the engine contexts)")
     ap.add_argument("--ell", type=int, default=252)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per engine context (0 = cores / (ranks x contexts), clamped to [8, 48])")
     ap.add_argument("--synth-cache", default="", help="pickle file for the synthetic batch (created if missing): keeps profiled runs free of setup kernels")
-    ap.add_argument("--ctxs", type=int, default=1, help="engine contexts (HIP streams + host threads) per GPU; the batch is split over them")
+    ap.add_argument("--ctxs", type=int, default=2, help="engine contexts (HIP streams + host threads) per GPU; the batch is split over them so that "
+                    "one context's Fiat-Shamir / scalar work on the host overlaps the other's kernels")
     args = ap.parse_args()
 
     import torch
@@ -105,9 +106,9 @@ def main():
     ell, B, K = args.ell, args.batch, max(1, args.ctxs)
     assert B % K == 0, "--batch must be a multiple of --ctxs"
     ctxs = [cpx.Context(local_rank) for _ in range(K)]          # raises without a GPU: no CPU fallback
+    host_threads = args.host_threads or max(8, min(48, (os.cpu_count() or 64) // (max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))) * K)))
     for c in ctxs:
-        if args.host_threads:
-            c.set_host_threads(args.host_threads)
+        c.set_host_threads(host_threads)
     ctx = ctxs[0]
     data = None
     cache = args.synth_cache and ("%s.r%d" % (args.synth_cache, rank))
@@ -207,7 +208,7 @@ def main():
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs)
             with open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")) as f:
                 hc = json.load(f).get("cpx::" + dom)
-            if hc and hc["batch_per_gpu"] == B:
+            if hc and hc["batch_per_gpu"] == B and hc.get("engine_contexts_per_gpu", 1) == K:
                 # counters are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)
                 traffic = (2.0 * hc["FETCH_SIZE"]["total"] / hc["FETCH_SIZE"]["dispatches"]
                            + hc["WRITE_SIZE"]["total"] / hc["WRITE_SIZE"]["dispatches"]) * 1024.0
@@ -216,15 +217,25 @@ def main():
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, avg_launch_ms=avg_ms, launches=st["launches"], alg_bytes_per_launch=bytes_per_launch,
                         units_per_launch=st["units"] / max(st["launches"], 1),
-                        note="integer big-number path: VALU (v_mad_u64_u32) bound, HBM fraction is tiny by construction; "
-                             "see DESIGN.md for the integer-MAD roofline")
+                        note="integer big-number path: VALU (v_mad_i64_i32) bound, the HBM fraction is tiny by construction; "
+                             "roofline.valu gives the modular-multiplication roofline (DESIGN.md section 5)")
+        # The honest bound of this integer path: modular multiplications on the VALU.  Peak = dependent
+        # Montgomery-product chains on the table kernels' 28-bit-limb field at full occupancy, measured now on this GPU
+        # (k_bench_f28mul); achieved = the dominant kernel's point additions x 11 products (7M + 4S mixed addition).
+        mulmods_per_point = {"k_msm_tblw": 64 * 15.0 / 16 * 11, "k_msm_accum": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * 11.0, "k_smul": 0.0}[dom]
+        os.environ["CPX_BENCH_FIELD"] = "28"
+        peak_mm = ctxs[0].bench_fpmul(2048, 1000, 2)
+        ach_mm = st["units"] * mulmods_per_point / (st["ms"] * 1e-3) if st["ms"] else 0.0
+        roofline["valu"] = dict(achieved=ach_mm, peak=peak_mm, unit="381-bit modular products/s", frac=ach_mm / peak_mm if peak_mm else None,
+                                mulmods_per_point=mulmods_per_point,
+                                note="kernel time is measured with both engine contexts sharing the GPU, so it includes the other context's kernels")
         out = dict(metric="shuffle proofs/sec (prove+verify) at ell=%d, BLS12-381" % ell, value=value, unit="proofs/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="u32", data="synthetic",
+                   vs_baseline=None, dtype="int64", data="synthetic",
                    config=dict(workload="ell=%d (n=%d, log2 n=%d): %d independent shuffle instances per GPU per step, each proven "
                                         "(CurdleproofsProof::new) then verified; BASELINE configs[1] instance shape, per-GPU share "
                                         "of configs[3]" % (ell, n, L, B),
-                               ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, parallelism="proofs sharded over %d GPU(s), no collective" % world),
+                               ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads, parallelism="proofs sharded over %d GPU(s), no collective" % world),
                    all_verified=all_ok, algorithmic_bytes_per_proof=b_prove + b_verify,
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items()},

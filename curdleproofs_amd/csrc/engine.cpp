@@ -80,12 +80,16 @@ void Engine::tick(const char* name, double bytes, double units) {
   CPX_HIP(hipEventCreate(&t.b));
   t.name = name;
   t.bytes = bytes;
-  CPX_HIP(hipEventRecord(t.a, stream_));
+  set_launch_events(t.a, t.b);   // bound to the next dispatch: kernel begin / end
   pending_.push_back(t);
 }
 void Engine::tock() {
   if (!profiling_) return;
-  CPX_HIP(hipEventRecord(pending_.back().b, stream_));
+  if (launches_since_set() == 0) {   // nothing was launched (empty phase): give the events a defined state
+    CPX_HIP(hipEventRecord(pending_.back().a, stream_));
+    CPX_HIP(hipEventRecord(pending_.back().b, stream_));
+  }
+  set_launch_events(nullptr, nullptr);
 }
 void Engine::flush_timers() {
   if (pending_.empty()) return;
@@ -290,10 +294,10 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
 void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out) {
   const size_t nt = reqs.size();
   if (!nt) return;
-  const bool fix = fix_bits_ && d_fixtab_.p;
+  const bool fix = fix_bits_ && fixtab();
   const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / 8) : 0;
-  const TAff* c_lo = d_ctab_.p;
-  const TAff* c_hi = d_ctab_.p + (size_t)copies_ * (n_ + 3);
+  const TAff* c_lo = ctab();
+  const TAff* c_hi = ctab() + (size_t)copies_ * (n_ + 3);
   auto is_crs = [&](const TblSeg& sg) { return fix && sg.n && sg.base >= c_lo && sg.base < c_hi; };
   // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
   std::vector<size_t> soff(nt);
@@ -381,7 +385,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   if (nft) {
     tick("k_msm_fix", 128.0 * pts_fix, pts_fix);
-    launch_msm_fix(d_ftasks_.p, (int)nft, d_fixtab_.p, fix_bits_, (int)(n_ + 3), d_tpart_.p, stream_);
+    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, (int)(n_ + 3), d_tpart_.p, stream_);
     tock();
   }
   if (ntt) {
@@ -443,35 +447,56 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
   launch_compress(d_pp_.p, 1, 1, 1, d_comp_.p, stream_);
   CPX_HIP(hipMemcpyAsync(crs_H_comp_, d_comp_.p, 48, hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
-  // shifted-base table of the CRS: built once per CRS, shared by every proof
+  // shifted-base table + fixed-base table of multiples: built once per (device, CRS), shared by every proof and
+  // by every engine of this process on the device
   {
+    static std::mutex reg_mu;
+    static std::vector<std::weak_ptr<CrsTables>> registry;
+    std::lock_guard<std::mutex> lk(reg_mu);
     const size_t NC = n + 3;
-    d_ctab_.ensure((size_t)copies_ * NC);
-    std::vector<Aff> row(NC);
-    for (size_t i = 0; i < n; i++) row[i] = pts[i];
-    row[n] = pts[n];
-    row[n + 1] = pts[n + 1];
-    row[n + 2] = pts[n + 2];
-    DevBuf<Aff> d_row;
-    d_row.ensure(NC);
-    CPX_HIP(hipMemcpy(d_row.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
-    d_tbltmp_.ensure(NC * (size_t)(copies_ - 1));
-    launch_table_build(d_row.p, 0, d_ctab_.p, 1, 0, (int)NC, (int)NC, copies_, d_tbltmp_.p, stream_);
-    CPX_HIP(hipStreamSynchronize(stream_));
-    if (fix_bits_ && use_tables_) {
-      // fixed-base table of multiples m * 2^(c w) * P, m <= 2^(c-1): shifted copies first, then the multiples
-      const int W = 256 / fix_bits_;
-      const size_t M = size_t(1) << (fix_bits_ - 1);
-      DevBuf<TAff> d_shift;
-      d_shift.ensure((size_t)W * NC);
-      d_tbltmp_.ensure(NC * (size_t)(W - 1));
-      launch_table_build(d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, d_tbltmp_.p, stream_);
-      d_fixtab_.ensure((size_t)W * M * NC);
-      const int chunk = (int)std::min<size_t>(256, M);
-      const size_t threads = ((size_t)W * NC + 63) / 64 * 64;
-      d_tbltmp_.ensure(threads * chunk);
-      launch_fix_build(d_shift.p, (int)NC, fix_bits_, d_fixtab_.p, d_tbltmp_.p, chunk, stream_);
+    const int want_fix = use_tables_ ? fix_bits_ : 0;
+    std::vector<uint8_t> key(points, points + (ell + 7) * sizeof(Aff));
+    crs_tab_.reset();
+    for (auto it = registry.begin(); it != registry.end();) {
+      auto sp = it->lock();
+      if (!sp) {
+        it = registry.erase(it);
+        continue;
+      }
+      if (sp->device == device_ && sp->fix_bits == want_fix && sp->key == key) crs_tab_ = sp;
+      ++it;
+    }
+    if (!crs_tab_) {
+      auto tab = std::make_shared<CrsTables>();
+      tab->device = device_;
+      tab->fix_bits = want_fix;
+      tab->key = std::move(key);
+      tab->ctab.ensure((size_t)copies_ * NC);
+      std::vector<Aff> row(NC);
+      for (size_t i = 0; i < n + 3; i++) row[i] = pts[i];   // G | Hvec | H | G_t | G_u
+      DevBuf<Aff> d_row;
+      d_row.ensure(NC);
+      CPX_HIP(hipMemcpy(d_row.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
+      DevBuf<TblTmp> tmp;   // build scratch, released afterwards
+      tmp.ensure(NC * (size_t)(copies_ - 1));
+      launch_table_build(d_row.p, 0, tab->ctab.p, 1, 0, (int)NC, (int)NC, copies_, tmp.p, stream_);
       CPX_HIP(hipStreamSynchronize(stream_));
+      if (want_fix) {
+        // multiples m * 2^(c w) * P, m <= 2^(c-1): shifted copies first, then the multiples
+        const int W = 256 / want_fix;
+        const size_t M = size_t(1) << (want_fix - 1);
+        DevBuf<TAff> d_shift;
+        d_shift.ensure((size_t)W * NC);
+        launch_table_build(d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, tmp.p, stream_);
+        tab->fixtab.ensure((size_t)W * M * NC);
+        const int chunk = (int)std::min<size_t>(256, M);
+        const size_t threads = ((size_t)W * NC + 63) / 64 * 64;
+        tmp.ensure(threads * chunk);
+        launch_fix_build(d_shift.p, (int)NC, want_fix, tab->fixtab.p, tmp.p, chunk, stream_);
+        CPX_HIP(hipStreamSynchronize(stream_));
+      }
+      registry.push_back(tab);
+      crs_tab_ = tab;
     }
   }
 }
@@ -1939,7 +1964,7 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     const uint32_t* e3 = idx_list({(uint32_t)sm.CMB1(), (uint32_t)SL_CMU1, (uint32_t)SL_GU});
     const uint32_t* e4 = idx_list({(uint32_t)sm.CMB2(), (uint32_t)SL_CMU2, (uint32_t)SL_S, (uint32_t)SL_H});
     const uint32_t* ecomb = idx_list({(uint32_t)sm.TMP(0), (uint32_t)sm.TMP(1), (uint32_t)sm.TMP(2), (uint32_t)sm.TMP(3)});
-    const bool fix_crs = fix_bits_ && d_fixtab_.p && use_tables_;
+    const bool fix_crs = fix_bits_ && fixtab() && use_tables_;
     std::vector<MsmReq> reqs;
     for (size_t p = 0; p < B; p++) {
       VState& s = st[p];

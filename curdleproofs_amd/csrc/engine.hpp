@@ -195,7 +195,7 @@ class Engine {
   size_t np() const { return 1 + 2 * n_; }   // M | T_b | U_b   (R and S are used once: no table)
   TAff* ptab(size_t p) const { return d_ptab_.p + p * (size_t)copies_ * np(); }
   TblSeg pseg(size_t p, size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ptab(p) + off, idx, (uint32_t)np(), cnt}; }
-  TblSeg cseg(size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{d_ctab_.p + off, idx, (uint32_t)(n_ + 3), cnt}; }
+  TblSeg cseg(size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ctab() + off, idx, (uint32_t)(n_ + 3), cnt}; }
   Aff* pp(size_t p) const { return d_pp_.p + p * pp_stride_; }
   Aff* slot(size_t p, int s) const { return pp(p) + 4 * ell_ + s; }
   uint32_t slot_index(size_t p, int s) const { return (uint32_t)(p * pp_stride_ + 4 * ell_ + s); }
@@ -218,13 +218,22 @@ class Engine {
   // shifted-base tables (all-MSM prover)
   static constexpr int copies_ = 64;   // table copies per base: 2^(4c) P, one per radix-16 window
   bool use_tables_ = true;
-  DevBuf<TAff> d_ctab_;      // CRS table [copies][n+3] : G | Hvec | H | G_t | G_u   (table representation)
+  // CRS tables are immutable once built and large (15 GB at ell = 252): engines on the same device that are
+  // given the same CRS share one copy (process-wide registry in engine.cpp).
+  struct CrsTables {
+    int device = 0, fix_bits = 0;
+    std::vector<uint8_t> key;   // the CRS points the tables were built from
+    DevBuf<TAff> ctab;         // shifted copies [copies][n+3] : G | Hvec | H | G_t | G_u   (table representation)
+    DevBuf<TAff> fixtab;       // multiples [256/c][2^(c-1)][n+3]
+  };
+  std::shared_ptr<CrsTables> crs_tab_;
+  const TAff* ctab() const { return crs_tab_ ? crs_tab_->ctab.p : nullptr; }
+  const TAff* fixtab() const { return crs_tab_ ? crs_tab_->fixtab.p : nullptr; }
   DevBuf<TAff> d_ptab_;      // per-proof tables [B][copies][NP]
   DevBuf<Aff> d_psrc_;       // their standard-form sources [B][NP] : M | T_b | U_b
   DevBuf<TblTmp> d_tbltmp_;
   DevBuf<TblTask> d_ttasks_;
   int fix_bits_ = 16;        // fixed-base CRS table of multiples: radix 2^16 (13 GB at ell = 252), 2^8 (0.1 GB) or 0 = off
-  DevBuf<TAff> d_fixtab_;    // [256/c][2^(c-1)][n+3]
   DevBuf<FixTask> d_ftasks_;
   DevBuf<uint32_t> d_pfirst_, d_pcount_;
 

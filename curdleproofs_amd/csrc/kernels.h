@@ -8,6 +8,11 @@ namespace cpx {
 
 enum : uint32_t { MSM_SCALARS_CANONICAL = 1u };
 
+// Profiling hook: the next launches of the calling thread bind these events to the kernel's begin / end
+// (nullptr, nullptr = plain launches).
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
+int launches_since_set();
+
 // One multi-scalar multiplication  sum_i scalars[i] * bases[idx ? idx[i] : i],  i < n.
 // All pointers are device pointers.  Scalars are Fr in Montgomery form unless flagged canonical.
 struct MsmTask {

@@ -265,7 +265,7 @@ class Context:
         self._check(self._L.cpx_get_stat(self._h, name.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(un)))
         return dict(launches=n.value, ms=ms.value, alg_bytes=by.value, units=un.value)
 
-    KERNELS = ("k_msm_fix", "k_msm_tblw", "k_finalize_ranges", "k_table_build", "k_msm_accum", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_prove_wall", "host_verify_wall")
+    KERNELS = ("k_msm_fix", "k_msm_tblw", "k_finalize_ranges", "k_table_build", "k_msm_accum", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_wait_baton", "host_prove_wall", "host_verify_wall")
 
     def stats(self):
         return {k: self.stat(k) for k in self.KERNELS}

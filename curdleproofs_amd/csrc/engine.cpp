@@ -58,6 +58,7 @@ Engine::Engine(int device) : device_(device) {
   CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   CPX_HIP(hipStreamCreateWithFlags(&side_.stream, hipStreamNonBlocking));
   CPX_HIP(hipEventCreateWithFlags(&side_.ev, hipEventDisableTiming));
+  baton_register(+1);
   if (const char* e = getenv("CPX_PROVER")) use_tables_ = std::string(e) != "fold";
   if (const char* e = getenv("CPX_FIX_BITS")) {
     int c = atoi(e);
@@ -65,6 +66,8 @@ Engine::Engine(int device) : device_(device) {
   }
 }
 Engine::~Engine() {
+  baton_release();
+  baton_register(-1);
   for (auto p : idx_allocs_) (void)hipFree(p);
   if (side_.ev) (void)hipEventDestroy(side_.ev);
   if (side_.stream) (void)hipStreamDestroy(side_.stream);
@@ -197,9 +200,57 @@ Engine::HostSpan::~HostSpan() {
   st.launches++;
   st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
 }
+// ---- host baton -----------------------------------------------------------------------------------------
+// Several engines on one GPU (one host thread each) take turns on the HOST side: an engine holds the device's
+// baton while it runs host work and enqueues kernels, and passes it on whenever it blocks on its stream.  Kernels
+// of different engines still overlap freely on the GPU.  Two effects: the engines fall into anti-phase (one
+// hashes transcripts and prepares scalars while the other one's kernels run) instead of the lock-step that
+// fair GPU sharing otherwise pulls them into (both finish their kernels together, then both leave the GPU idle
+// during their host halves), and their worker pools never compete for the same cores.
+namespace {
+struct HostBaton {   // FIFO ticket lock
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t next = 0, serving = 0;
+  std::atomic<int> engines{0};
+};
+HostBaton g_batons[64];
+bool baton_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("CPX_HOST_BATON");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+}  // namespace
+void Engine::baton_register(int delta) { g_batons[device_ & 63].engines += delta; }
+void Engine::baton_acquire() {
+  HostBaton& g = g_batons[device_ & 63];
+  if (baton_held_ || !baton_enabled() || g.engines.load(std::memory_order_relaxed) < 2) return;
+  HostSpan w(this, "host_wait_baton");
+  std::unique_lock<std::mutex> lk(g.mu);
+  const uint64_t my = g.next++;
+  g.cv.wait(lk, [&] { return g.serving == my; });
+  baton_held_ = true;
+}
+void Engine::baton_release() {
+  if (!baton_held_) return;
+  HostBaton& g = g_batons[device_ & 63];
+  {
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.serving++;
+  }
+  g.cv.notify_all();
+  baton_held_ = false;
+}
 void Engine::wait_stream() {
-  HostSpan w(this, "host_wait_device");
-  CPX_HIP(hipStreamSynchronize(stream_));
+  const bool had = baton_held_;
+  baton_release();
+  {
+    HostSpan w(this, "host_wait_device");
+    CPX_HIP(hipStreamSynchronize(stream_));
+  }
+  if (had) baton_acquire();
 }
 
 const uint32_t* Engine::idx_list(const std::vector<uint32_t>& v) {
@@ -1177,6 +1228,7 @@ void Engine::batch_prove_fold(const uint32_t* permutation, const uint8_t* k_in, 
 // folds, no per-round normalisation, every MSM runs on pre-shifted tables (k_msm_tbl) without a doubling tail.
 void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   HostSpan wall(this, "host_prove_wall");
+  BatonScope baton(this);
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;
   const SlotMap sm(L);
@@ -1533,7 +1585,15 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   {
     std::vector<uint8_t> id_comp(48, 0);
     id_comp[0] = 0xc0;
-    { HostSpan w(this, "host_wait_device"); CPX_HIP(hipEventSynchronize(side_.ev)); }   // R, S and the four T_2 commitments from the side stream
+    {
+      const bool had = baton_held_;
+      baton_release();
+      {
+        HostSpan w(this, "host_wait_device");
+        CPX_HIP(hipEventSynchronize(side_.ev));
+      }
+      if (had) baton_acquire();
+    }   // R, S and the four T_2 commitments from the side stream
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       s.c_final = s.c[0];
@@ -1653,6 +1713,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
 // ---------------------------------------------------------------- verifier
 void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdict) {
   HostSpan wall(this, "host_verify_wall");
+  BatonScope baton(this);
   if (!B_) throw std::logic_error("batch_load first");
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;

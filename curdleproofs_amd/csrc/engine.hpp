@@ -190,6 +190,16 @@ class Engine {
     std::chrono::steady_clock::time_point t0_;
   };
   void wait_stream();
+  // per-device host baton between engines (engine.cpp)
+  void baton_register(int delta);
+  void baton_acquire();
+  void baton_release();
+  bool baton_held_ = false;
+  struct BatonScope {
+    explicit BatonScope(Engine* e) : e_(e) { e_->baton_acquire(); }
+    ~BatonScope() { e_->baton_release(); }
+    Engine* e_;
+  };
 
   // per-proof table row: copy-major [copies][NP]
   size_t np() const { return 1 + 2 * n_; }   // M | T_b | U_b   (R and S are used once: no table)

@@ -232,6 +232,36 @@ def test_prove_matches_reference_kat_ell124(ctx, orc, whisk_kat):
     assert ctx.verify_batch([proof], rng.fr(8)) == [cpx.CPX_OK]
 
 
+def test_shuffle_permute_and_commit_input_matches_oracle_and_kat(ctx, orc, whisk_kat):
+    # util.rs:83-106 on the product API (curdleproofs_amd.util): k*R, k*S, permutation, M = msm(G, sigma) + msm(H, blinders).
+    # Inputs as in whisk.rs:416-456, so M must compress to the first 48 bytes of the reference's shuffle-proof vector.
+    from curdleproofs_amd import util
+    ell = 124
+    kat = bytes.fromhex(whisk_kat["whisk_shuffle_proof_ell124"])
+    crs = orc.generate_crs_points(ell)
+    rng = orc.rng(0)
+    gen = orc.g1_generator()
+    vec_R, vec_S = b"", b""
+    for _ in range(ell):
+        k, r = rng.fr(1), rng.fr(1)
+        rG = orc.g1_scale(gen, r)
+        vec_R += rG
+        vec_S += orc.g1_scale(rG, k)
+    perm = rng.shuffle(ell)
+    k = rng.fr(1)
+    mb = rng.fr(4)
+    want_T, want_U, want_M = orc.shuffle_permute_and_commit_input(ell, crs, vec_R, vec_S, perm, k, mb)
+    got_T, got_U, got_M = util.shuffle_permute_and_commit_input(ctx, crs, ell, vec_R, vec_S, perm, k, mb)
+    assert got_T == want_T and got_U == want_U
+    assert util.serialize_g1projective_vec(ctx, got_M) == kat[:48] == orc.g1_compress_jac(want_M)
+    # (de)serialisation helpers round-trip (util.rs:116-133)
+    comp = util.serialize_g1projective_vec(ctx, got_M + want_M)
+    assert util.deserialize_g1projective_vec(ctx, comp, 2) == orc.g1_to_affine(got_M) * 2
+    with pytest.raises(ValueError):
+        util.msm(ctx, crs[:96 * 3], mb)   # util.rs:20 assert_eq!(points.len(), scalars.len())
+    assert util.get_verification_scalars_bitstring(4, 2) == [[], [1], [0], [0, 1]]
+
+
 def test_prove_verify_ell252_batch(ctx, orc, oracle_vectors):
     # BASELINE config 2 (single ell = 252 instance, seed 0) inside a small batch (config 4 recipe: seed = index)
     crs, insts, proofs = _prove_and_check(ctx, orc, 252, [0, 1, 2])

@@ -346,10 +346,15 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   const size_t nt = reqs.size();
   if (!nt) return;
   const bool fix = fix_bits_ && fixtab();
-  const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / 8) : 0;
+  const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / FIX_WINDOWS_PER_WAVE) : 0;
   const TAff* c_lo = ctab();
   const TAff* c_hi = ctab() + (size_t)copies_ * (n_ + 3);
   auto is_crs = [&](const TblSeg& sg) { return fix && sg.n && sg.base >= c_lo && sg.base < c_hi; };
+  auto needs_tbl = [&](const TblReq& r) { return !fix || (r.seg0.n && !is_crs(r.seg0)) || (r.seg1.n && !is_crs(r.seg1)); };
+  size_t ntt_total = 0;
+  for (const TblReq& r : reqs) ntt_total += needs_tbl(r) ? 1 : 0;
+  const int tbl_wpw = msm_tblw_windows_per_wave((int)ntt_total);   // windows per wave of the shifted-table kernel
+  const uint32_t tbl_parts = (uint32_t)(64 / tbl_wpw);
   // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
   std::vector<size_t> soff(nt);
   std::vector<uint32_t> pfirst(nt), pcount(nt), tt_index(nt, ~0u), ft_index(nt * 2, ~0u);
@@ -361,10 +366,9 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     total += r.seg0.n + r.seg1.n;
     pfirst[i] = (uint32_t)nparts;
     const bool f0 = is_crs(r.seg0), f1 = is_crs(r.seg1);
-    const bool need_tbl = (r.seg0.n && !f0) || (r.seg1.n && !f1);
-    if (need_tbl || !fix) {
+    if (needs_tbl(r)) {
       tt_index[i] = (uint32_t)ntt++;
-      nparts += 8;
+      nparts += tbl_parts;
     }
     if (f0) {
       ft_index[2 * i] = (uint32_t)nft++;
@@ -414,7 +418,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
       t.flags = 0;
       t.pad = slot;
       ht[tt_index[i]] = t;
-      slot += 8;
+      slot += tbl_parts;
     }
     if (f0) {
       hf[ft_index[2 * i]] = FixTask{r.seg0.idx, d_scal_.p + soff[i], (uint32_t)(r.seg0.base - c_lo), r.seg0.n, 0, slot};
@@ -441,7 +445,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   }
   if (ntt) {
     tick("k_msm_tblw", 128.0 * pts_tbl, pts_tbl);
-    launch_msm_tblw(d_ttasks_.p, (int)ntt, d_tpart_.p, stream_);
+    launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_tpart_.p, stream_);
     tock();
   }
   tick("k_finalize_ranges", 0, (double)nt);

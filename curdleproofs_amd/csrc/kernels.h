@@ -48,14 +48,15 @@ struct TblTask {
   TblSeg seg[2];            // bases = seg[0] followed by seg[1]
   const Fr* scalars;        // seg[0].n + seg[1].n scalars
   uint32_t flags;
-  uint32_t pad;             // first partial slot of the task; it writes 8 partials
+  uint32_t pad;             // first partial slot of the task; it writes 64 / wpw partials
 };
 struct TblTmp {   // table-build scratch: a Jacobian copy and the running product of the previous copies' Z
   TJac p;
   TF pre;
 };
-// single-wave work-groups, 8 per task -> d_part[task.pad + j], j < 8
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, TJac* d_part, hipStream_t s);
+// single-wave work-groups owning wpw (8, 16, 32 or 64) windows each: 64 / wpw per task -> d_part[task.pad + j], j < 64 / wpw
+int msm_tblw_windows_per_wave(int ntasks);
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, hipStream_t s);
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
 void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
@@ -64,16 +65,17 @@ void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, 
 // ---- fixed-base MSM over a table of multiples (CRS bases) ----
 // fix_tab[(w*M + (m-1))*nc + i] = m * 2^(c*w) * P_i  (affine), w < W = 256/c windows, m = 1..M = 2^(c-1), i < nc.
 // A scalar is W signed radix-2^c digits; digit d of window w selects entry |d| directly: one mixed addition per
-// (point, window), no buckets.  One wave handles 8 windows of a task (lane = window x 8 point slices): every lane
-// performs the same number of additions.
+// (point, window), no buckets.  One wave handles FIX_WINDOWS_PER_WAVE windows of a task (lane = window x point
+// slice): every lane performs the same number of additions.
 struct FixTask {
   const uint32_t* idx;      // optional gather list of base indices (< nc)
   const Fr* scalars;
   uint32_t off;             // first base index when idx == nullptr
   uint32_t n;
   uint32_t flags;
-  uint32_t out_first;       // first partial slot of this task; it writes W/8 partials
+  uint32_t out_first;       // first partial slot of this task; it writes W / FIX_WINDOWS_PER_WAVE partials
 };
+constexpr int FIX_WINDOWS_PER_WAVE = 16;
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int nc, TJac* d_part, hipStream_t s);
 // shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);

@@ -19,6 +19,7 @@
 //    the NAF-driven add branch is wave-uniform; the Jacobian results are normalised with one Fp
 //    inversion per work-group (LDS product scans) instead of the reference's one inversion per point.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_ext.h>
 #include "g1.cuh"
 #include "tarith.cuh"
@@ -202,16 +203,19 @@ __global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const 
   if (b == 0) wsum[(size_t)blockIdx.x * 64 + w] = acc;
 }
 
-// ------------------------------------------------------------------ table-backed MSM, one wave per 8 windows
-// Barrier-free variant for 64-copy tables (every radix-16 window has its own pre-shifted copy, so all window
-// sums carry weight 1): a single-wave work-group owns windows [8*w8, 8*w8+8) of one task, lane = (window,
-// bucket).  Waves never wait for each other, and the CU scheduler backfills a finished wave's slot with the
-// next one of the grid, which is what keeps both wave slots of a SIMD issuing (PMC: the 8-wave group version
-// idles 67 % of its wave-cycles at barriers / s_waitcnt).  Output: one partial sum per wave; k_finalize_ranges
-// adds the partials of a request.  Window w reads the pre-shifted copy w of each base straight from the table
-// in HBM/L2 (one gather per digit addition); only the digit rows are staged in LDS.
-constexpr int TBW_CHUNK = 256;
-constexpr int TBW_LDS = 64 * (int)sizeof(TJac);   // >= 8 * 256 digit bytes
+// ------------------------------------------------------------------ table-backed MSM, barrier-free single-wave groups
+// 64-copy tables: every radix-16 window of a scalar has its own pre-shifted copy of the base, so ALL window
+// sums carry weight 1 and a bucket may collect additions from any window.  A single-wave work-group owns WPW
+// consecutive windows of one task; lane = (bucket magnitude b = 1..8, point slice s = 0..7) walks the
+// (window, point) pairs of its slice whose digit is +-b.  More windows per wave = more pairs per lane = better
+// balance (the slowest lane of a wave decides: Binomial(16 WPW, 1/8) at 128 points) and fewer fixed-cost bucket
+// reductions (9 point additions per wave); the launcher picks the largest WPW that still fills the GPU.
+// Waves never wait for each other, and the CU scheduler backfills a finished wave's slot with the next one of
+// the grid (an 8-wave group version idled 67 % of its wave-cycles at barriers / s_waitcnt).  Points are gathered
+// from the table in HBM/L2 (one gather per digit addition); only the digit rows are staged in LDS.
+// Output: one partial sum per wave; k_finalize_ranges adds the partials of a request.
+constexpr int TBW_CHUNK = 128;
+constexpr int tbw_lds(int wpw) { return wpw * TBW_CHUNK > 64 * (int)sizeof(TJac) ? wpw * TBW_CHUNK : 64 * (int)sizeof(TJac); }
 
 __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
   const uint32_t n0 = t.seg[0].n;
@@ -221,15 +225,15 @@ __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, u
 }
 
 
-__global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, TJac* __restrict__ part) {
+template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, TJac* __restrict__ part) {
+  constexpr int WV = 64 / WPW;   // waves per task
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [8][TBW_CHUNK]
-  TJac* red = reinterpret_cast<TJac*>(smem);            // [64] (aliases the digits afterwards)
-  const TblTask task = tasks[blockIdx.x >> 3];
-  const int w8 = blockIdx.x & 7;
+  int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [WPW][TBW_CHUNK]
+  TJac* red = reinterpret_cast<TJac*>(smem);          // [64] (aliases the digits afterwards)
+  const TblTask task = tasks[blockIdx.x / WV];
+  const int wv = blockIdx.x % WV, w0 = wv * WPW;
   const int lane = threadIdx.x;
-  const int wl = lane >> 3, mag = (lane & 7) + 1;
-  const uint32_t copy = (uint32_t)(w8 * 8 + wl);
+  const int mag = (lane & 7) + 1, sl = lane >> 3;
   const uint32_t ntot = task.seg[0].n + task.seg[1].n;
   TJac acc = TJac::identity();
 
@@ -241,33 +245,38 @@ __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ 
       if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
       int8_t d[64];
       recode_signed16(k.v, d);
-      CPX_UNROLL for (int j = 0; j < 8; j++) digits[j * TBW_CHUNK + t] = d[w8 * 8 + j];
+      CPX_UNROLL for (int j = 0; j < WPW; j++) digits[j * TBW_CHUNK + t] = d[w0 + j];
     }
     __syncthreads();
-    const int8_t* row = digits + wl * TBW_CHUNK;
-    int i = 0;
+    int j = 0, i = sl;
     for (;;) {
+      // cheap divergent scan to this lane's next (window, point) pair with digit +-mag
       int d = 0;
-      while (i < m) {
-        d = row[i];
-        if (d == mag || d == -mag) break;
-        i++;
+      while (j < WPW) {
+        const int8_t* row = digits + j * TBW_CHUNK;
+        while (i < m) {
+          d = row[i];
+          if (d == mag || d == -mag) break;
+          i += 8;
+        }
+        if (i < m) break;
+        j++;
+        i = sl;
       }
-      const bool have = i < m;
+      const bool have = j < WPW;
       if (!__any(have)) break;
       if (have) {
-        const TAff q = *tbl_point(task, base + i, copy);
+        const TAff q = *tbl_point(task, base + i, (uint32_t)(w0 + j));
         acc = t_add_mixed(acc, t_cneg(q, d < 0));
-        i++;
+        i += 8;
       }
     }
   }
   __syncthreads();
   red[lane] = acc;
   __syncthreads();
-  const int b = lane & 7;
-  for (int sft = 1; sft < 8; sft <<= 1) {           // suffix sums over the 8 bucket lanes of a window
-    const bool has = b + sft < 8;
+  for (int sft = 32; sft >= 8; sft >>= 1) {         // merge the 8 slices of every bucket: lanes 0..7 hold B_1..B_8
+    const bool has = lane < sft;
     TJac other;
     if (has) other = red[lane + sft];
     __syncthreads();
@@ -277,8 +286,8 @@ __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ 
     }
     __syncthreads();
   }
-  for (int sft = 4; sft >= 1; sft >>= 1) {          // ... summed: sum_b b * B_b in lane b == 0
-    const bool has = b < sft;
+  for (int sft = 1; sft < 8; sft <<= 1) {           // suffix sums S_b = B_b + ... + B_8 over lanes 0..7
+    const bool has = lane < 8 && lane + sft < 8;
     TJac other;
     if (has) other = red[lane + sft];
     __syncthreads();
@@ -288,8 +297,8 @@ __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ 
     }
     __syncthreads();
   }
-  for (int sft = 32; sft >= 8; sft >>= 1) {         // the wave's 8 window sums (weight 1 each)
-    const bool has = (b == 0) && lane < sft;
+  for (int sft = 4; sft >= 1; sft >>= 1) {          // ... summed: sum_b b * B_b in lane 0
+    const bool has = lane < sft;
     TJac other;
     if (has) other = red[lane + sft];
     __syncthreads();
@@ -299,14 +308,14 @@ __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ 
     }
     __syncthreads();
   }
-  if (lane == 0) part[task.pad + w8] = acc;   // task.pad = first partial slot of the task
+  if (lane == 0) part[task.pad + wv] = acc;   // task.pad = first partial slot of the task
 }
 
 // ------------------------------------------------------------------ fixed-base MSM over multiples tables
 constexpr int FIX_CHUNK = 256;
 
-// signed radix-2^c digits (c = 8 or 16) of a canonical scalar; writes the 8 digits of windows [w0, w0+8)
-template <int CB> __device__ __forceinline__ void fix_digits8(const uint32_t* k, int w0, int16_t* out, int stride) {
+// signed radix-2^c digits (c = 8 or 16) of a canonical scalar; writes the NW digits of windows [w0, w0+NW)
+template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint32_t* k, int w0, int16_t* out, int stride) {
   constexpr int W = 256 / CB;
   constexpr uint32_t HALF = 1u << (CB - 1), FULL = 1u << CB;
   uint32_t carry = 0;
@@ -317,22 +326,26 @@ template <int CB> __device__ __forceinline__ void fix_digits8(const uint32_t* k,
     // No carry leaves the top window: scalars are < r < 2^255, so the top chunk is < 2^(c-1) - 1.
     const int d = (v >= HALF) ? (int)v - (int)FULL : (int)v;
     carry = (v >= HALF) ? 1u : 0u;
-    if (w >= w0 && w < w0 + 8) out[(w - w0) * stride] = (int16_t)d;
+    if (w >= w0 && w < w0 + NW) out[(w - w0) * stride] = (int16_t)d;
   }
 }
 
+// One wave = FIX_WPW windows x (64 / FIX_WPW) point slices of one task.  16 windows per wave (a whole radix-2^16
+// task) keeps the fixed 6-step tree reduction small against the per-lane additions (n/4 per lane).
+constexpr int FIX_WPW = FIX_WINDOWS_PER_WAVE;
 template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TAff* __restrict__ tab, int nc,
                                                                      TJac* __restrict__ part) {
-  constexpr int W = 256 / CB, WG = W / 8;          // waves per task
+  constexpr int W = 256 / CB, WG = W / FIX_WPW;    // waves per task
+  constexpr int LPW = 64 / FIX_WPW;                // lanes (point slices) per window
   constexpr uint32_t M = 1u << (CB - 1);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  int16_t* digits = reinterpret_cast<int16_t*>(smem);   // [8][FIX_CHUNK]
-  TJac* red = reinterpret_cast<TJac*>(smem);              // [64] afterwards
+  int16_t* digits = reinterpret_cast<int16_t*>(smem);   // [FIX_WPW][FIX_CHUNK]
+  TJac* red = reinterpret_cast<TJac*>(smem);            // [64] afterwards
   const FixTask task = tasks[blockIdx.x / WG];
   const int wg = blockIdx.x % WG;
   const int lane = threadIdx.x;
-  const int wl = lane >> 3, sl = lane & 7;
-  const uint32_t w = (uint32_t)(wg * 8 + wl);
+  const int wl = lane / LPW, sl = lane % LPW;
+  const uint32_t w = (uint32_t)(wg * FIX_WPW + wl);
   const TAff* wtab = tab + (size_t)w * M * nc;
   TJac acc = TJac::identity();
 
@@ -342,16 +355,16 @@ template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTa
     for (int t = lane; t < m; t += 64) {
       Fr k = task.scalars[base + t];
       if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
-      fix_digits8<CB>(k.v, wg * 8, digits + t, FIX_CHUNK);
+      fix_digits<CB, FIX_WPW>(k.v, wg * FIX_WPW, digits + t, FIX_CHUNK);
     }
     __syncthreads();
     const int16_t* row = digits + wl * FIX_CHUNK;
-    // every lane walks its slice i = sl, sl+8, ...: same trip count for all lanes; points fetched two at a time
-    for (int i = sl; i < m; i += 16) {
+    // every lane walks its slice i = sl, sl+LPW, ...: same trip count for all lanes; points fetched two at a time
+    for (int i = sl; i < m; i += 2 * LPW) {
       const int d0 = row[i];
-      const bool h1 = i + 8 < m;
-      const int d1 = h1 ? row[i + 8] : 0;
-      const uint32_t g0 = base + i, g1 = base + i + 8;
+      const bool h1 = i + LPW < m;
+      const int d1 = h1 ? row[i + LPW] : 0;
+      const uint32_t g0 = base + i, g1 = base + i + LPW;
       TAff p0 = TAff::identity(), p1 = TAff::identity();
       if (d0) p0 = wtab[(size_t)((d0 < 0 ? -d0 : d0) - 1) * nc + task.off + (task.idx ? task.idx[g0] : g0)];
       if (d1) p1 = wtab[(size_t)((d1 < 0 ? -d1 : d1) - 1) * nc + task.off + (task.idx ? task.idx[g1] : g1)];
@@ -702,15 +715,37 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
   if (d_out_std) CPX_LAUNCH(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift);
   else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift);
 }
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, TJac* d_part, hipStream_t s) {
+int msm_tblw_windows_per_wave(int ntasks) {
+  // the largest group of windows per wave that still yields two waves per SIMD slot pair of the GPU
+  static const long min_waves = [] {
+    const char* e = getenv("CPX_TBW_MIN_WAVES");
+    return e ? atol(e) : 4096L;
+  }();
+  static const int forced = [] {   // CPX_TBW_WPW=8|16|32|64 pins the grouping (tests exercise every instantiation)
+    const char* e = getenv("CPX_TBW_WPW");
+    const int v = e ? atoi(e) : 0;
+    return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 0;
+  }();
+  if (forced) return forced;
+  for (int wpw = 64; wpw > 8; wpw >>= 1)
+    if ((long)ntasks * (64 / wpw) >= min_waves) return wpw;
+  return 8;
+}
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;
-  CPX_LAUNCH(k_msm_tblw, dim3(ntasks * 8), dim3(64), TBW_LDS, s, d_tasks, d_part);
+  const dim3 grid(ntasks * (64 / wpw)), block(64);
+  switch (wpw) {
+    case 64: CPX_LAUNCH(k_msm_tblw<64>, grid, block, tbw_lds(64), s, d_tasks, d_part); break;
+    case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, tbw_lds(32), s, d_tasks, d_part); break;
+    case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, tbw_lds(16), s, d_tasks, d_part); break;
+    default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, tbw_lds(8), s, d_tasks, d_part); break;
+  }
 }
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int nc, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;
-  const size_t lds = 64 * sizeof(TJac);
-  if (cbits == 16) CPX_LAUNCH(k_msm_fix<16>, dim3(ntasks * 2), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
-  else CPX_LAUNCH(k_msm_fix<8>, dim3(ntasks * 4), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
+  const size_t lds = 64 * sizeof(TJac);   // 10,752 B >= FIX_WPW * FIX_CHUNK * 2 = 8,192 B of digit rows
+  if (cbits == 16) CPX_LAUNCH(k_msm_fix<16>, dim3(ntasks * (16 / FIX_WPW)), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
+  else CPX_LAUNCH(k_msm_fix<8>, dim3(ntasks * (32 / FIX_WPW)), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
 }
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
   const int W = 256 / cbits, total = W * nc;

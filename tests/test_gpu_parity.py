@@ -327,3 +327,16 @@ def test_not_power_of_two_is_an_error(ctx, orc):
     with pytest.raises(cpx.CpxError) as e:   # inner_product_argument.rs:116 assert!(n.is_power_of_two())
         ctx.set_crs(27, orc.generate_crs_points(27))
     assert e.value.code == cpx.CPX_ERR_NOT_POW2
+
+
+@pytest.mark.parametrize("wpw", [16, 32, 64])
+def test_table_msm_window_groupings_reproduce_kat(wpw):
+    # k_msm_tblw<WPW>: the launcher picks the windows-per-wave grouping from the grid size, so small batches only
+    # reach WPW = 8.  Pin the other instantiations (fresh process: the choice is read once) on the reference KAT.
+    import subprocess
+    import sys
+    env = dict(os.environ, CPX_TBW_WPW=str(wpw))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_prove_matches_reference_kat_ell124 or test_prove_verify_ell252_batch"],
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -408,7 +408,7 @@ template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* 
     TF prod = t_one();
     if (live) {
       for (int j = 0; j < chunk; j++) {
-        acc = t_add_mixed_fn(acc, S);          // (m0 + j + 1) * S
+        acc = t_add_mixed(acc, S);          // (m0 + j + 1) * S
         my[j].p = acc;
         my[j].pre = prod;
         if (!inf) prod = t_mul(prod, acc.z);
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_finalize_ranges(const TJac* __restrict_
     const TJac* src = part + first[g];
     const uint32_t c = count[g];
     if (c) p = src[0];
-    for (uint32_t j = 1; j < c; j++) p = t_add_fn(p, src[j]);
+    for (uint32_t j = 1; j < c; j++) p = t_add(p, src[j]);
   }
   const bool inf = p.is_identity();
   const TF zinv = t_block_batch_inverse(p.z, buf);
@@ -453,34 +453,61 @@ __global__ __launch_bounds__(256) void k_finalize_ranges(const TJac* __restrict_
 }
 
 // ------------------------------------------------------------------ table construction
+// Scratch of the build kernels in structure-of-arrays form: word k of entry c of thread g lives at
+// ((c * TMP_WORDS + k) * nthreads + g), so the 64 lanes of a wave store / load 256 contiguous bytes per
+// instruction (the array-of-structs layout wrote 4 bytes per 14 KB stride: 3.5x write amplification in HBM).
+constexpr int TF_WORDS = (int)(sizeof(TF) / 4), TMP_WORDS = 4 * TF_WORDS;
+__device__ __forceinline__ void tmp_store_f(uint32_t* b, size_t stride, const TF& a) {
+  CPX_UNROLL for (int i = 0; i < TF_WORDS; i++) b[(size_t)i * stride] = (uint32_t)a.v[i];
+}
+__device__ __forceinline__ void tmp_load_f(const uint32_t* b, size_t stride, TF& a) {
+  CPX_UNROLL for (int i = 0; i < TF_WORDS; i++) a.v[i] = (decltype(a.v[0] + 0))b[(size_t)i * stride];
+}
+__device__ __forceinline__ void tmp_store(uint32_t* tmp, size_t nthreads, size_t g, int c, const TJac& p, const TF& pre) {
+  uint32_t* b = tmp + (size_t)c * TMP_WORDS * nthreads + g;
+  tmp_store_f(b, nthreads, p.x);
+  tmp_store_f(b + (size_t)TF_WORDS * nthreads, nthreads, p.y);
+  tmp_store_f(b + (size_t)2 * TF_WORDS * nthreads, nthreads, p.z);
+  tmp_store_f(b + (size_t)3 * TF_WORDS * nthreads, nthreads, pre);
+}
+__device__ __forceinline__ void tmp_load(const uint32_t* tmp, size_t nthreads, size_t g, int c, TJac& p, TF& pre) {
+  const uint32_t* b = tmp + (size_t)c * TMP_WORDS * nthreads + g;
+  tmp_load_f(b, nthreads, p.x);
+  tmp_load_f(b + (size_t)TF_WORDS * nthreads, nthreads, p.y);
+  tmp_load_f(b + (size_t)2 * TF_WORDS * nthreads, nthreads, p.z);
+  tmp_load_f(b + (size_t)3 * TF_WORDS * nthreads, nthreads, pre);
+}
+
 // Thread per base point: reads the standard-form source point, writes copy 0 in table form, then runs a chain
 // of 256 - sb doublings storing every sb-th value; the C-1 Jacobian copies are normalised with the thread's own
 // Montgomery trick plus one inversion per work-group.
 __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
-                                                     int npts, int copy_stride, int copies, TblTmp* __restrict__ tmp) {
+                                                     int npts, int copy_stride, int copies, TblTmp* __restrict__ tmp_) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(tmp_);
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)rows * npts;
   const bool live = g < total;
   const int sb = 256 / copies;
   TAff* col = nullptr;
-  TblTmp* mytmp = nullptr;
   TF prod = t_one();
   bool inf = true;
   if (live) {
-    const long r = g / npts, i = g % npts;
+    // point-major thread order: the lanes of a wave hold the same column of different rows (proofs), so the
+    // identity columns of the instance tables (blinder slots, curdleproofs.rs:141-155) retire whole waves at once
+    const long r = g % rows, i = g / rows;
     col = table + r * row_stride + i;
-    mytmp = tmp + g * (copies - 1);
     const TAff P = t_from_std(src[r * src_row_stride + i]);
     col[0] = P;
     inf = P.is_identity();
-    TJac acc = TJac::from_affine(P);
-    for (int c = 1; c < copies; c++) {
-      for (int s = 0; s < sb; s++) acc = t_dbl_fn(acc);
-      mytmp[c - 1].p = acc;
-      mytmp[c - 1].pre = prod;               // z_1 ... z_{c-1}
-      if (!inf) prod = t_mul(prod, acc.z);
+    if (!inf) {
+      TJac acc = TJac::from_affine(P);
+      for (int c = 1; c < copies; c++) {
+        for (int s = 0; s < sb; s++) acc = t_dbl(acc);
+        tmp_store(tmp, (size_t)total, (size_t)g, c - 1, acc, prod);   // prod = z_1 ... z_{c-1}
+        prod = t_mul(prod, acc.z);
+      }
     }
   }
   TF inv = t_block_batch_inverse(prod, buf);   // 1 / (z_1 ... z_{C-1})
@@ -488,8 +515,10 @@ __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src
   for (int c = copies - 1; c >= 1; c--) {
     TAff a = TAff::identity();
     if (!inf) {
-      const TJac p = mytmp[c - 1].p;
-      const TF zinv = t_mul(inv, mytmp[c - 1].pre);   // inv = 1/(z_1..z_c)
+      TJac p;
+      TF pre;
+      tmp_load(tmp, (size_t)total, (size_t)g, c - 1, p, pre);
+      const TF zinv = t_mul(inv, pre);   // inv = 1/(z_1..z_c)
       inv = t_mul(inv, p.z);
       a = t_to_affine(p, zinv);
     }
@@ -716,10 +745,10 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
   else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift);
 }
 int msm_tblw_windows_per_wave(int ntasks) {
-  // the largest group of windows per wave that still yields two waves per SIMD slot pair of the GPU
+  // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2)
   static const long min_waves = [] {
     const char* e = getenv("CPX_TBW_MIN_WAVES");
-    return e ? atol(e) : 4096L;
+    return e ? atol(e) : 2048L;
   }();
   static const int forced = [] {   // CPX_TBW_WPW=8|16|32|64 pins the grouping (tests exercise every instantiation)
     const char* e = getenv("CPX_TBW_WPW");

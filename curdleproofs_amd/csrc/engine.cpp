@@ -295,14 +295,17 @@ void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>
     const MsmReq& r = reqs[i];
     Fr* d = hs + soff[i];
     for (uint32_t j = 0; j < r.n; j++) d[j] = r.scalars[j].f;
-    ht[i] = MsmTask{r.bases, r.idx, d_scal_.p + soff[i], r.n, 0};
+    ht[i] = MsmTask{r.bases, r.idx, d_scal_.p + soff[i], r.n, 0, (uint32_t)soff[i]};
     hd[i] = r.dst;
   });
   CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, total * sizeof(Fr), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_tasks_.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  uint32_t max_n = 0;
+  for (auto& r : reqs) max_n = std::max(max_n, r.n);
+  d_conv_.ensure(std::max<size_t>(total, 1));
   tick("k_msm_accum", alg, (double)total);
-  launch_msm_accum(d_tasks_.p, (int)nt, d_wsum_.p, stream_);
+  launch_msm_accum(d_tasks_.p, (int)nt, (int)max_n, d_conv_.p, d_wsum_.p, stream_);
   tock();
   tick("k_msm_tail", 0, (double)nt * 8);
   launch_msm_tail(d_wsum_.p, d_part_.p, nullptr, (int)nt * 8, 8, 4, stream_);
@@ -578,10 +581,12 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
     CPX_HIP(hipMemcpyAsync(db.p, bases, n * sizeof(Aff), hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(ds.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
   }
-  MsmTask t{db.p, nullptr, ds.p, (uint32_t)n, 0};
+  MsmTask t{db.p, nullptr, ds.p, (uint32_t)n, 0, 0};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
+  DevBuf<TAff> conv;
+  conv.ensure(std::max<size_t>(n, 1));
   tick("k_msm_accum", 128.0 * n, (double)n);
-  launch_msm_accum(dt.p, 1, w.p, stream_);
+  launch_msm_accum(dt.p, 1, (int)n, conv.p, w.p, stream_);
   tock();
   launch_msm_tail(w.p, pt.p, nullptr, 8, 8, 4, stream_);
   launch_msm_tail(pt.p, nullptr, res.p, 1, 8, 32, stream_);
@@ -1337,15 +1342,16 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       for (size_t i = 0; i < ell; i++) hs[p * ell + i] = st[p].vec_a[i].f;
       hs[total + 2 * p] = st[p].scal[3][0].f;       // k
       hs[total + 2 * p + 1] = st[p].scal[3][1].f;   // r_k
-      ht[2 * p] = MsmTask{pp(p), nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0};
-      ht[2 * p + 1] = MsmTask{pp(p) + ell, nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0};
+      ht[2 * p] = MsmTask{pp(p), nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0, (uint32_t)(2 * p * ell)};
+      ht[2 * p + 1] = MsmTask{pp(p) + ell, nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0, (uint32_t)((2 * p + 1) * ell)};
       hd[2 * p] = slot_index(p, SL_R);
       hd[2 * p + 1] = slot_index(p, SL_S);
     });
     CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, (total + 2 * B) * sizeof(Fr), hipMemcpyHostToDevice, side_.stream));
     CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, side_.stream));
     CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, side_.stream));
-    launch_msm_accum(side_.tasks.p, (int)nt, side_.wsum.p, side_.stream);
+    side_.conv.ensure(2 * total);
+    launch_msm_accum(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.wsum.p, side_.stream);
     launch_msm_tail(side_.wsum.p, side_.part.p, nullptr, (int)nt * 8, 8, 4, side_.stream);
     launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 8, 32, side_.stream);
     launch_finalize(side_.res.p, (int)nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);

@@ -160,6 +160,7 @@ class Engine {
     DevBuf<SmulTask> stasks;
     DevBuf<Fr> scal;
     DevBuf<TJac> wsum, part;
+    DevBuf<TAff> conv;
     DevBuf<Jac> res;
     DevBuf<uint32_t> dst;
     DevBuf<uint8_t> comp;
@@ -260,6 +261,7 @@ class Engine {
   DevBuf<Fr> d_scal_;
   DevBuf<TJac> d_wsum_, d_part_;   // window sums / Horner partials of the bucket MSM (table representation)
   DevBuf<Jac> d_res_;
+  DevBuf<TAff> d_conv_;            // table-form copies of the bases of a bucket-MSM phase
   DevBuf<TJac> d_tpart_;           // partial sums of the table kernels
   DevBuf<uint32_t> d_dst_;
   DevBuf<uint8_t> d_comp_;

@@ -21,6 +21,7 @@ struct MsmTask {
   const Fr* scalars;
   uint32_t n;
   uint32_t flags;
+  uint32_t conv_off;     // where this task's bases go in the phase's table-form scratch (n entries)
 };
 
 // cnt elements:  out[e] = affine( (add ? add[e] : O) + scalars[e * scalar_stride] * mul[e] )
@@ -84,7 +85,9 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
                             uint8_t* d_comp, hipStream_t s);
 
 // ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian, table representation) ...
-void launch_msm_accum(const MsmTask* d_tasks, int ntasks, TJac* d_wsum, hipStream_t s);
+// d_conv: scratch for the table-form copies of all bases (sum of n over the tasks, addressed by task.conv_off);
+// max_n: largest task.n of the launch
+void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TJac* d_wsum, hipStream_t s);
 // ... then Horner tails: out[t] = sum_{j<group} 2^(shift*j) in[t*group+j]; (8,4) then (8,32) gives the MSM results.
 // Exactly one of d_out (table representation) / d_out_std (standard form, last stage) is non-null.
 void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s);

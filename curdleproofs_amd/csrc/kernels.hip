@@ -118,46 +118,55 @@ __device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
   return t_mul(t_mul(tinv, left), right);
 }
 
-// ------------------------------------------------------------------ MSM: bucket accumulation
-// One work-group per task.  Thread t owns bucket (window w = t / 8, magnitude b = t % 8 + 1).
-// LDS: digit rows [64][MSM_CHUNK] int8, staged points [MSM_CHUNK] (converted to the 28-bit-limb table form
-// while staging); afterwards the same LDS is reused for the 512 bucket sums that are folded into 64 window sums.
-constexpr int MSM_THREADS = 512;
-constexpr int MSM_CHUNK = 256;
-constexpr int MSM_LDS_BYTES = 512 * (int)sizeof(TJac);   // 86,016 B >= 64*256 + 256*112 = 45,056 B
+// ------------------------------------------------------------------ MSM over arbitrary bases: bucket accumulation
+// Pippenger with signed radix-16 windows for caller-supplied bases (tier 0, the instance vectors R and S, the
+// verifier's shards).  Two kernels:
+//  k_to_table   converts every base of every task to the table form once (2 products per coordinate) into a
+//               scratch array (task.conv_off); the 8 waves of a task then gather 112-B points from it (L2).
+//  k_msm_accw   barrier-free single-wave groups as in k_msm_tblw: a wave owns 8 windows of one task, lane =
+//               (window, bucket); the digit rows of the whole task (<= 1024 points per pass) sit in LDS, so lanes
+//               only re-synchronise once per task and the slowest lane is decided over the whole task.  Windows
+//               carry different weights here (no pre-shifted copies), so buckets cannot be shared across windows:
+//               output = 64 window sums per task, folded by the Horner tails below.
+// The previous one-group-per-task version (512 threads, LDS-staged points, 4 barriers per 256 points) spent 37 %
+// of its wave-cycles waiting and, at one 86 KB group per CU, left no room for other kernels' waves to fill in.
+constexpr int ACW_CHUNK = 1024;
+constexpr int ACW_LDS = 64 * (int)sizeof(TJac) > 8 * ACW_CHUNK ? 64 * (int)sizeof(TJac) : 8 * ACW_CHUNK;
 
-#ifndef CPX_MSM_WAVES
-#define CPX_MSM_WAVES 2   // waves per SIMD the register allocator must leave room for (2 = one 512-thread group per CU)
-#endif
-__global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const MsmTask* __restrict__ tasks, TJac* __restrict__ wsum) {
+__global__ __launch_bounds__(64) void k_to_table(const MsmTask* __restrict__ tasks, TAff* __restrict__ conv) {
+  const MsmTask task = tasks[blockIdx.y];
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= task.n) return;
+  conv[(size_t)task.conv_off + j] = t_from_std(task.bases[task.idx ? task.idx[j] : j]);
+}
+
+__global__ __launch_bounds__(64, 2) void k_msm_accw(const MsmTask* __restrict__ tasks, const TAff* __restrict__ conv, TJac* __restrict__ wsum) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  int8_t* digits = reinterpret_cast<int8_t*>(smem);                       // [64][MSM_CHUNK]
-  TAff* pts = reinterpret_cast<TAff*>(smem + 64 * MSM_CHUNK);             // [MSM_CHUNK], table representation
-  TJac* buckets = reinterpret_cast<TJac*>(smem);                          // [512] (aliases the above later)
-
-  const MsmTask task = tasks[blockIdx.x];
-  const int tid = threadIdx.x;
-  const int w = tid >> 3, mag = (tid & 7) + 1;
+  int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [8][ACW_CHUNK]
+  TJac* red = reinterpret_cast<TJac*>(smem);          // [64] (aliases the digits afterwards)
+  const MsmTask task = tasks[blockIdx.x >> 3];
+  const int w8 = blockIdx.x & 7;
+  const int lane = threadIdx.x;
+  const int wl = lane >> 3, mag = (lane & 7) + 1;
+  const TAff* pts = conv + task.conv_off;
   TJac acc = TJac::identity();
 
-  for (uint32_t base = 0; base < task.n; base += MSM_CHUNK) {
-    const int m = min((uint32_t)MSM_CHUNK, task.n - base);
-    __syncthreads();   // previous chunk fully consumed
-    if (tid < m) {
-      Fr k = task.scalars[base + tid];
+  for (uint32_t base = 0; base < task.n; base += ACW_CHUNK) {
+    const int m = min((uint32_t)ACW_CHUNK, task.n - base);
+    __syncthreads();
+    for (int t = lane; t < m; t += 64) {
+      Fr k = task.scalars[base + t];
       if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
-      recode_signed16(k.v, digits + tid, MSM_CHUNK);
-    } else if (tid >= 256 && tid - 256 < m) {
-      const uint32_t j = base + tid - 256;
-      pts[tid - 256] = t_from_std(task.bases[task.idx ? task.idx[j] : j]);   // converted once, used by 64 windows
+      int8_t d[64];
+      recode_signed16(k.v, d);
+      CPX_UNROLL for (int j = 0; j < 8; j++) digits[j * ACW_CHUNK + t] = d[w8 * 8 + j];
     }
     __syncthreads();
-    const int8_t* row = digits + w * MSM_CHUNK;
+    const int8_t* row = digits + wl * ACW_CHUNK;
     int i = 0;
     for (;;) {
-      // cheap divergent scan to this lane's next matching point
       int d = 0;
-      while (i < m) {
+      while (i < m) {   // cheap divergent scan to this lane's next matching point
         d = row[i];
         if (d == mag || d == -mag) break;
         i++;
@@ -165,42 +174,41 @@ __global__ __launch_bounds__(MSM_THREADS, CPX_MSM_WAVES) void k_msm_accum(const 
       const bool have = i < m;
       if (!__any(have)) break;
       if (have) {
-        const TAff q = pts[i];
+        const TAff q = pts[base + i];
         acc = t_add_mixed(acc, t_cneg(q, d < 0));
         i++;
       }
     }
   }
   __syncthreads();
-  buckets[tid] = acc;
+  red[lane] = acc;
   __syncthreads();
   // Window sum  sum_{b=1..8} b * B_b  =  sum_b (suffix sum of B from b): a Hillis-Steele suffix scan over the
-  // window's 8 lanes (3 steps) followed by a tree sum (3 steps) — 6 point additions with every wave of the
-  // work-group busy, instead of 16 on one wave with seven waves idle.
-  const int b = tid & 7;
+  // window's 8 lanes (3 steps) followed by a tree sum (3 steps).
+  const int b = lane & 7;
   for (int sft = 1; sft < 8; sft <<= 1) {
     const bool has = b + sft < 8;
     TJac other;
-    if (has) other = buckets[tid + sft];
+    if (has) other = red[lane + sft];
     __syncthreads();
     if (has) {
       acc = t_add(acc, other);
-      buckets[tid] = acc;
+      red[lane] = acc;
     }
     __syncthreads();
   }
   for (int sft = 4; sft >= 1; sft >>= 1) {
     const bool has = b < sft;
     TJac other;
-    if (has) other = buckets[tid + sft];
+    if (has) other = red[lane + sft];
     __syncthreads();
     if (has) {
       acc = t_add(acc, other);
-      buckets[tid] = acc;
+      red[lane] = acc;
     }
     __syncthreads();
   }
-  if (b == 0) wsum[(size_t)blockIdx.x * 64 + w] = acc;
+  if (b == 0) wsum[(size_t)(blockIdx.x >> 3) * 64 + w8 * 8 + wl] = acc;
 }
 
 // ------------------------------------------------------------------ table-backed MSM, barrier-free single-wave groups
@@ -735,9 +743,16 @@ int launches_since_set() { return tl_launches; }
     tl_launches++;                                                                                        \
     hipExtLaunchKernelGGL(kern, grid, block, lds, stream, tl_ev_start, tl_ev_stop, 0, __VA_ARGS__);       \
   } while (0)
-void launch_msm_accum(const MsmTask* d_tasks, int ntasks, TJac* d_wsum, hipStream_t s) {
+void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TJac* d_wsum, hipStream_t s) {
   if (ntasks <= 0) return;
-  CPX_LAUNCH(k_msm_accum, dim3(ntasks), dim3(MSM_THREADS), MSM_LDS_BYTES, s, d_tasks, d_wsum);
+  if (max_n > 0) {
+    hipEvent_t ea = tl_ev_start, eb = tl_ev_stop;   // the profiling events belong to the accumulation kernel
+    tl_ev_start = tl_ev_stop = nullptr;
+    CPX_LAUNCH(k_to_table, dim3((max_n + 63) / 64, ntasks), dim3(64), 0, s, d_tasks, d_conv);
+    tl_ev_start = ea;
+    tl_ev_stop = eb;
+  }
+  CPX_LAUNCH(k_msm_accw, dim3(ntasks * 8), dim3(64), ACW_LDS, s, d_tasks, d_conv, d_wsum);
 }
 void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s) {
   if (nout <= 0) return;

@@ -349,13 +349,17 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   const size_t nt = reqs.size();
   if (!nt) return;
   const bool fix = fix_bits_ && fixtab();
-  const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / FIX_WINDOWS_PER_WAVE) : 0;
   const TAff* c_lo = ctab();
   const TAff* c_hi = ctab() + (size_t)copies_ * (n_ + 3);
   auto is_crs = [&](const TblSeg& sg) { return fix && sg.n && sg.base >= c_lo && sg.base < c_hi; };
   auto needs_tbl = [&](const TblReq& r) { return !fix || (r.seg0.n && !is_crs(r.seg0)) || (r.seg1.n && !is_crs(r.seg1)); };
-  size_t ntt_total = 0;
-  for (const TblReq& r : reqs) ntt_total += needs_tbl(r) ? 1 : 0;
+  size_t ntt_total = 0, nft_total = 0;
+  for (const TblReq& r : reqs) {
+    ntt_total += needs_tbl(r) ? 1 : 0;
+    nft_total += (is_crs(r.seg0) ? 1 : 0) + (is_crs(r.seg1) ? 1 : 0);
+  }
+  const int fix_wpw = fix ? msm_fix_windows_per_wave((int)nft_total, fix_bits_) : 16;
+  const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / fix_wpw) : 0;
   const int tbl_wpw = msm_tblw_windows_per_wave((int)ntt_total);   // windows per wave of the shifted-table kernel
   const uint32_t tbl_parts = (uint32_t)(64 / tbl_wpw);
   // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
@@ -443,7 +447,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   if (nft) {
     tick("k_msm_fix", 128.0 * pts_fix, pts_fix);
-    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, (int)(n_ + 3), d_tpart_.p, stream_);
+    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)(n_ + 3), d_tpart_.p, stream_);
     tock();
   }
   if (ntt) {

@@ -40,6 +40,11 @@ struct F28Cfg {
                                       0xda0f73e, 0x9b09b42, 0x1297bb0, 0x515d98f, 0x012ca7c, 0x659fcfa, 0x000577a};
   static constexpr int32_t C_IN[14] = {0x80e6299, 0x3500034, 0xeb12856, 0xdeb2699, 0xc988670, 0x4ef6697, 0x70983e8,
                                        0xa4e6fe9, 0x3e8a053, 0xecf271e, 0xc20d323, 0x6eb6385, 0x47f1286, 0x00156da};
+  // 4 and the cube root of unity beta of the G1 endomorphism (x, y) -> (beta x, y) = [-u^2](x, y), Montgomery form
+  static constexpr int32_t FOUR[14] = {0xd1ff2e0, 0x6000000, 0x00ac467, 0x3379b48, 0x1c84b80, 0x0e88243, 0x0dd9a7e,
+                                       0x683dcf8, 0x6c26d0b, 0x4a5eec2, 0x457663c, 0x04b29f1, 0x967f3e8, 0x0015de9};
+  static constexpr int32_t BETA[14] = {0xa75929a, 0x681b798, 0x22a3e9d, 0xabc02bf, 0x4e5bb45, 0x55e6e7e, 0x4814117,
+                                       0x6d04f1b, 0xae3387d, 0x54acb0c, 0x0a4c74b, 0x56138b5, 0xb64e066, 0x00076f2};
   static constexpr int32_t C_OUT[14] = {0x002fffd, 0x0900000, 0xc000276, 0x000bc40, 0x8baebf4, 0x5753c75, 0x55f4898,
                                         0x7052574, 0x7ce5853, 0x56ec6d7, 0x71a97a2, 0xe4935c0, 0xec3fa80, 0x0015f65};
 };

@@ -129,4 +129,53 @@ CPX_HD F28 f28_inv(const F28& a) {
   return r;
 }
 
+
+// a^((p+1)/4): the square root of a if a is a quadratic residue (p = 3 mod 4)
+CPX_HD F28 f28_sqrt_candidate(const F28& a) {
+  // (p+1)/4, little-endian 32-bit words
+  const uint32_t E[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                          0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
+  F28 r = f28_one();
+  bool started = false;
+  for (int l = 11; l >= 0; l--) {
+    const uint32_t w = E[l];
+    for (int b = 31; b >= 0; b--) {
+      if (started) r = f28_sqr(r);
+      if ((w >> b) & 1u) {
+        r = started ? f28_mul(r, a) : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+// a == b mod p for lazy values
+CPX_HD bool f28_eq(const F28& a, const F28& b) { return f28_product_is_zero(f28_mul(f28_sub(a, b), f28_one())); }
+
+// Membership of an on-curve affine point in the order-r subgroup by the endomorphism test (M. Scott, "A note on
+// group membership tests for G1, G2 and GT on BLS pairing-friendly curves", 2021): phi(x, y) = (beta x, y) satisfies
+// phi^2 + phi + 1 = 0 on the whole curve and acts on G1 as [-u^2], and u^4 - u^2 + 1 = r exactly, hence
+// phi(P) = [-u^2] P  <=>  [r] P = O.  Same verdict as ark-ec's [r]P == O (reference: deserialize_compressed with
+// Validate::Yes, whisk.rs:265-277), at two 64-bit multiplications by |u| = 0xd201000000010000 instead of a 255-bit one.
+CPX_HD bool g1_28_in_subgroup(const Aff28& P) {
+  if (P.is_identity()) return true;
+  const uint64_t U = 0xd201000000010000ull;
+  Jac28 q = Jac28::from_affine(P);             // [|u|] P
+  for (int b = 62; b >= 0; b--) {
+    q = jac28_dbl(q);
+    if ((U >> b) & 1) q = jac28_add_mixed(q, P);
+  }
+  const Jac28 q1 = q;                          // [u^2] P = [|u|] ([|u|] P)
+  for (int b = 62; b >= 0; b--) {
+    q = jac28_dbl(q);
+    if ((U >> b) & 1) q = jac28_add(q, q1);
+  }
+  if (q.is_identity()) return false;
+  // (beta x_P, y_P) == (X / Z^2, -Y / Z^3)
+  const F28 zz = f28_sqr(q.z);
+  const F28 lhs_x = f28_mul(f28_mul(f28_const(F28Cfg::BETA), P.x), zz);
+  const F28 lhs_y = f28_mul(f28_mul(P.y, zz), q.z);
+  return f28_eq(lhs_x, q.x) && f28_eq(lhs_y, f28_neg(q.y));
+}
+
 }  // namespace cpx

@@ -66,18 +66,18 @@ void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, 
 // ---- fixed-base MSM over a table of multiples (CRS bases) ----
 // fix_tab[(w*M + (m-1))*nc + i] = m * 2^(c*w) * P_i  (affine), w < W = 256/c windows, m = 1..M = 2^(c-1), i < nc.
 // A scalar is W signed radix-2^c digits; digit d of window w selects entry |d| directly: one mixed addition per
-// (point, window), no buckets.  One wave handles FIX_WINDOWS_PER_WAVE windows of a task (lane = window x point
-// slice): every lane performs the same number of additions.
+// (point, window), no buckets.  One wave handles wpw (8 or 16) windows of a task (lane = window x point slice):
+// every lane performs the same number of additions.
 struct FixTask {
   const uint32_t* idx;      // optional gather list of base indices (< nc)
   const Fr* scalars;
   uint32_t off;             // first base index when idx == nullptr
   uint32_t n;
   uint32_t flags;
-  uint32_t out_first;       // first partial slot of this task; it writes W / FIX_WINDOWS_PER_WAVE partials
+  uint32_t out_first;       // first partial slot of this task; it writes W / wpw partials
 };
-constexpr int FIX_WINDOWS_PER_WAVE = 16;
-void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int nc, TJac* d_part, hipStream_t s);
+int msm_fix_windows_per_wave(int ntasks, int cbits);
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, TJac* d_part, hipStream_t s);
 // shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
 // output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)

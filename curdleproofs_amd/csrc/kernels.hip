@@ -339,9 +339,9 @@ template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint3
 }
 
 // One wave = FIX_WPW windows x (64 / FIX_WPW) point slices of one task.  16 windows per wave (a whole radix-2^16
-// task) keeps the fixed 6-step tree reduction small against the per-lane additions (n/4 per lane).
-constexpr int FIX_WPW = FIX_WINDOWS_PER_WAVE;
-template <int CB> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TAff* __restrict__ tab, int nc,
+// task) keeps the fixed 6-step tree reduction small against the per-lane additions (n/4 per lane); 8 windows
+// per wave double the number of waves when the launch would not fill the GPU otherwise.
+template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TAff* __restrict__ tab, int nc,
                                                                      TJac* __restrict__ part) {
   constexpr int W = 256 / CB, WG = W / FIX_WPW;    // waves per task
   constexpr int LPW = 64 / FIX_WPW;                // lanes (point slices) per window
@@ -630,24 +630,9 @@ __global__ __launch_bounds__(SMUL_THREADS, CPX_SMUL_WAVES) void k_smul(const Smu
 // ark-bls12-381 `deserialize_compressed` (Validate::Yes) for tracker / proof ingestion
 // (/root/reference/src/whisk.rs:265-277, :318-320; curdleproofs.rs:312-323): y = sqrt(x^3 + 4) by
 // a^((p+1)/4), sign chosen by the flag bit, then r * P == O.
-__device__ __noinline__ Fp fp_sqrt_candidate(const Fp& a) {
-  // (p+1)/4, little-endian 32-bit words
-  const uint32_t E[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
-                          0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
-  Fp r = Fp::one();
-  bool started = false;
-  for (int l = 11; l >= 0; l--) {
-    const uint32_t w = E[l];
-    for (int b = 31; b >= 0; b--) {
-      if (started) r = fe_sqr(r);
-      if ((w >> b) & 1u) {
-        r = started ? fe_mul(r, a) : a;
-        started = true;
-      }
-    }
-  }
-  return r;
-}
+// All field work runs on the table form (fp28.cuh); the subgroup test is the endomorphism test of g1_28.cuh.
+__device__ __noinline__ F28 f28_sqrt_device(const F28& a) { return f28_sqrt_candidate(a); }
+__device__ __noinline__ bool g1_in_subgroup_device(const Aff28& P) { return g1_28_in_subgroup(P); }
 
 __global__ __launch_bounds__(64) void k_decompress(const uint8_t* __restrict__ in, int n, Aff* __restrict__ out,
                                                    const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ status, int check_subgroup) {
@@ -674,29 +659,18 @@ __global__ __launch_bounds__(64) void k_decompress(const uint8_t* __restrict__ i
       st = 1;
     } else {
       const Fp x = fe_to_mont(xc);
-      Fp four = Fp::one();
-      four = fe_dbl(fe_dbl(four));
-      const Fp rhs = fe_add(fe_mul(fe_sqr(x), x), four);
-      Fp y = fp_sqrt_candidate(rhs);
-      if (!fe_sqr(y).eq(rhs)) {
+      const F28 x28 = f28_from_std(x);
+      const F28 rhs = f28_add(f28_mul(f28_sqr(x28), x28), f28_const(F28Cfg::FOUR));
+      const F28 y28 = f28_sqrt_device(rhs);
+      if (!f28_eq(f28_sqr(y28), rhs)) {
         st = 1;
       } else {
-        const Fp ny = fe_neg(y);
+        const Fp y = f28_to_std(y28), ny = fe_neg(y);
         const bool y_larger = fe_raw_gt(fe_from_mont(y), fe_from_mont(ny));
+        const bool keep = (y_larger == sort);
         res.x = x;
-        res.y = (y_larger == sort) ? y : ny;
-        if (check_subgroup) {
-          // r * P by MSB-first double-and-add over the fixed modulus bits
-          Jac acc = Jac::identity();
-          for (int l = 7; l >= 0; l--) {
-            const uint32_t w = FrCfg::P[l];
-            for (int bit = 31; bit >= 0; bit--) {
-              acc = jac_dbl(acc);
-              if ((w >> bit) & 1u) acc = jac_add_mixed(acc, res);
-            }
-          }
-          if (!acc.is_identity()) st = 2;
-        }
+        res.y = keep ? y : ny;
+        if (check_subgroup && !g1_in_subgroup_device(Aff28{x28, f28_cneg(y28, !keep)})) st = 2;
       }
     }
   }
@@ -785,11 +759,18 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, 
     default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, tbw_lds(8), s, d_tasks, d_part); break;
   }
 }
-void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int nc, TJac* d_part, hipStream_t s) {
+int msm_fix_windows_per_wave(int ntasks, int cbits) {
+  const int w = 256 / cbits;
+  return (long)ntasks * (w / 16) >= 2048 ? 16 : 8;
+}
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;
-  const size_t lds = 64 * sizeof(TJac);   // 10,752 B >= FIX_WPW * FIX_CHUNK * 2 = 8,192 B of digit rows
-  if (cbits == 16) CPX_LAUNCH(k_msm_fix<16>, dim3(ntasks * (16 / FIX_WPW)), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
-  else CPX_LAUNCH(k_msm_fix<8>, dim3(ntasks * (32 / FIX_WPW)), dim3(64), lds, s, d_tasks, d_fix_tab, nc, d_part);
+  const size_t lds = 64 * sizeof(TJac);   // 10,752 B >= 16 * FIX_CHUNK * 2 = 8,192 B of digit rows
+  const dim3 grid(ntasks * (256 / cbits / wpw)), block(64);
+  if (cbits == 16 && wpw == 16) CPX_LAUNCH((k_msm_fix<16, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
+  else if (cbits == 16) CPX_LAUNCH((k_msm_fix<16, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
+  else if (wpw == 16) CPX_LAUNCH((k_msm_fix<8, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
+  else CPX_LAUNCH((k_msm_fix<8, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
 }
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
   const int W = 256 / cbits, total = W * nc;

@@ -231,4 +231,17 @@ void emul_f28_edges(const uint8_t* base, uint8_t* out /*8*96*/) {
   }
 }
 
+// decompression helpers on the table form: sqrt candidate and the endomorphism subgroup test
+void emul_f28_sqrt(const uint8_t* a, uint8_t* out) {
+  Fp x;
+  memcpy(x.v, a, 48);
+  Fp r = f28_to_std(f28_sqrt_candidate(f28_from_std(x)));
+  memcpy(out, r.v, 48);
+}
+int emul_f28_in_subgroup(const uint8_t* aff) {
+  Aff p;
+  memcpy(&p, aff, 96);
+  return g1_28_in_subgroup(aff28_from_std(p)) ? 1 : 0;
+}
+
 }  // extern "C"

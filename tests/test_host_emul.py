@@ -179,3 +179,29 @@ def test_f28_point_formulas(emul, orc):
     emul.emul_f28_edges(_b(g), e)
     got = [bytes(e)[i * AFF:(i + 1) * AFF] for i in range(8)]
     assert got == [mult(2), bytes(AFF), mult(4), mult(1), mult(8), bytes(AFF), mult(4), mult(3)]
+
+
+def test_f28_sqrt_and_endomorphism_subgroup_test(emul, orc):
+    """k_decompress's field work: a^((p+1)/4) and the phi(P) = [-u^2]P membership test vs the oracle's [r]P = O."""
+    import random
+    rnd = random.Random(5)
+    on_curve = []
+    while len(on_curve) < 6:
+        x = rnd.randrange(P)
+        rhs = (x * x * x + 4) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        r = _o(48)
+        emul.emul_f28_sqrt(_b(_to_mont(rhs)), r)
+        got = _from_mont(bytes(r))
+        if y * y % P == rhs:
+            assert got in (y, P - y)
+            on_curve.append(_to_mont(x) + _to_mont(y))
+        else:
+            assert got * got % P != rhs
+    verdicts = [emul.emul_f28_in_subgroup(_b(pt)) for pt in on_curve]
+    assert verdicts == [int(orc.g1_in_subgroup(pt)) for pt in on_curve] == [0] * 6   # random curve points have the cofactor
+    good = orc.rng(3).g1_affine(4)
+    for i in range(4):
+        pt = good[i * AFF:(i + 1) * AFF]
+        assert orc.g1_in_subgroup(pt) and emul.emul_f28_in_subgroup(_b(pt)) == 1
+    assert emul.emul_f28_in_subgroup(_b(bytes(AFF))) == 1   # identity

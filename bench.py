@@ -199,7 +199,8 @@ def main():
         b_prove = 128 * (6 * ell + 15 * n + 2) + 288 * 5 * (n - 1) + 224 * n
         b_verify = 128 * (5 * ell + 8) + 10 * L * 176
         value = world * B * args.steps / dt
-        dom = max(("k_msm_fix", "k_msm_tblw", "k_msm_accum", "k_smul"), key=lambda k: stats[k]["ms"])
+        # kernel names are the instantiations rocprofv3 reports (k_msm_tblw<64> = 64 windows per wave, ...)
+        dom = max((k for k in stats if k.startswith(("k_msm_fix", "k_msm_tblw", "k_msm_accw", "k_smul"))), key=lambda k: stats[k]["ms"])
         st = stats[dom]
         avg_ms = st["ms"] / max(st["launches"], 1)
         bytes_per_launch = st["alg_bytes"] / max(st["launches"], 1)
@@ -207,7 +208,7 @@ def main():
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs)
             with open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")) as f:
-                hc = json.load(f).get("cpx::" + dom)
+                hc = json.load(f).get("cpx::" + dom)   # per instantiation, as rocprofv3 names it
             if hc and hc["batch_per_gpu"] == B and hc.get("engine_contexts_per_gpu", 1) == K:
                 # counters are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)
                 traffic = (2.0 * hc["FETCH_SIZE"]["total"] / hc["FETCH_SIZE"]["dispatches"]
@@ -222,7 +223,7 @@ def main():
         # The honest bound of this integer path: modular multiplications on the VALU.  Peak = dependent
         # Montgomery-product chains on the table kernels' 28-bit-limb field at full occupancy, measured now on this GPU
         # (k_bench_f28mul); achieved = the dominant kernel's point additions x 11 products (7M + 4S mixed addition).
-        mulmods_per_point = {"k_msm_tblw": 64 * 15.0 / 16 * 11, "k_msm_accum": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * 11.0, "k_smul": 0.0}[dom]
+        mulmods_per_point = {"k_msm_tblw": 64 * 15.0 / 16 * 11, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * 11.0, "k_smul": 0.0}[dom.split("<")[0]]
         os.environ["CPX_BENCH_FIELD"] = "28"
         peak_mm = ctxs[0].bench_fpmul(2048, 1000, 2)
         ach_mm = st["units"] * mulmods_per_point / (st["ms"] * 1e-3) if st["ms"] else 0.0
@@ -238,7 +239,7 @@ def main():
                                ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads, parallelism="proofs sharded over %d GPU(s), no collective" % world),
                    all_verified=all_ok, algorithmic_bytes_per_proof=b_prove + b_verify,
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
-                   kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items()},
+                   kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
                    vs_readme_i7_8550u=value / README_I7_PROOFS_PER_S, roofline=roofline)
         if not args.no_cpu_baseline:
             psz = ctxs[0].proof_size

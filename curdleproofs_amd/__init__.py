@@ -53,7 +53,7 @@ EXPORTS = [
     "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size",
     "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress",
     "cpx_accum_new", "cpx_accum_free", "cpx_accum_check", "cpx_accum_verify",
-    "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify",
+    "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify", "cpx_batch_verify_fused", "cpx_g1_sum_jac",
     "cpx_set_profiling", "cpx_reset_stats", "cpx_get_stat", "cpx_set_host_threads", "cpx_bench_fpmul",
 ]
 
@@ -97,6 +97,8 @@ def load_library():
     L.cpx_reset_stats.argtypes = [vp]
     L.cpx_get_stat.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.cpx_batch_verify_fused.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ci)]
+    L.cpx_g1_sum_jac.argtypes = [vp, vp, sz, vp, ctypes.POINTER(ci)]
     L.cpx_set_host_threads.argtypes = [vp, ci]
     L.cpx_bench_fpmul.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     _lib = L
@@ -254,6 +256,28 @@ class Context:
         return list(verdict)
 
     # ---- measurement ----
+    def verify_batch_fused_partial(self, proofs, rand):
+        """BASELINE config 5: one accumulated MSM over all loaded proofs.  `rand`: 12 Fr per proof.
+        Returns (partial sum as a 144-byte Jacobian point, number of structurally invalid proofs)."""
+        data = proofs if isinstance(proofs, (bytes, bytearray)) or hasattr(proofs, "_length_") else b"".join(proofs)
+        out = _out(JAC)
+        bad = ctypes.c_int(0)
+        self._check(self._L.cpx_batch_verify_fused(self._h, _in(data), _in(rand), out, ctypes.byref(bad)))
+        return bytes(out)[:JAC], bad.value
+
+    def sum_jac(self, points_jac):
+        """sum of Jacobian points -> (sum, is_identity)"""
+        n = len(points_jac) // JAC
+        out = _out(JAC)
+        flag = ctypes.c_int(0)
+        self._check(self._L.cpx_g1_sum_jac(self._h, _in(points_jac), n, out, ctypes.byref(flag)))
+        return bytes(out)[:JAC], bool(flag.value)
+
+    def verify_batch_fused(self, proofs, rand):
+        """Single-context form of config 5: True iff every loaded proof is valid (all-or-nothing)."""
+        part, bad = self.verify_batch_fused_partial(proofs, rand)
+        return bad == 0 and self.sum_jac(part)[1]
+
     def set_profiling(self, on=True):
         self._check(self._L.cpx_set_profiling(self._h, 1 if on else 0))
 
@@ -265,7 +289,8 @@ class Context:
         self._check(self._L.cpx_get_stat(self._h, name.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by), ctypes.byref(un)))
         return dict(launches=n.value, ms=ms.value, alg_bytes=by.value, units=un.value)
 
-    KERNELS = ("k_msm_fix", "k_msm_tblw", "k_finalize_ranges", "k_table_build", "k_msm_accum", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_wait_baton", "host_prove_wall", "host_verify_wall")
+    KERNELS = ("k_msm_tblw<64>", "k_msm_tblw<32>", "k_msm_tblw<16>", "k_msm_tblw<8>", "k_msm_fix<16, 16>", "k_msm_fix<16, 8>", "k_msm_fix<8, 16>", "k_msm_fix<8, 8>",
+               "k_finalize_ranges", "k_table_build", "k_msm_accw", "big_msm", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_wait_baton", "host_prove_wall", "host_verify_wall")
 
     def stats(self):
         return {k: self.stat(k) for k in self.KERNELS}

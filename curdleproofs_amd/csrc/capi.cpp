@@ -217,6 +217,21 @@ int cpx_batch_verify(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, i
   });
 }
 
+int cpx_batch_verify_fused(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, uint8_t* partial_jac, int* n_invalid) {
+  if (!proofs || !rand || !partial_jac || !n_invalid) return CPX_ERR_ARG;
+  return guarded(ctx, [&] {
+    ctx->eng->batch_verify_fused(proofs, rand, partial_jac, n_invalid);
+    return CPX_OK;
+  });
+}
+int cpx_g1_sum_jac(cpx_ctx* ctx, const uint8_t* points_jac, size_t n, uint8_t* out_jac, int* is_identity) {
+  if ((n && !points_jac) || !out_jac || !is_identity) return CPX_ERR_ARG;
+  return guarded(ctx, [&] {
+    *is_identity = ctx->eng->sum_jac(points_jac, n, out_jac) ? 1 : 0;
+    return CPX_OK;
+  });
+}
+
 int cpx_set_profiling(cpx_ctx* ctx, int on) {
   if (!ctx || !ctx->eng) return CPX_ERR_ARG;
   ctx->eng->set_profiling(on != 0);

@@ -75,7 +75,7 @@ Engine::~Engine() {
 }
 
 // ---------------------------------------------------------------- timing
-void Engine::tick(const char* name, double bytes, double units) {
+void Engine::tick(const char* name, double bytes, double units, bool span) {
   if (!profiling_) return;
   Timed t;
   t.units = units;
@@ -83,16 +83,21 @@ void Engine::tick(const char* name, double bytes, double units) {
   CPX_HIP(hipEventCreate(&t.b));
   t.name = name;
   t.bytes = bytes;
-  set_launch_events(t.a, t.b);   // bound to the next dispatch: kernel begin / end
+  span_ = span;
+  if (span) CPX_HIP(hipEventRecord(t.a, stream_));   // a sequence of launches: bracket it on the stream
+  else set_launch_events(t.a, t.b);                  // one dispatch: events bound to kernel begin / end
   pending_.push_back(t);
 }
 void Engine::tock() {
   if (!profiling_) return;
-  if (launches_since_set() == 0) {   // nothing was launched (empty phase): give the events a defined state
+  if (span_) {
+    CPX_HIP(hipEventRecord(pending_.back().b, stream_));
+  } else if (launches_since_set() == 0) {   // nothing was launched (empty phase): give the events a defined state
     CPX_HIP(hipEventRecord(pending_.back().a, stream_));
     CPX_HIP(hipEventRecord(pending_.back().b, stream_));
   }
   set_launch_events(nullptr, nullptr);
+  span_ = false;
 }
 void Engine::flush_timers() {
   if (pending_.empty()) return;
@@ -304,7 +309,7 @@ void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>
   uint32_t max_n = 0;
   for (auto& r : reqs) max_n = std::max(max_n, r.n);
   d_conv_.ensure(std::max<size_t>(total, 1));
-  tick("k_msm_accum", alg, (double)total);
+  tick("k_msm_accw", alg, (double)total);
   launch_msm_accum(d_tasks_.p, (int)nt, (int)max_n, d_conv_.p, d_wsum_.p, stream_);
   tock();
   tick("k_msm_tail", 0, (double)nt * 8);
@@ -446,12 +451,12 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   if (nft) {
-    tick("k_msm_fix", 128.0 * pts_fix, pts_fix);
+    tick(fix_bits_ == 16 ? (fix_wpw == 16 ? "k_msm_fix<16, 16>" : "k_msm_fix<16, 8>") : (fix_wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>"), 128.0 * pts_fix, pts_fix);
     launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)(n_ + 3), d_tpart_.p, stream_);
     tock();
   }
   if (ntt) {
-    tick("k_msm_tblw", 128.0 * pts_tbl, pts_tbl);
+    tick(tbl_wpw == 64 ? "k_msm_tblw<64>" : tbl_wpw == 32 ? "k_msm_tblw<32>" : tbl_wpw == 16 ? "k_msm_tblw<16>" : "k_msm_tblw<8>", 128.0 * pts_tbl, pts_tbl);
     launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_tpart_.p, stream_);
     tock();
   }
@@ -589,7 +594,7 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
   DevBuf<TAff> conv;
   conv.ensure(std::max<size_t>(n, 1));
-  tick("k_msm_accum", 128.0 * n, (double)n);
+  tick("k_msm_accw", 128.0 * n, (double)n);
   launch_msm_accum(dt.p, 1, (int)n, conv.p, w.p, stream_);
   tock();
   launch_msm_tail(w.p, pt.p, nullptr, 8, 8, 4, stream_);
@@ -612,6 +617,21 @@ void Engine::normalize(const uint8_t* jac, size_t n, uint8_t* out_aff, uint8_t* 
   if (out_aff) CPX_HIP(hipMemcpyAsync(out_aff, da.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
   if (out_comp) CPX_HIP(hipMemcpyAsync(out_comp, dc.p, n * 48, hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
+}
+bool Engine::sum_jac(const uint8_t* points_jac, size_t n, uint8_t* out_jac) {
+  CPX_HIP(hipSetDevice(device_));
+  DevBuf<Jac> din, dout;
+  DevBuf<int> dflag;
+  din.ensure(std::max<size_t>(n, 1));
+  dout.ensure(1);
+  dflag.ensure(1);
+  if (n) CPX_HIP(hipMemcpyAsync(din.p, points_jac, n * sizeof(Jac), hipMemcpyHostToDevice, stream_));
+  launch_sum_jac(din.p, (int)n, dout.p, dflag.p, stream_);
+  int flag = 0;
+  CPX_HIP(hipMemcpyAsync(out_jac, dout.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipMemcpyAsync(&flag, dflag.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipStreamSynchronize(stream_));
+  return flag != 0;
 }
 void Engine::msm_jac(const uint8_t* bases_jac, const uint8_t* scalars, size_t n, uint8_t* out_jac) {
   std::vector<uint8_t> aff(std::max<size_t>(n, 1) * sizeof(Aff));
@@ -1725,7 +1745,16 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
 }
 
 // ---------------------------------------------------------------- verifier
-void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdict) {
+void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdict) { verify_core(proofs, rand, 8, verdict, nullptr, nullptr); }
+void Engine::batch_verify_fused(const uint8_t* proofs, const uint8_t* rand, uint8_t* partial_jac, int* n_invalid) {
+  verify_core(proofs, rand, 12, nullptr, partial_jac, n_invalid);
+}
+
+// Shared body.  Per-proof mode (verdict != nullptr, 8 random factors per proof): curdleproofs.rs:197.  Fused mode
+// (fused_partial != nullptr, 12 factors per proof): BASELINE config 5 — every check of every proof goes into ONE
+// accumulated MSM (the reference's MsmAccumulator shared by all verify calls); the result is this
+// engine's partial sum, which must add up to the identity over all engines / GPUs.
+void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid) {
   HostSpan wall(this, "host_verify_wall");
   BatonScope baton(this);
   if (!B_) throw std::logic_error("batch_load first");
@@ -1886,9 +1915,9 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     VState& s = st[p];
     const uint8_t* pb = s.pb;
     auto P = [&](int slot_id) { return pb + pt_off[slot_id - SL_A]; };
-    const S a1 = S_from_wire(rand + (p * 8 + 0) * 32), a2 = S_from_wire(rand + (p * 8 + 1) * 32), a3 = S_from_wire(rand + (p * 8 + 2) * 32),
-            a4 = S_from_wire(rand + (p * 8 + 3) * 32), a5 = S_from_wire(rand + (p * 8 + 4) * 32), a6 = S_from_wire(rand + (p * 8 + 5) * 32),
-            a7 = S_from_wire(rand + (p * 8 + 6) * 32), a8 = S_from_wire(rand + (p * 8 + 7) * 32);
+    const S a1 = S_from_wire(rand + (p * rand_stride + 0) * 32), a2 = S_from_wire(rand + (p * rand_stride + 1) * 32), a3 = S_from_wire(rand + (p * rand_stride + 2) * 32),
+            a4 = S_from_wire(rand + (p * rand_stride + 3) * 32), a5 = S_from_wire(rand + (p * rand_stride + 4) * 32), a6 = S_from_wire(rand + (p * rand_stride + 5) * 32),
+            a7 = S_from_wire(rand + (p * rand_stride + 6) * 32), a8 = S_from_wire(rand + (p * rand_stride + 7) * 32);
     const S beta_l = s.beta_g.pow_u64(ell), beta_l1 = beta_l * s.beta_g;
     s.z_ip = s.r_p * beta_l1 + s.gprod * beta_l - S::one();
     // inner_product_argument.rs:283-290, 202-250
@@ -2030,7 +2059,90 @@ void Engine::batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdi
     s.scal[5] = {S::one(), s.alpha_s, -s.z_u};             // cm_B.T_1 + alpha cm_U.T_1 - z_u G_u
     s.scal[6] = {S::one(), s.alpha_s, -s.z_k, -s.z_u};     // cm_B.T_2 + alpha cm_U.T_2 - z_k S - z_u H
     s.scal[7] = {S::one(), S::one(), S::one(), S::one()};  // combine the four partial sums
+    if (fused_partial) {
+      // fused mode: the four equalities join the accumulated MSM with their own random weights (factors 9..12)
+      const S w1 = S_from_wire(rand + (p * rand_stride + 8) * 32), w2 = S_from_wire(rand + (p * rand_stride + 9) * 32),
+              w3 = S_from_wire(rand + (p * rand_stride + 10) * 32), w4 = S_from_wire(rand + (p * rand_stride + 11) * 32);
+      at(sm.CMA1()) += w1;
+      at(SL_CMT1) += w1 * s.alpha_s;
+      at(SL_GT) += -(w1 * s.z_t);
+      at(sm.CMA2()) += w2;
+      at(SL_CMT2) += w2 * s.alpha_s;
+      at(SL_R) += -(w2 * s.z_k);
+      at(SL_H) += -(w2 * s.z_t);
+      at(sm.CMB1()) += w3;
+      at(SL_CMU1) += w3 * s.alpha_s;
+      at(SL_GU) += -(w3 * s.z_u);
+      at(sm.CMB2()) += w4;
+      at(SL_CMU2) += w4 * s.alpha_s;
+      at(SL_S) += -(w4 * s.z_k);
+      at(SL_H) += -(w4 * s.z_u);
+    }
   });
+
+  if (fused_partial) {
+    // ---- one MSM over the CRS (scalars summed over the proofs, fixed-base table) and B * (4 ell + NM) per-proof points ----
+    if (!(fix_bits_ && fixtab() && use_tables_)) throw std::logic_error("fused verification needs the fixed-base CRS table");
+    const size_t NI = 4 * ell, NPT = NI + NM, N = B * NPT;
+    int invalid = 0;
+    for (size_t p = 0; p < B; p++) invalid += (st[p].bad || st[p].reject) ? 1 : 0;
+    SVec crs_sum(n, S::zero());
+    parallel_for(n, [&](size_t i) {
+      S t = S::zero();
+      for (size_t p = 0; p < B; p++)
+        if (!st[p].bad) t += st[p].scal[0][i];
+      crs_sum[i] = t;
+    });
+    const BigMsmPlan plan = big_msm_plan(N);
+    const int fix_wpw = msm_fix_windows_per_wave(1, fix_bits_);
+    const int fix_parts = 256 / fix_bits_ / fix_wpw;
+    d_scal_.ensure(N + n);
+    d_big_idx_.ensure(N);
+    d_conv_.ensure(N);
+    d_big_keys_.ensure(2 * plan.nkeys);
+    d_big_vals_.ensure(2 * plan.nkeys);
+    d_big_temp_.ensure(plan.sort_temp_bytes + 16);
+    d_big_bounds_.ensure(2 * (size_t)plan.nbuckets);
+    d_big_buckets_.ensure(3 * (size_t)plan.nbuckets + 64);
+    d_tpart_.ensure(fix_parts);
+    d_ftasks_.ensure(1);
+    d_res_.ensure(1);
+    const size_t b_scal = (N + n) * sizeof(Fr), b_idx = N * sizeof(uint32_t);
+    h_stage_.ensure(b_scal + b_idx + sizeof(FixTask));
+    Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
+    uint32_t* hi = reinterpret_cast<uint32_t*>(h_stage_.p + b_scal);
+    FixTask* hf = reinterpret_cast<FixTask*>(h_stage_.p + b_scal + b_idx);
+    parallel_for(B, [&](size_t p) {
+      const VState& s = st[p];
+      Fr* d = hs + p * NPT;
+      uint32_t* x = hi + p * NPT;
+      for (size_t i = 0; i < NI; i++) {
+        d[i] = s.bad ? S::zero().f : s.scal[1][i].f;   // an undecodable proof contributes nothing (and is counted as invalid)
+        x[i] = (uint32_t)(p * pp_stride_ + i);
+      }
+      for (size_t j = 0; j < NM; j++) {
+        d[NI + j] = s.bad ? S::zero().f : s.scal[2][j].f;
+        x[NI + j] = slot_index(p, (int)misc_idx[j]);
+      }
+    });
+    for (size_t i = 0; i < n; i++) hs[N + i] = crs_sum[i].f;
+    *hf = FixTask{nullptr, d_scal_.p + N, 0, (uint32_t)n, 0, 0};
+    CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_big_idx_.p, hi, b_idx, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, sizeof(FixTask), hipMemcpyHostToDevice, stream_));
+    launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)(n_ + 3), d_tpart_.p, stream_);
+    tick("big_msm", 128.0 * N, (double)N, true);
+    launch_big_msm(plan, d_pp_.p, d_big_idx_.p, d_scal_.p, N, d_conv_.p, d_big_keys_.p, d_big_vals_.p, d_big_temp_.p, d_big_bounds_.p, d_big_buckets_.p,
+                   d_tpart_.p, fix_parts, d_res_.p, stream_);
+    tock();
+    h_comp_.ensure(sizeof(Jac));
+    CPX_HIP(hipMemcpyAsync(h_comp_.p, d_res_.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
+    wait_stream();
+    memcpy(fused_partial, h_comp_.p, sizeof(Jac));
+    if (fused_invalid) *fused_invalid = invalid;
+    flush_timers();
+    return;
+  }
 
   // -- V2: the accumulated MSM in four shards + the SameScalar equalities; V3: combine
   {

@@ -121,7 +121,11 @@ class Engine {
   // witnesses + the 3n+9 Fr draws per proof (SURVEY §8b RNG contract); writes batch * proof_size() bytes
   void batch_prove(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   // proofs: batch * proof_size() bytes; rand: batch * 8 Fr; verdict[i] = CPX_OK / CPX_ERR_VERIFY / CPX_ERR_DESERIALIZE
+  bool sum_jac(const uint8_t* points_jac, size_t n, uint8_t* out_jac);   // true iff the sum is the identity
   void batch_verify(const uint8_t* proofs, const uint8_t* rand, int* verdict);
+  // BASELINE config 5: all proofs of the batch in one accumulated MSM; 12 random factors per proof; output = this
+  // engine's partial sum (Jacobian, standard form) and the number of structurally invalid proofs
+  void batch_verify_fused(const uint8_t* proofs, const uint8_t* rand, uint8_t* partial_jac, int* n_invalid);
   size_t batch() const { return B_; }
 
   // ---- measurement ----
@@ -175,11 +179,13 @@ class Engine {
 
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
   void run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out);
+  void verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid);
   void batch_prove_fold(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   void batch_prove_tables(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   void run_smul(const std::vector<SmulTask>& tasks, int cnt, const host::S* scalars, size_t nscalars, double alg_bytes);
   const uint32_t* idx_list(const std::vector<uint32_t>& v);
-  void tick(const char* name, double bytes, double units);
+  void tick(const char* name, double bytes, double units, bool span = false);
+  bool span_ = false;
   void tock();
   void flush_timers();
   template <class F> void parallel_for(size_t n, F&& f);
@@ -261,6 +267,9 @@ class Engine {
   DevBuf<Fr> d_scal_;
   DevBuf<TJac> d_wsum_, d_part_;   // window sums / Horner partials of the bucket MSM (table representation)
   DevBuf<Jac> d_res_;
+  DevBuf<uint32_t> d_big_idx_, d_big_keys_, d_big_vals_, d_big_bounds_;   // large MSM of the fused verifier
+  DevBuf<uint8_t> d_big_temp_;
+  DevBuf<TJac> d_big_buckets_;
   DevBuf<TAff> d_conv_;            // table-form copies of the bases of a bucket-MSM phase
   DevBuf<TJac> d_tpart_;           // partial sums of the table kernels
   DevBuf<uint32_t> d_dst_;

@@ -106,6 +106,10 @@ CPX_HD Aff aff28_to_std(const Aff28& a) {
   if (a.is_identity()) return Aff::identity();
   return Aff{f28_to_std(a.x), f28_to_std(a.y)};
 }
+CPX_HD Jac28 jac28_from_std(const Jac& p) {
+  if (p.is_identity()) return Jac28::identity();
+  return Jac28{f28_from_std(p.x), f28_from_std(p.y), f28_from_std(p.z)};
+}
 CPX_HD Jac jac28_to_std(const Jac28& p) {
   if (p.is_identity()) return Jac::identity();
   return Jac{f28_to_std(p.x), f28_to_std(p.y), f28_to_std(p.z)};

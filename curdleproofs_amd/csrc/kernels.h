@@ -98,6 +98,17 @@ void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_o
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s);
+// ---- one large MSM (fused batch verification): wide-window Pippenger over ~10^6 points of d_pp gathered through d_idx ----
+struct BigMsmPlan {
+  int c, W, key_bits;          // window bits, windows, sort key width
+  uint32_t half, nbuckets;     // buckets per window, W * half
+  size_t nkeys;                // n * W (point, window) pairs
+  size_t sort_temp_bytes;
+};
+BigMsmPlan big_msm_plan(size_t n);
+void launch_big_msm(const BigMsmPlan& p, const Aff* d_pp, const uint32_t* d_idx, const Fr* d_scalars, size_t n, TAff* d_conv, uint32_t* d_keys,
+                    uint32_t* d_vals, void* d_sort_temp, uint32_t* d_bounds, TJac* d_buckets, const TJac* d_extra, int nextra, Jac* d_out, hipStream_t s);
+void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s);
 void launch_bench_fpmul(Fp* d_data, int blocks, int iters, hipStream_t s);
 void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s);
 

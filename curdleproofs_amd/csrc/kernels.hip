@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <hip/hip_ext.h>
+#include <hipcub/device/device_radix_sort.hpp>
 #include "g1.cuh"
 #include "tarith.cuh"
 #include "recode.cuh"
@@ -678,6 +679,104 @@ __global__ __launch_bounds__(64) void k_decompress(const uint8_t* __restrict__ i
   status[g] = st;
 }
 
+
+// ------------------------------------------------------------------ one large MSM (fused batch verification, BASELINE config 5)
+// Pippenger with wide windows for N ~ 10^6 points: signed radix-2^c digits (c = 8, 12 or 16), (window, |digit|)
+// keys sorted with the library radix sort, one lane per bucket walking its run of the sorted list, then a tree of
+// "weighted segment sums" per window and a Horner pass.  16 mixed additions per point at c = 16 instead of the 60
+// of the per-proof radix-16 kernels: this is where batching many proofs into one accumulator pays.
+__global__ __launch_bounds__(64) void k_big_gather(const Aff* __restrict__ pp, const uint32_t* __restrict__ idx, uint32_t n, TAff* __restrict__ conv) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) conv[i] = t_from_std(pp[idx[i]]);
+}
+// thread per point: all W digits.  keys[w * n + i] = w * 2^(c-1) + |d| - 1 (or `none` for a zero digit),
+// vals[...] = i | sign << 31
+__global__ __launch_bounds__(256) void k_big_keys(const Fr* __restrict__ scalars, uint32_t n, int c, int W, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Fr k = fe_from_mont(scalars[i]);
+  const uint32_t half = 1u << (c - 1), full = 1u << c, none = (uint32_t)W * half;
+  uint32_t carry = 0;
+  for (int w = 0; w < W; w++) {
+    const int bit = w * c, word = bit >> 5, off = bit & 31;
+    uint32_t chunk = 0;
+    if (word < 8) {
+      uint64_t two = k.v[word];
+      if (word + 1 < 8) two |= (uint64_t)k.v[word + 1] << 32;
+      chunk = (uint32_t)(two >> off) & (full - 1);
+    }
+    const uint32_t v = chunk + carry;           // <= 2^c
+    const bool neg = v >= half;                 // digit v - 2^c in [-2^(c-1), 0]
+    carry = neg ? 1u : 0u;
+    const uint32_t mag = neg ? full - v : v;    // |digit| <= 2^(c-1)
+    keys[(size_t)w * n + i] = mag ? (uint32_t)w * half + (mag - 1) : none;
+    vals[(size_t)w * n + i] = i | (neg ? 0x80000000u : 0u);
+  }
+}
+__global__ __launch_bounds__(256) void k_big_bounds(const uint32_t* __restrict__ keys, size_t total, uint32_t none, uint32_t* __restrict__ start,
+                                                    uint32_t* __restrict__ end) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total) return;
+  const uint32_t k = keys[j];
+  if (k >= none) return;
+  if (j == 0 || keys[j - 1] != k) start[k] = (uint32_t)j;
+  if (j + 1 == total || keys[j + 1] != k) end[k] = (uint32_t)(j + 1);
+}
+__global__ __launch_bounds__(64, 2) void k_big_accum(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ start, const uint32_t* __restrict__ end,
+                                                     const TAff* __restrict__ conv, uint32_t nbuckets, TJac* __restrict__ buckets) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= nbuckets) return;
+  TJac acc = TJac::identity();
+  const uint32_t e = end[b];
+  for (uint32_t j = start[b]; j < e; j++) {
+    const uint32_t v = vals[j];
+    const TAff q = conv[v & 0x7fffffffu];
+    acc = t_add_mixed(acc, t_cneg(q, (v >> 31) != 0));
+  }
+  buckets[b] = acc;
+}
+// One level of the per-window reduction  sum_b b * B_b.  A segment of m = 2^s consecutive buckets is summarised by
+// (T, S) = (sum_j (j+1) x_j, sum_j x_j); K neighbouring segments combine into one of length K m:
+//   S' = sum_i S_i,   T' = sum_i T_i + m * sum_i i S_i     (running sums from the top, then s doublings).
+// Level 0 passes the buckets themselves as both T and S (m = 1).  Thread per output segment.
+__global__ __launch_bounds__(64, 2) void k_big_combine(const TJac* __restrict__ Tin, const TJac* __restrict__ Sin, uint32_t nout, int K, int s,
+                                                       TJac* __restrict__ Tout, TJac* __restrict__ Sout) {
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= nout) return;
+  const TJac* Ti = Tin + (size_t)t * K;
+  const TJac* Si = Sin + (size_t)t * K;
+  TJac run = TJac::identity(), acc = TJac::identity(), tsum = Ti[0];
+  for (int i = K - 1; i >= 1; i--) {
+    run = t_add(run, Si[i]);
+    acc = t_add(acc, run);       // ends as sum_{i >= 1} i S_i
+    tsum = t_add(tsum, Ti[i]);
+  }
+  for (int d = 0; d < s; d++) acc = t_dbl(acc);
+  Tout[t] = t_add(tsum, acc);
+  Sout[t] = t_add(run, Si[0]);
+}
+// Horner over the W window sums, plus `nextra` further partial sums (the CRS part from k_msm_fix); standard form out.
+__global__ __launch_bounds__(64) void k_big_final(const TJac* __restrict__ wsum, int W, int c, const TJac* __restrict__ extra, int nextra, Jac* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  TJac acc = wsum[W - 1];
+  for (int w = W - 2; w >= 0; w--) {
+    for (int d = 0; d < c; d++) acc = t_dbl(acc);
+    acc = t_add(acc, wsum[w]);
+  }
+  for (int i = 0; i < nextra; i++) acc = t_add(acc, extra[i]);
+  out[0] = t_jac_to_std(acc);
+}
+
+// sum of n Jacobian points (the partial sums of several engines / GPUs); flag[0] = 1 iff the sum is the identity
+__global__ __launch_bounds__(64) void k_sum_jac(const Jac* __restrict__ in, int n, Jac* __restrict__ out, int* __restrict__ flag) {
+  if (threadIdx.x || blockIdx.x) return;
+  TJac acc = TJac::identity();
+  for (int i = 0; i < n; i++) acc = t_add(acc, t_jac_from_std(in[i]));
+  out[0] = t_jac_to_std(acc);
+  flag[0] = acc.is_identity() ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ micro-benchmarks (bench.py --micro)
 // Dependent Fp multiply chains: measures the achieved modular-multiply rate of this build.
 __global__ __launch_bounds__(256) void k_bench_fpmul(Fp* data, int iters) {
@@ -807,6 +906,61 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s) {
   if (n <= 0) return;
   CPX_LAUNCH(k_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in, n, d_out, d_dst_index, d_status, check_subgroup);
+}
+void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s) { CPX_LAUNCH(k_sum_jac, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_flag); }
+// ---- large MSM ----
+BigMsmPlan big_msm_plan(size_t n) {
+  BigMsmPlan p;
+  p.c = n >= (size_t(1) << 18) ? 16 : (n >= (size_t(1) << 13) ? 12 : 8);
+  if (const char* e = getenv("CPX_BIG_WINDOW")) {   // tests pin the window width to reach every plan with small inputs
+    const int v = atoi(e);
+    if (v == 8 || v == 12 || v == 16) p.c = v;
+  }
+  p.W = (256 + p.c - 1) / p.c;
+  p.half = 1u << (p.c - 1);
+  p.nbuckets = (uint32_t)p.W * p.half;
+  p.nkeys = n * (size_t)p.W;
+  p.sort_temp_bytes = 0;
+  uint32_t* nul = nullptr;
+  int end_bit = 1;
+  while ((1u << end_bit) <= p.nbuckets) end_bit++;
+  p.key_bits = end_bit;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, p.sort_temp_bytes, nul, nul, nul, nul, p.nkeys, 0, end_bit, nullptr);
+  return p;
+}
+// d_keys/d_vals: 2 * nkeys each (ping-pong); d_bounds: 2 * nbuckets; d_buckets: 3 * nbuckets TJac (buckets + two levels of (T, S));
+// result: d_out[0] (standard Jacobian) = sum scalars[i] * pp[idx[i]] + sum extra[j]
+void launch_big_msm(const BigMsmPlan& p, const Aff* d_pp, const uint32_t* d_idx, const Fr* d_scalars, size_t n, TAff* d_conv, uint32_t* d_keys,
+                    uint32_t* d_vals, void* d_sort_temp, uint32_t* d_bounds, TJac* d_buckets, const TJac* d_extra, int nextra, Jac* d_out, hipStream_t s) {
+  const uint32_t n32 = (uint32_t)n;
+  CPX_LAUNCH(k_big_gather, dim3((n32 + 63) / 64), dim3(64), 0, s, d_pp, d_idx, n32, d_conv);
+  CPX_LAUNCH(k_big_keys, dim3((n32 + 255) / 256), dim3(256), 0, s, d_scalars, n32, p.c, p.W, d_keys, d_vals);
+  size_t temp = p.sort_temp_bytes;
+  (void)hipcub::DeviceRadixSort::SortPairs(d_sort_temp, temp, d_keys, d_keys + p.nkeys, d_vals, d_vals + p.nkeys, p.nkeys, 0, p.key_bits, s);
+  uint32_t* start = d_bounds;
+  uint32_t* end = d_bounds + p.nbuckets;
+  (void)hipMemsetAsync(d_bounds, 0, 2 * (size_t)p.nbuckets * sizeof(uint32_t), s);
+  CPX_LAUNCH(k_big_bounds, dim3((unsigned)((p.nkeys + 255) / 256)), dim3(256), 0, s, d_keys + p.nkeys, p.nkeys, p.nbuckets, start, end);
+  CPX_LAUNCH(k_big_accum, dim3((p.nbuckets + 63) / 64), dim3(64), 0, s, d_vals + p.nkeys, start, end, d_conv, p.nbuckets, d_buckets);
+  // per-window reduction tree: segments of 32 (or what is left) per level
+  const TJac* Tin = d_buckets;
+  const TJac* Sin = d_buckets;
+  TJac* lvl = d_buckets + p.nbuckets;
+  uint32_t per_window = p.half;
+  int shift = 0;
+  while (per_window > 1) {
+    const int K = per_window >= 32 ? 32 : (int)per_window;
+    const uint32_t nout = (uint32_t)p.W * (per_window / K);
+    TJac* Tout = lvl;
+    TJac* Sout = lvl + nout;
+    CPX_LAUNCH(k_big_combine, dim3((nout + 63) / 64), dim3(64), 0, s, Tin, Sin, nout, K, shift, Tout, Sout);
+    Tin = Tout;
+    Sin = Sout;
+    lvl = Sout + nout;
+    per_window /= K;
+    while ((1 << shift) < (int)(p.half / per_window)) shift++;
+  }
+  CPX_LAUNCH(k_big_final, dim3(1), dim3(64), 0, s, Tin, p.W, p.c, d_extra, nextra, d_out);
 }
 void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s) {
   CPX_LAUNCH(k_bench_f28mul, dim3(blocks), dim3(256), 0, s, d_data, iters);

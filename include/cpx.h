@@ -96,6 +96,19 @@ int cpx_batch_prove(cpx_ctx* ctx, const uint32_t* permutation, const uint8_t* k,
  *   rand     batch*8*32: the eight `accumulate_check` factors (msm_accumulator.rs:44) in call order
  *   verdict  batch ints: CPX_OK, CPX_ERR_VERIFY or CPX_ERR_DESERIALIZE */
 int cpx_batch_verify(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, int* verdict);
+/* BASELINE config 5: the batched verifier.  Every `accumulate_check` of every loaded proof goes into
+ * ONE accumulated MSM — the reference's `MsmAccumulator` (msm_accumulator.rs:22-68; `new` is pub(crate), :28, and
+ * `CurdleproofsProof::verify` makes one per call, curdleproofs.rs:215) shared by all verify calls; the SameScalar
+ * equalities (same_scalar_argument.rs:127-137) join it with their own random weights.
+ *   rand         batch*12*32: per proof the eight `accumulate_check` factors, then four weights for the equalities
+ *   partial_jac  144 B: this context's share  sum (lhs - rhs)  of the accumulated check (Jacobian, standard form).
+ *                The batch is accepted iff the partial sums of all contexts / GPUs add up to the identity
+ *                (all-gather the 144-byte partials, add them with cpx_g1_sum_jac) and no context reports invalid proofs.
+ *   n_invalid    number of loaded proofs that failed deserialisation or the structural checks (curdleproofs.rs:218)
+ * All-or-nothing: a rejected batch does not say which proof is wrong (re-run cpx_batch_verify for that). */
+int cpx_batch_verify_fused(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, uint8_t* partial_jac, int* n_invalid);
+/* sum of n Jacobian points (n*144 B) -> out (144 B); *is_identity = 1 iff the sum is the point at infinity */
+int cpx_g1_sum_jac(cpx_ctx* ctx, const uint8_t* points_jac, size_t n, uint8_t* out_jac, int* is_identity);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 int cpx_set_profiling(cpx_ctx* ctx, int on); /* time every kernel group with HIP events on the ctx stream */

@@ -15,8 +15,7 @@ def load(path, counter):
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            k = k.split("<")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")   # keeps the template arguments: k_msm_tblw<64>
             tot[k] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     return {k: dict(total=tot[k], dispatches=len(disp[k])) for k in tot}

@@ -340,3 +340,65 @@ def test_table_msm_window_groupings_reproduce_kat(wpw):
                         "test_prove_matches_reference_kat_ell124 or test_prove_verify_ell252_batch"],
                        env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_batch_verifier_config5(ctx, orc):
+    # BASELINE config 5: one accumulated MSM over all proofs of the batch (all-or-nothing).  The verdict must equal
+    # the AND of the oracle's per-proof verdicts; the partial sum of a valid batch is the point at infinity.
+    import curdleproofs_amd as cpx
+    ell = 28
+    seeds = [0, 1, 2, 3, 4]
+    crs, insts, proofs = _prove_and_check(ctx, orc, ell, seeds)
+    rand = orc.rng(4242).fr(12 * len(seeds))
+    part, bad = ctx.verify_batch_fused_partial(proofs, rand)
+    assert bad == 0
+    assert orc.g1_compress_jac(part) == bytes([0xc0]) + bytes(47)          # identity
+    assert ctx.verify_batch_fused(proofs, rand)
+    # the same partial split over two "GPUs": halves of the batch, partials added like the all-gather step does
+    cat = lambda key, sel: b"".join(insts[i][key] for i in sel)
+    halves = []
+    for sel in ([0, 1], [2, 3, 4]):
+        ctx.load_batch(cat("vec_R", sel), cat("vec_S", sel), cat("vec_T", sel), cat("vec_U", sel), cat("M", sel))
+        pj, b = ctx.verify_batch_fused_partial([proofs[i] for i in sel], rand[:12 * 32 * len(sel)])
+        assert b == 0
+        halves.append(pj)
+    assert ctx.sum_jac(b"".join(halves))[1]
+    # one wrong proof anywhere rejects the batch: proof 3 verified against instance 2's proof bytes
+    ctx.load_batch(cat("vec_R", range(5)), cat("vec_S", range(5)), cat("vec_T", range(5)), cat("vec_U", range(5)), cat("M", range(5)))
+    wrong = list(proofs)
+    wrong[3] = proofs[2]
+    want = all(orc.verify(ell, crs, insts[i]["vec_R"], insts[i]["vec_S"], insts[i]["vec_T"], insts[i]["vec_U"], insts[i]["M"], wrong[i],
+                          insts[i]["verifier_rand"]) == 1 for i in range(5))
+    assert want is False
+    assert not ctx.verify_batch_fused(wrong, rand)
+    part, bad = ctx.verify_batch_fused_partial(wrong, rand)
+    assert orc.g1_compress_jac(part) != bytes([0xc0]) + bytes(47)
+    # a corrupted point encoding is reported as structurally invalid
+    broken = bytearray(proofs[1])
+    broken[0] ^= 0x80
+    wrong = list(proofs)
+    wrong[1] = bytes(broken)
+    part, bad = ctx.verify_batch_fused_partial(wrong, rand)
+    assert bad == 1 and not ctx.verify_batch_fused(wrong, rand)
+
+
+@pytest.mark.parametrize("ell,nproofs", [(124, 3)])
+def test_fused_batch_verifier_wider_windows(ctx, orc, ell, nproofs):
+    # enough points (> 2^13) for the 12-bit window plan of the large MSM
+    crs, insts, proofs = _prove_and_check(ctx, orc, ell, list(range(nproofs)) * 6)
+    rand = orc.rng(7).fr(12 * len(proofs))
+    assert ctx.verify_batch_fused(proofs, rand)
+    wrong = list(proofs)
+    wrong[-1] = proofs[0]
+    assert not ctx.verify_batch_fused(wrong, rand)
+
+
+@pytest.mark.parametrize("window", [16])
+def test_fused_batch_verifier_window_plans(window):
+    # the 16-bit plan is chosen from 2^18 points on (bench scale); pin it on the small batches (fresh process: read once per call site)
+    import subprocess
+    import sys
+    env = dict(os.environ, CPX_BIG_WINDOW=str(window))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "test_fused_batch_verifier_config5"],
+                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

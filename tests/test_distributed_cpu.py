@@ -10,7 +10,7 @@ WORKER = r'''
 import os, sys, time, json
 sys.path.insert(0, %r)
 import torch.distributed as dist
-from curdleproofs_amd.dist import env_world, partition, max_over_ranks, gather_lists
+from curdleproofs_amd.dist import env_world, partition, max_over_ranks, gather_lists, all_gather_partials
 from tests.oracle_lib import Oracle
 world, rank, _ = env_world()
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -26,8 +26,18 @@ for seed in mine:                      # BASELINE config 4 recipe: proof i uses 
 dt = time.perf_counter() - t0
 tmax = max_over_ranks(dt, dist)
 allv = gather_lists(verdicts, dist)
+# config 5 exchange step: rank r contributes (+/-) k * G so that the partial sums cancel; the oracle stands in for the GPU adder
+k = orc.fr_from_u64(987654321)
+mk = orc.fr_from_canonical_bytes((0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001 - 987654321).to_bytes(32, "little"))
+part = orc.g1_msm(orc.g1_generator(), k if rank == 0 else mk)
+parts, bad = all_gather_partials(part, rank, dist)          # rank r reports r invalid proofs
+total = parts[:144]
+for r in range(1, world):
+    total = orc.g1_add_jac(total, parts[144 * r:144 * (r + 1)])
 if rank == 0:
-    print(json.dumps(dict(world=world, order=[s for s, _ in allv], ok=[v for _, v in allv], tmax_ge_local=tmax >= dt - 1e-9)))
+    print(json.dumps(dict(world=world, order=[s for s, _ in allv], ok=[v for _, v in allv], tmax_ge_local=tmax >= dt - 1e-9,
+                          gathered=len(parts) // 144, bad=bad, cancels=orc.g1_compress_jac(total)[0] == 0xc0,
+                          first_is_mine=parts[:144] == part)))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -54,3 +64,5 @@ def test_two_rank_gloo_run(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["world"] == 2 and res["order"] == [0, 1, 2, 3, 4] and res["ok"] == [1] * 5 and res["tmax_ge_local"]
+    # config 5: all-gather of the 144-byte partial sums (+ invalid counts) in rank order, partials cancel
+    assert res["gathered"] == 2 and res["bad"] == 1 and res["cancels"] and res["first_is_mine"]

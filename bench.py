@@ -334,6 +334,21 @@ def main():
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
                    vs_readme_i7_8550u=value / README_I7_PROOFS_PER_S, roofline=roofline)
+        # BASELINE configs[1]: the same instance shape as ONE proof (latency, not throughput): instance 0 alone on context 0
+        AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
+        c0, n_ = ctxs[0], ell + 4
+        c0.load_batch(data["vec_R"][:ell * AFF], data["vec_S"][:ell * AFF], data["vec_T"][:ell * AFF], data["vec_U"][:ell * AFF], data["M"][:JAC])
+        tp, tv = [], []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            one = c0.prove_batch(data["perms"][:ell], data["k"][:FR], data["mbl"][:4 * FR], data["prand"][:(3 * n_ + 9) * FR])
+            t1 = time.perf_counter()
+            v1 = c0.verify_batch(one, data["vrand"][:8 * FR])
+            t2 = time.perf_counter()
+            tp.append(t1 - t0)
+            tv.append(t2 - t1)
+        out["single_proof"] = dict(prove_ms=1e3 * min(tp), verify_ms=1e3 * min(tv), accepted=v1 == [cpx.CPX_OK],
+                                   note="BASELINE configs[1] as a latency figure: one ell=%d proof alone on the GPU (best of 4)" % ell)
         if not args.no_cpu_baseline:
             psz = ctxs[0].proof_size
             out["cpu_baseline"] = cpu_baseline(ell, data, bytes(proofs[0])[:psz])

@@ -268,6 +268,13 @@ def test_prove_verify_ell252_batch(ctx, orc, oracle_vectors):
     assert hashlib.sha256(proofs[0]).hexdigest() == oracle_vectors["252"]["proof_sha256"]
 
 
+def test_prove_verify_ell1020_single(ctx, orc, oracle_vectors):
+    # BASELINE config 3 (ell = 1020, n = 1024, 10 rounds, seed 0): proof bytes equal the oracle's, 5888 B
+    crs, insts, proofs = _prove_and_check(ctx, orc, 1020, [0])
+    assert len(proofs[0]) == 5888
+    assert hashlib.sha256(proofs[0]).hexdigest() == oracle_vectors["1020"]["proof_sha256"]
+
+
 def test_verify_rejects_mutated_instances(ctx, orc):
     # curdleproofs.rs:427-470 test_bad_shuffle_arguments, N = 128: the four negative mutations
     import curdleproofs_amd as cpx

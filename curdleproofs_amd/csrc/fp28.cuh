@@ -45,6 +45,9 @@ struct F28Cfg {
                                        0x683dcf8, 0x6c26d0b, 0x4a5eec2, 0x457663c, 0x04b29f1, 0x967f3e8, 0x0015de9};
   static constexpr int32_t BETA[14] = {0xa75929a, 0x681b798, 0x22a3e9d, 0xabc02bf, 0x4e5bb45, 0x55e6e7e, 0x4814117,
                                        0x6d04f1b, 0xae3387d, 0x54acb0c, 0x0a4c74b, 0x56138b5, 0xb64e066, 0x00076f2};
+  // 2^1176 mod p: plain integer -> Montgomery form with two extra factors of 2^392 (used after an integer inversion)
+  static constexpr int32_t C_INV[14] = {0x1f7b890, 0x294cc4d, 0x9f3af22, 0xb5ba56c, 0xcb5c0cc, 0xc0d975c, 0xc89a8c5,
+                                        0x6c968b4, 0x22672ea, 0x91de8c9, 0x35652a6, 0x84977c8, 0x424bbb9, 0x00141ab};
   static constexpr int32_t C_OUT[14] = {0x002fffd, 0x0900000, 0xc000276, 0x000bc40, 0x8baebf4, 0x5753c75, 0x55f4898,
                                         0x7052574, 0x7ce5853, 0x56ec6d7, 0x71a97a2, 0xe4935c0, 0xec3fa80, 0x0015f65};
 };
@@ -177,19 +180,12 @@ CPX_HD bool f28_product_is_zero(const F28& a) {
 }
 
 // standard wire form (12 x u32 Montgomery, R = 2^384, canonical) <-> internal
+CPX_HD F28 f28_from_words(const uint32_t* w);
 CPX_HD F28 f28_from_std(const Fp& s) {
-  F28 u;
-  CPX_UNROLL for (int i = 0; i < 14; i++) {
-    const int bit = 28 * i, w = bit >> 5, o = bit & 31;
-    uint64_t x = s.v[w];
-    if (w + 1 < 12) x |= (uint64_t)s.v[w + 1] << 32;
-    u.v[i] = (int32_t)((x >> o) & (uint32_t)F28Cfg::MASK);
-  }
-  return f28_mul(u, f28_const(F28Cfg::C_IN));   // X * 2^400 / 2^392 = X * 2^8 = x * 2^392
+  return f28_mul(f28_from_words(s.v), f28_const(F28Cfg::C_IN));   // X * 2^400 / 2^392 = X * 2^8 = x * 2^392
 }
-CPX_HD Fp f28_to_std(const F28& a) {
-  F28 t = f28_mul(a, f28_const(F28Cfg::C_OUT));   // x * 2^384, in (-0.81p, 1.81p)
-  // canonicalise: add p if negative, then subtract p if >= p
+// canonical integer value (12 x u32) of a PRODUCT-range lazy value (-0.81p, 1.81p)
+CPX_HD void f28_canonical_words(F28 t, uint32_t* w) {
   const bool neg = t.v[13] < 0;
   CPX_UNROLL for (int i = 0; i < 14; i++) t.v[i] += neg ? F28Cfg::P[i] : 0;
   f28_normalize(t);
@@ -198,15 +194,36 @@ CPX_HD Fp f28_to_std(const F28& a) {
   f28_normalize(d);
   const bool ge = d.v[13] >= 0;
   CPX_UNROLL for (int i = 0; i < 14; i++) t.v[i] = ge ? d.v[i] : t.v[i];
-  Fp r;
-  CPX_UNROLL for (int w = 0; w < 12; w++) {
-    const int bit = 32 * w, i = bit / 28, o = bit % 28;
+  CPX_UNROLL for (int k = 0; k < 12; k++) {
+    const int bit = 32 * k, i = bit / 28, o = bit % 28;
     uint64_t x = (uint64_t)(uint32_t)t.v[i] >> o;
     if (i + 1 < 14) x |= (uint64_t)(uint32_t)t.v[i + 1] << (28 - o);
     if (i + 2 < 14 && 56 - o < 32) x |= (uint64_t)(uint32_t)t.v[i + 2] << (56 - o);
-    r.v[w] = (uint32_t)x;
+    w[k] = (uint32_t)x;
   }
+}
+CPX_HD F28 f28_from_words(const uint32_t* w) {   // plain 28-bit limbs of a 384-bit integer (no Montgomery factor applied)
+  F28 u;
+  CPX_UNROLL for (int i = 0; i < 14; i++) {
+    const int bit = 28 * i, k = bit >> 5, o = bit & 31;
+    uint64_t x = w[k];
+    if (k + 1 < 12) x |= (uint64_t)w[k + 1] << 32;
+    u.v[i] = (int32_t)((x >> o) & (uint32_t)F28Cfg::MASK);
+  }
+  return u;
+}
+CPX_HD Fp f28_to_std(const F28& a) {
+  Fp r;
+  f28_canonical_words(f28_mul(a, f28_const(F28Cfg::C_OUT)), r.v);   // x * 2^384, canonical
   return r;
+}
+// Inverse of a lazy PRODUCT-range value by the binary Euclidean algorithm (mont32.cuh: words_inv_mod_p):
+// X = a 2^392 -> X^-1 = a^-1 2^-392 as a plain integer -> one product with 2^1176 gives a^-1 2^392.
+CPX_HD F28 f28_inv_euclid(const F28& a) {
+  uint32_t w[12], iw[12];
+  f28_canonical_words(f28_mul(a, f28_one()), w);   // any lazy input: one product brings it into the canonicalisable range
+  words_inv_mod_p(w, iw);
+  return f28_mul(f28_from_words(iw), f28_const(F28Cfg::C_INV));
 }
 
 }  // namespace cpx

@@ -316,4 +316,98 @@ template <class C> CPX_HD Fe<C> fe_inv(const Fe<C>& a) {
 typedef Fe<FpCfg> Fp;
 typedef Fe<FrCfg> Fr;
 
+// ---- inversion by the binary extended Euclidean algorithm (one value at a time) ----
+// a^-1 mod p for a canonical integer 0 < a < p (plain 12 x u32 words, no Montgomery factor).  About 760 halvings
+// and 380 subtractions of 384-bit integers, ~85 k cheap instructions, against the 571 Montgomery products (~290 k
+// instructions) of Fermat's a^(p-2): the kernels that invert ONE value per work-group (batch inversion by product
+// scans) are bound by the latency of exactly this chain.  Variable time: only public data (group elements of the
+// proof) is ever inverted on the device.
+CPX_HD void words_inv_mod_p(const uint32_t* a_in, uint32_t* out) {
+  constexpr int N = 12;
+  uint32_t u[N], v[N], x1[N], x2[N];
+  CPX_UNROLL for (int i = 0; i < N; i++) {
+    u[i] = a_in[i];
+    v[i] = FpCfg::P[i];
+    x1[i] = 0;
+    x2[i] = 0;
+  }
+  x1[0] = 1;
+  auto is_one = [](const uint32_t* w) {
+    uint32_t o = w[0] ^ 1u;
+    CPX_UNROLL for (int i = 1; i < N; i++) o |= w[i];
+    return o == 0;
+  };
+  auto halve = [](uint32_t* w, uint32_t top) {   // (top:w) >> 1
+    CPX_UNROLL for (int i = 0; i < N - 1; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
+    w[N - 1] = (w[N - 1] >> 1) | (top << 31);
+  };
+  auto halve_mod = [&](uint32_t* x) {            // x / 2 mod p
+    uint32_t carry = 0;
+    if (x[0] & 1u) {
+      uint64_t c = 0;
+      CPX_UNROLL for (int i = 0; i < N; i++) {
+        c += (uint64_t)x[i] + FpCfg::P[i];
+        x[i] = (uint32_t)c;
+        c >>= 32;
+      }
+      carry = (uint32_t)c;
+    }
+    halve(x, carry);
+  };
+  auto geq = [](const uint32_t* a, const uint32_t* b) {
+    for (int i = N - 1; i >= 0; i--) {
+      if (a[i] != b[i]) return a[i] > b[i];
+    }
+    return true;
+  };
+  auto sub = [](uint32_t* a, const uint32_t* b) {   // a -= b, returns the borrow
+    uint64_t bw = 0;
+    CPX_UNROLL for (int i = 0; i < N; i++) {
+      const uint64_t d = (uint64_t)a[i] - b[i] - bw;
+      a[i] = (uint32_t)d;
+      bw = (d >> 32) & 1u;
+    }
+    return (uint32_t)bw;
+  };
+  auto sub_mod = [&](uint32_t* a, const uint32_t* b) {   // a = a - b mod p, both in [0, p)
+    if (sub(a, b)) {
+      uint64_t c = 0;
+      CPX_UNROLL for (int i = 0; i < N; i++) {
+        c += (uint64_t)a[i] + FpCfg::P[i];
+        a[i] = (uint32_t)c;
+        c >>= 32;
+      }
+    }
+  };
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1u)) {
+      halve(u, 0);
+      halve_mod(x1);
+    }
+    while (!(v[0] & 1u)) {
+      halve(v, 0);
+      halve_mod(x2);
+    }
+    if (geq(u, v)) {
+      sub(u, v);
+      sub_mod(x1, x2);
+    } else {
+      sub(v, u);
+      sub_mod(x2, x1);
+    }
+  }
+  const bool first = is_one(u);
+  CPX_UNROLL for (int i = 0; i < N; i++) out[i] = first ? x1[i] : x2[i];
+}
+
+// Montgomery-form inverse through it: X = a R  ->  X^-1 = a^-1 R^-1  ->  times R^3 (one Montgomery product) = a^-1 R
+CPX_HD Fp fe_inv_euclid(const Fp& a) {
+  static constexpr uint32_t R3[12] = {0xd94ca1e0u, 0xed48ac6bu, 0x03a7adf8u, 0x315f831eu, 0x615e29ddu, 0x9a53352au,
+                                      0x921e1761u, 0x34c04e5eu, 0x65724728u, 0x2512d435u, 0x91755d4du, 0x0aa63460u};
+  Fp t, r3;
+  words_inv_mod_p(a.v, t.v);
+  CPX_UNROLL for (int i = 0; i < 12; i++) r3.v[i] = R3[i];
+  return fe_mul(t, r3);
+}
+
 }  // namespace cpx

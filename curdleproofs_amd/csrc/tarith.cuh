@@ -33,7 +33,7 @@ CPX_HD TAff t_from_std(const Aff& a) { return aff28_from_std(a); }
 CPX_HD Aff t_to_std(const TAff& a) { return aff28_to_std(a); }
 CPX_HD Jac t_jac_to_std(const TJac& p) { return jac28_to_std(p); }
 CPX_HD TJac t_jac_from_std(const Jac& p) { return jac28_from_std(p); }
-CPX_HD TF t_inv(const TF& a) { return f28_inv(a); }
+CPX_HD TF t_inv(const TF& a) { return f28_inv_euclid(a); }
 #else
 typedef Fp TF;
 typedef Aff TAff;
@@ -53,7 +53,7 @@ CPX_HD TAff t_from_std(const Aff& a) { return a; }
 CPX_HD Aff t_to_std(const TAff& a) { return a; }
 CPX_HD Jac t_jac_to_std(const TJac& p) { return p; }
 CPX_HD TJac t_jac_from_std(const Jac& p) { return p; }
-CPX_HD TF t_inv(const TF& a) { return fe_inv(a); }
+CPX_HD TF t_inv(const TF& a) { return fe_inv_euclid(a); }
 #endif
 
 }  // namespace cpx

@@ -244,4 +244,16 @@ int emul_f28_in_subgroup(const uint8_t* aff) {
   return g1_28_in_subgroup(aff28_from_std(p)) ? 1 : 0;
 }
 
+// binary-Euclid inversions against Fermat, both field forms
+int emul_inv_euclid(const uint8_t* a, uint8_t* out /*2*48: std form, table form converted back*/) {
+  Fp x;
+  memcpy(x.v, a, 48);
+  const Fp e = fe_inv_euclid(x), f = fe_inv(x);
+  const F28 x28 = f28_mul(f28_from_std(x), f28_one());
+  const Fp e28 = f28_to_std(f28_inv_euclid(x28)), f28v = f28_to_std(f28_inv(x28));
+  memcpy(out, e.v, 48);
+  memcpy(out + 48, e28.v, 48);
+  return (memcmp(e.v, f.v, 48) == 0 && memcmp(e28.v, f28v.v, 48) == 0 && memcmp(e.v, e28.v, 48) == 0) ? 1 : 0;
+}
+
 }  // extern "C"

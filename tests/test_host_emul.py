@@ -205,3 +205,14 @@ def test_f28_sqrt_and_endomorphism_subgroup_test(emul, orc):
         pt = good[i * AFF:(i + 1) * AFF]
         assert orc.g1_in_subgroup(pt) and emul.emul_f28_in_subgroup(_b(pt)) == 1
     assert emul.emul_f28_in_subgroup(_b(bytes(AFF))) == 1   # identity
+
+
+def test_euclid_inversion_matches_fermat(emul, orc):
+    """words_inv_mod_p / fe_inv_euclid / f28_inv_euclid: the one-value inversion of the batch-inversion kernels."""
+    vals = [1, 2, 3, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 380, (1 << 381) - 1, 0x1234567] + [int.from_bytes(os.urandom(48), "little") % P for _ in range(40)]
+    for x in vals:
+        if x == 0:
+            continue
+        r = _o(96)
+        assert emul.emul_inv_euclid(_b(_to_mont(x)), r) == 1
+        assert _from_mont(bytes(r)[:48]) == pow(x, -1, P) == _from_mont(bytes(r)[48:])

@@ -37,7 +37,7 @@ __device__ __noinline__ Fp fp_inv_device(const Fp& a) { return fe_inv_euclid(a);
 
 // In-work-group batch inversion.  Every thread passes its z (any value; zero is treated as 1 and
 // returns an unspecified value the caller must ignore).  `buf` holds 2 * blockDim.x Fp values.
-// Inclusive Hillis-Steele product scans from both ends, one Fermat inversion by wave 0.
+// Inclusive Hillis-Steele product scans from both ends, one inversion by wave 0.
 __device__ __forceinline__ Fp block_batch_inverse(Fp z, Fp* buf) {
   const int tid = threadIdx.x, n = blockDim.x;
   if (z.is_zero()) z = Fp::one();
@@ -846,7 +846,11 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, 
 }
 int msm_fix_windows_per_wave(int ntasks, int cbits) {
   const int w = 256 / cbits;
-  return (long)ntasks * (w / 16) >= 2048 ? 16 : 8;
+  static const long min_waves = [] {
+    const char* e = getenv("CPX_FIX_MIN_WAVES");
+    return e ? atol(e) : 4096L;   // two waves per SIMD
+  }();
+  return (long)ntasks * (w / 16) >= min_waves ? 16 : 8;
 }
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;

@@ -78,7 +78,7 @@ def cpu_baseline(ell, data, gpu_proof0, budget_s=12.0):
                 prove_s=tp / reps, verify_s=tv / reps, accepted=bool(ok), gpu_proof_bit_exact=bool(parity))
 
 
-def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch):
+def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, red_dev="cuda"):
     """BASELINE config 5: batched verifier.  Proofs are produced once (untimed); a step = every context's fused
     verification of its share (one wide-window MSM per context), the per-GPU partial sums added on the GPU, one
     all-gather of 144-byte partials over the ranks and the final identity test."""
@@ -104,7 +104,7 @@ def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch):
         for t in th:
             t.join()
         part, _ = ctxs[0].sum_jac(b"".join(o[0] for o in out))              # this GPU's partial
-        parts, bad = all_gather_partials(part, sum(o[1] for o in out), dist, "cuda")
+        parts, bad = all_gather_partials(part, sum(o[1] for o in out), dist, red_dev)
         return bad == 0 and ctxs[0].sum_jac(parts)[1]
 
     def barrier():
@@ -125,7 +125,7 @@ def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch):
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stats = {}
@@ -186,11 +186,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (a 1-GPU box can rehearse the multi-rank path): CPX_BENCH_DEVICE pins every rank to one device,
+    # CPX_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on the same GPU)
+    backend = os.environ.get("CPX_BENCH_BACKEND", "nccl")
+    if "CPX_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["CPX_BENCH_DEVICE"])
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     import curdleproofs_amd as cpx
     import threading
     ell, B, K = args.ell, args.batch, max(1, args.ctxs)
@@ -236,7 +245,7 @@ def main():
         shares.append(sh)
 
     if args.fused_verify:
-        return run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch)
+        return run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, red_dev)
 
     def step_one(k, out):
         c, sh = ctxs[k], shares[k]
@@ -273,7 +282,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     all_ok = all(v == cpx.CPX_OK for v in verdicts)

@@ -379,15 +379,19 @@ CPX_HD void words_inv_mod_p(const uint32_t* a_in, uint32_t* out) {
       }
     }
   };
-  while (!is_one(u) && !is_one(v)) {
-    while (!(u[0] & 1u)) {
+  // u + v loses at least one bit per halving: <= 2 * 384 halvings in total.  The budget only matters for the
+  // invalid input a = 0 (never produced by the callers), which must not spin forever on a GPU.
+  int budget = 4 * 384;
+  while (!is_one(u) && !is_one(v) && budget > 0) {
+    while (!(u[0] & 1u) && budget-- > 0) {
       halve(u, 0);
       halve_mod(x1);
     }
-    while (!(v[0] & 1u)) {
+    while (!(v[0] & 1u) && budget-- > 0) {
       halve(v, 0);
       halve_mod(x2);
     }
+    budget--;
     if (geq(u, v)) {
       sub(u, v);
       sub_mod(x1, x2);

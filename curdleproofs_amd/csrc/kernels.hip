@@ -569,20 +569,19 @@ __global__ __launch_bounds__(256) void k_compress(const Aff* __restrict__ in, in
 //   s = scalars[e * scalar_stride]  (stride 0: one scalar for the whole task = a fold).
 // All tasks of a launch have `cnt` elements; consecutive threads take consecutive elements so the
 // 96-byte point loads/stores of a wave are contiguous.
+// The arithmetic runs on the table form: the two input points are converted on load (2 products per coordinate)
+// and the result is converted back after the in-group batch inversion.
 constexpr int SMUL_THREADS = 256;
 
-#ifndef CPX_SMUL_WAVES
-#define CPX_SMUL_WAVES 2
-#endif
-__global__ __launch_bounds__(SMUL_THREADS, CPX_SMUL_WAVES) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
+__global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  Fp* buf = reinterpret_cast<Fp*>(smem);                                             // 2*256 Fp = 24 KB
-  uint32_t* naf = reinterpret_cast<uint32_t*>(smem + 2 * SMUL_THREADS * sizeof(Fp));  // [18][256]
+  TF* buf = reinterpret_cast<TF*>(smem);                                             // 2*256 field elements
+  uint32_t* naf = reinterpret_cast<uint32_t*>(smem + 2 * SMUL_THREADS * sizeof(TF));  // [18][256]
   const int tid = threadIdx.x;
   const long g = (long)blockIdx.x * blockDim.x + tid;
   const long total = (long)ntasks * cnt;
   const bool live = g < total;
-  Jac acc = Jac::identity();
+  TJac acc = TJac::identity();
   Aff* dst = nullptr;
   if (live) {
     const int t = (int)(g / cnt), e = (int)(g % cnt);
@@ -596,21 +595,21 @@ __global__ __launch_bounds__(SMUL_THREADS, CPX_SMUL_WAVES) void k_smul(const Smu
       naf[i * SMUL_THREADS + tid] = nz[i];
       naf[(9 + i) * SMUL_THREADS + tid] = ng[i];
     }
-    const Aff P = task.mul[e];
+    const TAff P = t_from_std(task.mul[e]);
     for (int i = 256; i >= 0; i--) {
-      acc = jac_dbl_fn(acc);
+      acc = t_dbl(acc);
       const uint32_t nzw = naf[(i >> 5) * SMUL_THREADS + tid];
       if ((nzw >> (i & 31)) & 1u) {
         const uint32_t ngw = naf[(9 + (i >> 5)) * SMUL_THREADS + tid];
-        acc = jac_add_mixed_fn(acc, aff_cneg(P, (ngw >> (i & 31)) & 1u));
+        acc = t_add_mixed(acc, t_cneg(P, (ngw >> (i & 31)) & 1u));
       }
     }
-    if (task.add) acc = jac_add_mixed_fn(acc, task.add[e]);
+    if (task.add) acc = t_add_mixed(acc, t_from_std(task.add[e]));
   }
   const bool inf = acc.is_identity();
-  Fp zinv = block_batch_inverse(acc.z, buf);
+  const TF zinv = t_block_batch_inverse(acc.z, buf);
   if (!live) return;
-  *dst = inf ? Aff::identity() : jac_to_affine_with_zinv(acc, zinv);
+  *dst = inf ? Aff::identity() : t_to_std(t_to_affine(acc, zinv));
 }
 
 // ------------------------------------------------------------------ decompression (+ subgroup check)
@@ -890,7 +889,7 @@ void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_o
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
   const long total = (long)ntasks * cnt;
   if (total <= 0) return;
-  const size_t lds = 2 * SMUL_THREADS * sizeof(Fp) + 18 * SMUL_THREADS * sizeof(uint32_t);
+  const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 18 * SMUL_THREADS * sizeof(uint32_t);
   CPX_LAUNCH(k_smul, dim3((unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS)), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
 }
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s) {

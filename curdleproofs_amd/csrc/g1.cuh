@@ -1,22 +1,17 @@
-// BLS12-381 G1 group law on 32-bit-limb Montgomery Fp — product code (host + gfx950 device).
+// BLS12-381 G1 points in the standard form (32-bit-limb Montgomery Fp) — product code (host + gfx950 device).
+// The group law itself runs on the table form (g1_28.cuh); this header holds the wire types, the affine
+// normalisation step and the compressed encoding.
 //
 // Points cross the C-ABI in arkworks' in-memory limb layout (include/cpx.h):
 //   Aff : x || y                (96 B; the identity is encoded x = y = 0 — (0,0) is not on y^2 = x^3 + 4)
 //   Jac : X || Y || Z Jacobian  (144 B; Z = 0 is the identity)
-// The formulas are complete w.r.t. the corner cases the reference's inputs really contain:
-// identity operands (the G1Affine::zero() padding of curdleproofs.rs:141-155 in /root/reference),
-// P + P and P + (-P) (ark-ec's add falls back to doubling / identity the same way).
 #pragma once
 #include "mont32.cuh"
 
-// Point formulas: inlined into the kernels by default so that a kernel's __launch_bounds__ governs their
-// register budget (a non-kernel function is compiled for the maximum budget: 248 VGPRs here, which pins
-// every caller at 2 waves per SIMD).  -DCPX_PT_NOINLINE restores real calls for A/B runs.
-#if defined(CPX_PT_NOINLINE)
-#define CPX_PT_FN CPX_HD_FN
-#else
+// Point formulas (g1_28.cuh) are inlined into the kernels so that a kernel's __launch_bounds__ governs their
+// register budget (a non-kernel function is compiled for the maximum budget, which pins every caller at 2 waves
+// per SIMD).
 #define CPX_PT_FN CPX_HD
-#endif
 
 namespace cpx {
 
@@ -51,77 +46,6 @@ CPX_HD Aff aff_cneg(const Aff& p, bool neg) {
   return r;
 }
 CPX_HD Jac jac_neg(const Jac& p) { return Jac{p.x, fe_neg(p.y), p.z}; }
-
-// dbl-2009-l (a = 0): 2M + 5S
-CPX_PT_FN Jac jac_dbl(const Jac& p) {
-  // Z = 0 stays 0 through the formula (Z3 = 2*Y*Z), so no identity branch is needed.
-  Fp A = fe_sqr(p.x), B = fe_sqr(p.y), C = fe_sqr(B);
-  Fp D = fe_sub(fe_sub(fe_sqr(fe_add(p.x, B)), A), C);
-  D = fe_dbl(D);
-  Fp E = fe_add(fe_dbl(A), A), F = fe_sqr(E);
-  Jac r;
-  r.x = fe_sub(F, fe_dbl(D));
-  Fp C8 = fe_dbl(fe_dbl(fe_dbl(C)));
-  r.y = fe_sub(fe_mul(E, fe_sub(D, r.x)), C8);
-  r.z = fe_dbl(fe_mul(p.y, p.z));
-  return r;
-}
-
-// madd-2007-bl: 7M + 4S; complete
-CPX_PT_FN Jac jac_add_mixed(const Jac& p, const Aff& q) {
-  if (q.is_identity()) return p;
-  if (p.is_identity()) return Jac::from_affine(q);
-  Fp z1z1 = fe_sqr(p.z);
-  Fp u2 = fe_mul(q.x, z1z1);
-  Fp s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
-  Fp h = fe_sub(u2, p.x);
-  Fp rr = fe_sub(s2, p.y);
-  if (h.is_zero()) {
-    if (rr.is_zero()) return jac_dbl(p);
-    return Jac::identity();
-  }
-  rr = fe_dbl(rr);
-  Fp hh = fe_sqr(h);
-  Fp i = fe_dbl(fe_dbl(hh));
-  Fp j = fe_mul(h, i);
-  Fp v = fe_mul(p.x, i);
-  Jac r;
-  r.x = fe_sub(fe_sub(fe_sqr(rr), j), fe_dbl(v));
-  r.y = fe_sub(fe_mul(rr, fe_sub(v, r.x)), fe_dbl(fe_mul(p.y, j)));
-  r.z = fe_sub(fe_sub(fe_sqr(fe_add(p.z, h)), z1z1), hh);
-  return r;
-}
-
-// add-2007-bl: 11M + 5S; complete
-CPX_PT_FN Jac jac_add(const Jac& p, const Jac& q) {
-  if (p.is_identity()) return q;
-  if (q.is_identity()) return p;
-  Fp z1z1 = fe_sqr(p.z), z2z2 = fe_sqr(q.z);
-  Fp u1 = fe_mul(p.x, z2z2), u2 = fe_mul(q.x, z1z1);
-  Fp s1 = fe_mul(fe_mul(p.y, q.z), z2z2), s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
-  Fp h = fe_sub(u2, u1);
-  Fp rr = fe_sub(s2, s1);
-  if (h.is_zero()) {
-    if (rr.is_zero()) return jac_dbl(p);
-    return Jac::identity();
-  }
-  rr = fe_dbl(rr);
-  Fp i = fe_sqr(fe_dbl(h));
-  Fp j = fe_mul(h, i);
-  Fp v = fe_mul(u1, i);
-  Jac r;
-  r.x = fe_sub(fe_sub(fe_sqr(rr), j), fe_dbl(v));
-  r.y = fe_sub(fe_mul(rr, fe_sub(v, r.x)), fe_dbl(fe_mul(s1, j)));
-  r.z = fe_mul(fe_sub(fe_sub(fe_sqr(fe_add(p.z, q.z)), z1z1), z2z2), h);
-  return r;
-}
-
-// Real-call versions of the three formulas.  k_smul uses these: with the formulas inlined, hipcc (ROCm 7.2)
-// miscompiles that kernel at register budgets above 128 VGPRs (every fold/scale parity test fails, with
-// or without the inline-asm multiply) while the called form is bit-exact; see DESIGN.md "toolchain notes".
-CPX_HD_FN Jac jac_dbl_fn(const Jac& p) { return jac_dbl(p); }
-CPX_HD_FN Jac jac_add_mixed_fn(const Jac& p, const Aff& q) { return jac_add_mixed(p, q); }
-CPX_HD_FN Jac jac_add_fn(const Jac& p, const Jac& q) { return jac_add(p, q); }
 
 // Jacobian -> affine given zinv = Z^-1 (caller handles identity)
 CPX_HD Aff jac_to_affine_with_zinv(const Jac& p, const Fp& zinv) {

@@ -88,9 +88,6 @@ CPX_PT_FN Jac28 jac28_add(const Jac28& p, const Jac28& q) {
   r.z = f28_shl<1>(zzh);
   return r;
 }
-CPX_HD_FN Jac28 jac28_dbl_fn(const Jac28& p) { return jac28_dbl(p); }
-CPX_HD_FN Jac28 jac28_add_mixed_fn(const Jac28& p, const Aff28& q) { return jac28_add_mixed(p, q); }
-CPX_HD_FN Jac28 jac28_add_fn(const Jac28& p, const Jac28& q) { return jac28_add(p, q); }
 
 CPX_HD Aff28 jac28_to_affine_with_zinv(const Jac28& p, const F28& zinv) {
   const F28 zi2 = f28_sqr(zinv);

@@ -71,7 +71,7 @@ __device__ __forceinline__ Fp block_batch_inverse(Fp z, Fp* buf) {
   return fe_mul(fe_mul(tinv, left), right);
 }
 
-// The same for the table kernels' field (tarith.cuh): 28-bit-limb lazy values.
+// The same on the table form (tarith.cuh): 28-bit-limb lazy values.
 __device__ __noinline__ TF t_inv_device(const TF& a) { return t_inv(a); }
 __device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
   const int tid = threadIdx.x, n = blockDim.x;

@@ -6,7 +6,7 @@
 #include <cstring>
 #include <vector>
 #include "../../curdleproofs_amd/csrc/g1.cuh"
-#include "../../curdleproofs_amd/csrc/g1_28.cuh"
+#include "../../curdleproofs_amd/csrc/tarith.cuh"
 #include "../../curdleproofs_amd/csrc/recode.cuh"
 #include "../../curdleproofs_amd/csrc/host_math.hpp"
 
@@ -52,70 +52,74 @@ void emul_fr_inv(const uint8_t* a, uint8_t* out) {
   memcpy(out, s.f.v, 32);
 }
 
-// the MSM exactly as k_msm_accum + k_msm_tail(8,4) + k_msm_tail(8,32) compute it
+// the MSM exactly as k_to_table + k_msm_accw + k_msm_tail(8,4) + k_msm_tail(8,32) compute it
 void emul_msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
   const Aff* P = reinterpret_cast<const Aff*>(bases);
-  std::vector<Jac> bucket(512, Jac::identity());
+  std::vector<TJac> bucket(512, TJac::identity());
   std::vector<int8_t> dig(64);
   for (size_t i = 0; i < n; i++) {
     Fr k;
     memcpy(k.v, scalars + 32 * i, 32);
     k = fe_from_mont(k);
     recode_signed16(k.v, dig.data());
+    const TAff q = t_from_std(P[i]);                    // k_to_table
     for (int w = 0; w < 64; w++) {
       int d = dig[w];
       if (!d) continue;
       int mag = d < 0 ? -d : d;
-      Jac& b = bucket[w * 8 + mag - 1];
-      b = jac_add_mixed(b, aff_cneg(P[i], d < 0));
+      TJac& b = bucket[w * 8 + mag - 1];
+      b = t_add_mixed(b, t_cneg(q, d < 0));
     }
   }
-  Jac wsum[64];
+  TJac wsum[64];
   for (int w = 0; w < 64; w++) {
-    Jac run = Jac::identity(), tot = Jac::identity();
+    TJac run = TJac::identity(), tot = TJac::identity();
     for (int b = 7; b >= 0; b--) {
-      run = jac_add(run, bucket[w * 8 + b]);
-      tot = jac_add(tot, run);
+      run = t_add(run, bucket[w * 8 + b]);
+      tot = t_add(tot, run);
     }
     wsum[w] = tot;
   }
-  auto tail = [](const Jac* in, Jac* o, int nout, int group, int shift) {
+  auto tail = [](const TJac* in, TJac* o, int nout, int group, int shift) {
     for (int t = 0; t < nout; t++) {
-      const Jac* src = in + t * group;
-      Jac acc = src[group - 1];
+      const TJac* src = in + t * group;
+      TJac acc = src[group - 1];
       for (int j = group - 2; j >= 0; j--) {
-        for (int s = 0; s < shift; s++) acc = jac_dbl(acc);
-        acc = jac_add(acc, src[j]);
+        for (int s = 0; s < shift; s++) acc = t_dbl(acc);
+        acc = t_add(acc, src[j]);
       }
       o[t] = acc;
     }
   };
-  Jac part[8], res;
+  TJac part[8], res28;
   tail(wsum, part, 8, 8, 4);
-  tail(part, &res, 1, 8, 32);
+  tail(part, &res28, 1, 8, 32);
+  const Jac res = t_jac_to_std(res28);
   memcpy(out, &res, sizeof res);
 }
 
-// k_smul's per-element computation: (add ? add : O) + s*mul via NAF, Jacobian out
+// k_smul's per-element computation: (add ? add : O) + s*mul via NAF, Jacobian (standard form) out
 void emul_smul(const uint8_t* add, const uint8_t* mul, const uint8_t* scalar, uint8_t* out) {
   Fr k;
   memcpy(k.v, scalar, 32);
   k = fe_from_mont(k);
   uint32_t nz[9], ng[9];
   recode_naf(k.v, nz, ng);
-  Aff P;
-  memcpy(&P, mul, sizeof P);
-  Jac acc = Jac::identity();
+  Aff Ps;
+  memcpy(&Ps, mul, sizeof Ps);
+  const TAff P = t_from_std(Ps);
+  TJac acc = TJac::identity();
   for (int i = 256; i >= 0; i--) {
-    acc = jac_dbl(acc);
-    if ((nz[i >> 5] >> (i & 31)) & 1u) acc = jac_add_mixed(acc, aff_cneg(P, (ng[i >> 5] >> (i & 31)) & 1u));
+    acc = t_dbl(acc);
+    if ((nz[i >> 5] >> (i & 31)) & 1u) acc = t_add_mixed(acc, t_cneg(P, (ng[i >> 5] >> (i & 31)) & 1u));
   }
   if (add) {
     Aff A;
     memcpy(&A, add, sizeof A);
-    acc = jac_add_mixed(acc, A);
+    acc = t_add_mixed(acc, t_from_std(A));
   }
-  memcpy(out, &acc, sizeof acc);
+  const Jac r = t_jac_to_std(acc);
+  memcpy(out, &r, sizeof r);
 }
 
 void emul_compress(const uint8_t* aff, uint8_t* out) {

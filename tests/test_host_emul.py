@@ -17,7 +17,7 @@ FR, AFF, JAC = 32, 96, 144
 
 @pytest.fixture(scope="module")
 def emul():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp", "fp28.cuh", "g1_28.cuh")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp", "fp28.cuh", "g1_28.cuh", "tarith.cuh")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC])
     L = ctypes.CDLL(LIB)

@@ -1908,7 +1908,6 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
   std::vector<uint32_t> misc_idx;
   for (int q = SL_H; q <= SL_M; q++) misc_idx.push_back((uint32_t)q);
   for (int q = 0; q < NPP; q++) misc_idx.push_back((uint32_t)(SL_A + q));
-  const uint32_t* d_misc = idx_list(misc_idx);
   const size_t NM = misc_idx.size();
 
   parallel_for(B, [&](size_t p) {
@@ -2053,16 +2052,27 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
       at(sm.LU((int)j)) = a6 * s.gam_m[j];
       at(sm.RU((int)j)) = a6 * s.gam_m_inv[j];
     }
-    // SameScalar direct equalities (same_scalar_argument.rs:127-137), each as "... == O"
-    s.scal[3] = {S::one(), s.alpha_s, -s.z_t};             // cm_A.T_1 + alpha cm_T.T_1 - z_t G_t
-    s.scal[4] = {S::one(), s.alpha_s, -s.z_k, -s.z_t};     // cm_A.T_2 + alpha cm_T.T_2 - z_k R - z_t H
-    s.scal[5] = {S::one(), s.alpha_s, -s.z_u};             // cm_B.T_1 + alpha cm_U.T_1 - z_u G_u
-    s.scal[6] = {S::one(), s.alpha_s, -s.z_k, -s.z_u};     // cm_B.T_2 + alpha cm_U.T_2 - z_k S - z_u H
-    s.scal[7] = {S::one(), S::one(), S::one(), S::one()};  // combine the four partial sums
-    if (fused_partial) {
-      // fused mode: the four equalities join the accumulated MSM with their own random weights (factors 9..12)
-      const S w1 = S_from_wire(rand + (p * rand_stride + 8) * 32), w2 = S_from_wire(rand + (p * rand_stride + 9) * 32),
-              w3 = S_from_wire(rand + (p * rand_stride + 10) * 32), w4 = S_from_wire(rand + (p * rand_stride + 11) * 32);
+    // SameScalar equalities (same_scalar_argument.rs:127-137), each of the form "... == O":
+    //   cm_A.T_1 + alpha cm_T.T_1 - z_t G_t,   cm_A.T_2 + alpha cm_T.T_2 - z_k R - z_t H,
+    //   cm_B.T_1 + alpha cm_U.T_1 - z_u G_u,   cm_B.T_2 + alpha cm_U.T_2 - z_k S - z_u H
+    {
+      // The four equalities join the accumulated MSM with random weights of their own: factors 9..12 in fused mode;
+      // in per-proof mode the pairwise products a1 a2, a3 a4, a5 a6, a7 a8 of the caller's eight factors — the
+      // accumulated sum is then a polynomial of degree 2 in independent uniform factors whose coefficients are the
+      // individual check values, so it vanishes with probability <= 2/r unless every check holds (Schwartz-Zippel),
+      // the same argument that backs msm_accumulator.rs itself.
+      S w1, w2, w3, w4;
+      if (fused_partial) {
+        w1 = S_from_wire(rand + (p * rand_stride + 8) * 32);
+        w2 = S_from_wire(rand + (p * rand_stride + 9) * 32);
+        w3 = S_from_wire(rand + (p * rand_stride + 10) * 32);
+        w4 = S_from_wire(rand + (p * rand_stride + 11) * 32);
+      } else {
+        w1 = a1 * a2;
+        w2 = a3 * a4;
+        w3 = a5 * a6;
+        w4 = a7 * a8;
+      }
       at(sm.CMA1()) += w1;
       at(SL_CMT1) += w1 * s.alpha_s;
       at(SL_GT) += -(w1 * s.z_t);
@@ -2144,44 +2154,66 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     return;
   }
 
-  // -- V2: the accumulated MSM in four shards + the SameScalar equalities; V3: combine
+  // -- V2: the accumulated check of every proof as ONE sum: the CRS part on the fixed-base table (k_msm_fix), all the
+  //    per-proof points (R | S | T | U and the slots) in one bucket MSM (k_msm_accw); the Horner tail adds the two.
   {
-    const uint32_t* e1 = idx_list({(uint32_t)sm.CMA1(), (uint32_t)SL_CMT1, (uint32_t)SL_GT});
-    const uint32_t* e2 = idx_list({(uint32_t)sm.CMA2(), (uint32_t)SL_CMT2, (uint32_t)SL_R, (uint32_t)SL_H});
-    const uint32_t* e3 = idx_list({(uint32_t)sm.CMB1(), (uint32_t)SL_CMU1, (uint32_t)SL_GU});
-    const uint32_t* e4 = idx_list({(uint32_t)sm.CMB2(), (uint32_t)SL_CMU2, (uint32_t)SL_S, (uint32_t)SL_H});
-    const uint32_t* ecomb = idx_list({(uint32_t)sm.TMP(0), (uint32_t)sm.TMP(1), (uint32_t)sm.TMP(2), (uint32_t)sm.TMP(3)});
-    const bool fix_crs = fix_bits_ && fixtab() && use_tables_;
-    std::vector<MsmReq> reqs;
+    if (!(fix_bits_ && fixtab() && use_tables_)) throw std::logic_error("verification needs the fixed-base CRS table");
+    const size_t NI = 4 * ell, NPT = NI + NM;
+    std::vector<uint32_t> all_idx(NPT);   // row-relative gather list: instance vectors, then the slots of the misc part
+    for (size_t i = 0; i < NI; i++) all_idx[i] = (uint32_t)i;
+    for (size_t j = 0; j < NM; j++) all_idx[NI + j] = (uint32_t)(NI + misc_idx[j]);
+    const uint32_t* d_all = idx_list(all_idx);
+    const int fix_wpw = msm_fix_windows_per_wave((int)B, fix_bits_);
+    const int fix_parts = 256 / fix_bits_ / fix_wpw;
+    const size_t total = B * (NPT + n);
+    d_scal_.ensure(total);
+    d_tasks_.ensure(B);
+    d_ftasks_.ensure(B);
+    d_conv_.ensure(B * NPT);
+    d_wsum_.ensure(B * 64);
+    d_part_.ensure(B * 8);
+    d_tpart_.ensure(B * (size_t)fix_parts);
+    d_res_.ensure(B);
+    d_comp_.ensure(B * 48);
+    const size_t b_scal = total * sizeof(Fr), b_mt = B * sizeof(MsmTask), b_ft = B * sizeof(FixTask);
+    h_stage_.ensure(b_scal + b_mt + b_ft);
+    Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
+    MsmTask* hm = reinterpret_cast<MsmTask*>(h_stage_.p + b_scal);
+    FixTask* hf = reinterpret_cast<FixTask*>(h_stage_.p + b_scal + b_mt);
+    parallel_for(B, [&](size_t p) {
+      const VState& s = st[p];
+      Fr* d = hs + p * (NPT + n);
+      for (size_t i = 0; i < NI; i++) d[i] = s.scal[1][i].f;
+      for (size_t j = 0; j < NM; j++) d[NI + j] = s.scal[2][j].f;
+      for (size_t i = 0; i < n; i++) d[NPT + i] = s.scal[0][i].f;
+      hm[p] = MsmTask{pp(p), d_all, d_scal_.p + p * (NPT + n), (uint32_t)NPT, 0, (uint32_t)(p * NPT)};
+      hf[p] = FixTask{nullptr, d_scal_.p + p * (NPT + n) + NPT, 0, (uint32_t)n, 0, (uint32_t)(p * fix_parts)};
+    });
+    CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_tasks_.p, hm, b_mt, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
+    tick(fix_bits_ == 16 ? (fix_wpw == 16 ? "k_msm_fix<16, 16>" : "k_msm_fix<16, 8>") : (fix_wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>"), 128.0 * n * B,
+         (double)(n * B));
+    launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)(n_ + 3), d_tpart_.p, stream_);
+    tock();
+    tick("k_msm_accw", 128.0 * NPT * B, (double)(NPT * B));
+    launch_msm_accum(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_wsum_.p, stream_);
+    tock();
+    tick("k_msm_tail", 0, (double)B * 8);
+    launch_msm_tail(d_wsum_.p, d_part_.p, nullptr, (int)B * 8, 8, 4, stream_);
+    tock();
+    tick("k_msm_tail", 0, (double)B);
+    launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)B, 8, 32, stream_, d_tpart_.p, fix_parts);
+    tock();
+    tick("k_finalize", 0, (double)B);
+    launch_finalize(d_res_.p, (int)B, nullptr, nullptr, d_comp_.p, stream_);
+    tock();
+    h_comp_.ensure(B * 48);
+    CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
+    wait_stream();
     for (size_t p = 0; p < B; p++) {
-      VState& s = st[p];
-      if (!fix_crs) reqs.push_back({d_crs_.p, nullptr, s.scal[0].data(), (uint32_t)n, slot_index(p, sm.TMP(0))});
-      reqs.push_back({pp(p), nullptr, s.scal[1].data(), (uint32_t)(2 * ell), slot_index(p, sm.TMP(1))});
-      reqs.push_back({pp(p) + 2 * ell, nullptr, s.scal[1].data() + 2 * ell, (uint32_t)(2 * ell), slot_index(p, sm.TMP(2))});
-      reqs.push_back({slot(p, 0), d_misc, s.scal[2].data(), (uint32_t)NM, slot_index(p, sm.TMP(3))});
-      reqs.push_back({slot(p, 0), e1, s.scal[3].data(), 3, slot_index(p, sm.TMP(4))});
-      reqs.push_back({slot(p, 0), e2, s.scal[4].data(), 4, slot_index(p, sm.TMP(5))});
-      reqs.push_back({slot(p, 0), e3, s.scal[5].data(), 3, slot_index(p, sm.TMP(6))});
-      reqs.push_back({slot(p, 0), e4, s.scal[6].data(), 4, slot_index(p, sm.TMP(7))});
-    }
-    if (fix_crs) {   // CRS shard of the accumulated check on the fixed-base table (no buckets, no tail)
-      std::vector<TblReq> treqs;
-      const TblSeg none{nullptr, nullptr, 0, 0};
-      for (size_t p = 0; p < B; p++) treqs.push_back({cseg(0, (uint32_t)n), st[p].scal[0].data(), none, nullptr, slot_index(p, sm.TMP(0))});
-      std::vector<uint8_t> unused;
-      run_tbl_phase(treqs, &unused);   // synchronises: the staging buffers are reused by the next phase
-    }
-    std::vector<uint8_t> comp2;
-    run_msm_phase(reqs, &comp2);
-    std::vector<MsmReq> reqs3;
-    for (size_t p = 0; p < B; p++) reqs3.push_back({slot(p, 0), ecomb, st[p].scal[7].data(), 4, slot_index(p, sm.TMP(0))});
-    std::vector<uint8_t> comp3;
-    run_msm_phase(reqs3, &comp3);
-    for (size_t p = 0; p < B; p++) {
-      VState& s = st[p];
-      bool ok = comp3[p * 48] == ID0;
-      const size_t per = fix_crs ? 7 : 8, first_eq = fix_crs ? 3 : 4;
-      for (size_t e = first_eq; e < per; e++) ok = ok && comp2[(p * per + e) * 48] == ID0;
+      const VState& s = st[p];
+      const bool ok = h_comp_.p[p * 48] == ID0;
       verdict[p] = s.bad ? CPX_ERR_DESERIALIZE : ((s.reject || !ok) ? CPX_ERR_VERIFY : CPX_OK);
     }
   }

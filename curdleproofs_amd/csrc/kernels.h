@@ -90,7 +90,9 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
 void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TJac* d_wsum, hipStream_t s);
 // ... then Horner tails: out[t] = sum_{j<group} 2^(shift*j) in[t*group+j]; (8,4) then (8,32) gives the MSM results.
 // Exactly one of d_out (table representation) / d_out_std (standard form, last stage) is non-null.
-void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s);
+// d_extra (optional): extra_per_out further partial sums added to output t before it is written
+void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra = nullptr,
+                     int extra_per_out = 0);
 // Jacobian -> affine (+ optional scatter through dst_index) and optional 48-byte compressed form.
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
 // `batch` rows of n points, row r starting at d_in + r*stride; output dense [batch][n][48]

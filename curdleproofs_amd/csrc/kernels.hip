@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src
 // out[t] = sum_{j < group} 2^(shift*j) in[t*group + j], one lane per output; the last stage hands the result
 // over in the standard form.
 template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const TJac* __restrict__ in, TJac* __restrict__ out, Jac* __restrict__ out_std, int nout,
-                                                                         int group, int shift) {
+                                                                         int group, int shift, const TJac* __restrict__ extra, int extra_per_out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nout) return;
   const TJac* src = in + (size_t)t * group;
@@ -534,6 +534,7 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const T
     for (int s = 0; s < shift; s++) acc = t_dbl(acc);
     acc = t_add(acc, src[j]);
   }
+  for (int j = 0; j < extra_per_out; j++) acc = t_add(acc, extra[(size_t)t * extra_per_out + j]);   // e.g. fixed-base partial sums
   if (STD_OUT) out_std[t] = t_jac_to_std(acc);
   else out[t] = acc;
 }
@@ -812,10 +813,10 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_con
   }
   CPX_LAUNCH(k_msm_accw, dim3(ntasks * 8), dim3(64), ACW_LDS, s, d_tasks, d_conv, d_wsum);
 }
-void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s) {
+void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra, int extra_per_out) {
   if (nout <= 0) return;
-  if (d_out_std) CPX_LAUNCH(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift);
-  else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift);
+  if (d_out_std) CPX_LAUNCH(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out);
+  else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out);
 }
 int msm_tblw_windows_per_wave(int ntasks) {
   // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2)

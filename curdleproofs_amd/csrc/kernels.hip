@@ -1,23 +1,26 @@
 // gfx950 (MI355X / CDNA4) kernels for the Curdleproofs G1 hot path.
 //
 // Replaces, behind include/cpx.h, the arithmetic the reference reaches through
-//   util::msm                       /root/reference/src/util.rs:19-22            -> k_msm_accum + k_msm_tail
+//   util::msm                       /root/reference/src/util.rs:19-22             -> k_to_table + k_msm_accw + k_msm_tail
+//   the commitments and log-round cross terms of the prover (all MSMs over fixed bases in the batch engine)
+//                                   inner_product_argument.rs:126-127,158-161,
+//                                   same_multiscalar_argument.rs:80-82,107-112 ...  -> k_msm_fix (CRS), k_msm_tblw (per-proof tables)
 //   IPA / SameMSM basis folds       inner_product_argument.rs:174-179,
-//                                   same_multiscalar_argument.rs:126-131           -> k_smul (add operand set)
+//                                   same_multiscalar_argument.rs:126-131            -> k_smul (add operand set; tier 0)
 //   G' rescale / shuffle scaling    grand_product_argument.rs:90-102, util.rs:94-95 -> k_smul (no add operand)
-//   into_affine / normalize_batch + compressed serialisation                       -> k_finalize
+//   into_affine / normalize_batch + compressed serialisation                        -> k_finalize, k_finalize_ranges, k_compress
+//   deserialize_compressed (Validate::Yes)                                          -> k_decompress
+//   MsmAccumulator shared by many proofs (BASELINE config 5)                        -> launch_big_msm
 //
-// Integer big-number work on the 32-bit VALU (v_mad_u64_u32 chains); no MFMA — there is no dense
-// contraction here.  Design notes:
-//  * wave = 64 lanes; MSM work-group = 512 threads = 64 windows x 8 signed-digit buckets, so every
-//    lane owns exactly one Pippenger bucket in registers (36 VGPRs) and walks the window's digit row
-//    in LDS; the points of the current chunk are staged once in LDS and shared by all 64 windows.
-//  * the long doubling chain that combines windows is split out of the bucket kernel into
-//    k_msm_tail, one *lane* per partial Horner evaluation, so that lanes stay busy across the many
-//    independent MSMs of a proof batch instead of one lane per work-group idling 511 others.
-//  * per-element scalar multiplications share the scalar across a whole wave in the fold case, so
-//    the NAF-driven add branch is wave-uniform; the Jacobian results are normalised with one Fp
-//    inversion per work-group (LDS product scans) instead of the reference's one inversion per point.
+// Integer big-number work on the VALU; no MFMA — there is no dense contraction here.  Design notes:
+//  * every group operation runs on the carry-free 28-bit-limb "table form" (fp28.cuh / g1_28.cuh / tarith.cuh);
+//    points enter a kernel through t_from_std and leave through t_to_std / t_jac_to_std;
+//  * MSM work-groups are single waves (no inter-wave barriers): lanes own buckets in registers and walk digit rows
+//    staged in LDS, points are gathered from HBM/L2 tables;
+//  * the long doubling chain that combines the windows of a bucket MSM is split out into k_msm_tail, one *lane* per
+//    partial Horner evaluation, so that lanes stay busy across the many independent MSMs of a proof batch;
+//  * Jacobian results are normalised with one inversion per work-group (LDS product scans + binary Euclid on one
+//    wave) instead of the reference's one inversion per point.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <hip/hip_ext.h>

@@ -62,7 +62,7 @@ Engine::Engine(int device) : device_(device) {
   if (const char* e = getenv("CPX_PROVER")) use_tables_ = std::string(e) != "fold";
   if (const char* e = getenv("CPX_FIX_BITS")) {
     int c = atoi(e);
-    if (c == 0 || c == 8 || c == 16) fix_bits_ = c;
+    if (c == 8 || c == 16) fix_bits_ = c;   // radix of the fixed-base CRS table (8: 0.1 GB, 16: 15 GB at ell = 252)
   }
 }
 Engine::~Engine() {
@@ -521,7 +521,7 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
     static std::vector<std::weak_ptr<CrsTables>> registry;
     std::lock_guard<std::mutex> lk(reg_mu);
     const size_t NC = n + 3;
-    const int want_fix = use_tables_ ? fix_bits_ : 0;
+    const int want_fix = fix_bits_;   // the verifier needs the table whichever prover is selected
     std::vector<uint8_t> key(points, points + (ell + 7) * sizeof(Aff));
     crs_tab_.reset();
     for (auto it = registry.begin(); it != registry.end();) {
@@ -2092,7 +2092,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
 
   if (fused_partial) {
     // ---- one MSM over the CRS (scalars summed over the proofs, fixed-base table) and B * (4 ell + NM) per-proof points ----
-    if (!(fix_bits_ && fixtab() && use_tables_)) throw std::logic_error("fused verification needs the fixed-base CRS table");
+    if (!fixtab()) throw std::logic_error("set_crs first");
     const size_t NI = 4 * ell, NPT = NI + NM, N = B * NPT;
     int invalid = 0;
     for (size_t p = 0; p < B; p++) invalid += (st[p].bad || st[p].reject) ? 1 : 0;
@@ -2157,7 +2157,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
   // -- V2: the accumulated check of every proof as ONE sum: the CRS part on the fixed-base table (k_msm_fix), all the
   //    per-proof points (R | S | T | U and the slots) in one bucket MSM (k_msm_accw); the Horner tail adds the two.
   {
-    if (!(fix_bits_ && fixtab() && use_tables_)) throw std::logic_error("verification needs the fixed-base CRS table");
+    if (!fixtab()) throw std::logic_error("set_crs first");
     const size_t NI = 4 * ell, NPT = NI + NM;
     std::vector<uint32_t> all_idx(NPT);   // row-relative gather list: instance vectors, then the slots of the misc part
     for (size_t i = 0; i < NI; i++) all_idx[i] = (uint32_t)i;

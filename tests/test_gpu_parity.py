@@ -409,3 +409,15 @@ def test_fused_batch_verifier_window_plans(window):
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "test_fused_batch_verifier_config5"],
                        env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [{"CPX_PROVER": "fold"}, {"CPX_FIX_BITS": "8"}])
+def test_engine_variants_stay_bit_exact(env):
+    # the reference-shaped fold prover (basis folds + shrinking MSMs) and the 8-bit fixed-base table are alternative
+    # engine configurations; both must reproduce the reference KAT and the oracle's verdicts
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_prove_matches_reference_kat_ell124 or test_verify_rejects_mutated_instances or test_fused_batch_verifier_config5"],
+                       env=dict(os.environ, **env), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -45,6 +45,16 @@ void emul_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
     memcpy(out + 32 * i, z.v, 32);
   }
 }
+// the host engine's own Fr product (64-bit limbs, host_math.hpp)
+void emul_host_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    host::S x, y;
+    memcpy(x.f.v, a + 32 * i, 32);
+    memcpy(y.f.v, b + 32 * i, 32);
+    const host::S z = x * y;
+    memcpy(out + 32 * i, z.f.v, 32);
+  }
+}
 void emul_fr_inv(const uint8_t* a, uint8_t* out) {
   host::S s;
   memcpy(s.f.v, a, 32);

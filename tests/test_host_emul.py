@@ -24,6 +24,7 @@ def emul():
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     L.emul_fp_mul.argtypes = [vp, vp, vp, sz]
     L.emul_fr_mul.argtypes = [vp, vp, vp, sz]
+    L.emul_host_fr_mul.argtypes = [vp, vp, vp, sz]
     L.emul_msm.argtypes = [vp, vp, sz, vp]
     L.emul_smul.argtypes = [vp, vp, vp, vp]
     L.emul_challenges.argtypes = [vp, sz, vp]
@@ -216,3 +217,14 @@ def test_euclid_inversion_matches_fermat(emul, orc):
         r = _o(96)
         assert emul.emul_inv_euclid(_b(_to_mont(x)), r) == 1
         assert _from_mont(bytes(r)[:48]) == pow(x, -1, P) == _from_mont(bytes(r)[48:])
+
+
+def test_host_fr_product(emul, orc):
+    """host_math.hpp fr64::mul (the engine's Fr algebra) vs the oracle, incl. operands near r"""
+    R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    edge = [orc.fr_from_canonical_bytes(v.to_bytes(32, "little")) for v in (0, 1, 2, R_ - 1, R_ - 2, (R_ - 1) // 2, 1 << 254, (1 << 254) + 12345)]
+    s = orc.rng(15).fr(200) + b"".join(edge)
+    t = b"".join(edge) + orc.rng(16).fr(200)
+    o = _o(len(s))
+    emul.emul_host_fr_mul(_b(s), _b(t), o, len(s) // 32)
+    assert bytes(o) == orc.fr_mul(s, t)

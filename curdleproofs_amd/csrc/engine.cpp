@@ -70,6 +70,7 @@ Engine::~Engine() {
   baton_register(-1);
   for (auto p : idx_allocs_) (void)hipFree(p);
   if (side_.ev) (void)hipEventDestroy(side_.ev);
+  if (side_.ev2) (void)hipEventDestroy(side_.ev2);
   if (side_.stream) (void)hipStreamDestroy(side_.stream);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -254,6 +255,33 @@ void Engine::wait_stream() {
   {
     HostSpan w(this, "host_wait_device");
     CPX_HIP(hipStreamSynchronize(stream_));
+  }
+  if (had) baton_acquire();
+}
+
+// Transcript prefix of every loaded proof on the side stream (after the main stream has produced d_bytes_ / d_mcomp_):
+// k_transcript_step1, then the copies the host needs (state, vec_a, compressed instance vectors, compressed M).
+void Engine::transcript_prefix_async(size_t B) {
+  d_tstate_.ensure(B * 27);
+  d_veca_.ensure(B * ell_);
+  h_tstate_.ensure(B * 27);
+  h_veca_.ensure(B * ell_);
+  if (!side_.ev2) CPX_HIP(hipEventCreateWithFlags(&side_.ev2, hipEventDisableTiming));
+  CPX_HIP(hipEventRecord(side_.ev2, stream_));
+  CPX_HIP(hipStreamWaitEvent(side_.stream, side_.ev2, 0));
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, (int)B, (int)ell_, d_tstate_.p, d_veca_.p, side_.stream);
+  CPX_HIP(hipMemcpyAsync(h_tstate_.p, d_tstate_.p, B * 27 * sizeof(uint64_t), hipMemcpyDeviceToHost, side_.stream));
+  CPX_HIP(hipMemcpyAsync(h_veca_.p, d_veca_.p, B * ell_ * sizeof(Fr), hipMemcpyDeviceToHost, side_.stream));
+  CPX_HIP(hipMemcpyAsync(h_inst_comp_.p, d_bytes_.p, B * 4 * ell_ * 48, hipMemcpyDeviceToHost, side_.stream));
+  CPX_HIP(hipMemcpyAsync(h_mcomp_.p, d_mcomp_.p, B * 48, hipMemcpyDeviceToHost, side_.stream));
+  CPX_HIP(hipEventRecord(side_.ev, side_.stream));
+}
+void Engine::wait_side() {
+  const bool had = baton_held_;
+  baton_release();
+  {
+    HostSpan w(this, "host_wait_device");
+    CPX_HIP(hipEventSynchronize(side_.ev));
   }
   if (had) baton_acquire();
 }
@@ -1290,38 +1318,37 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   const uint32_t* iAp = idx_list(ap);
   const TblSeg none{nullptr, nullptr, 0, 0};
 
-  // -- P0: compressed instance vectors, M -> affine (into table slot 0), then the per-proof tables
+  // -- P0: compressed instance vectors, M -> affine (into table slot 0), then the per-proof tables.  The transcript
+  //    prefix (instance + M absorbed, vec_a drawn) is hashed on the side stream while the tables are built.
   h_inst_comp_.ensure(B * 4 * ell * 48);   // pinned and persistent: no page faults, true async copies
   h_mcomp_.ensure(B * 48);
   h_u32_.ensure(B);
   const uint8_t* inst_comp = h_inst_comp_.p;
   {
     d_bytes_.ensure(B * 4 * ell * 48);
-      tick("k_compress", 0, (double)(4 * ell * B));
+    tick("k_compress", 0, (double)(4 * ell * B));
     launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
     tock();
     d_dst_.ensure(B);
-    d_comp_.ensure(B * 48);
+    d_mcomp_.ensure(B * 48);
     uint32_t* dst = h_u32_.p;
     for (size_t p = 0; p < B; p++) dst[p] = (uint32_t)(p * NP + O_M);
     CPX_HIP(hipMemcpyAsync(d_dst_.p, dst, B * 4, hipMemcpyHostToDevice, stream_));
-    launch_finalize(d_Mjac_.p, (int)B, d_psrc_.p, d_dst_.p, d_comp_.p, stream_);
+    launch_finalize(d_Mjac_.p, (int)B, d_psrc_.p, d_dst_.p, d_mcomp_.p, stream_);
+    transcript_prefix_async(B);   // side stream: k_transcript_step1 + copies of its outputs and of the compressed bytes
     tick("k_table_build", 0, (double)(B * NP));
     launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, d_tbltmp_.p, stream_);
     tock();
     const uint8_t* mcomp = h_mcomp_.p;
-    CPX_HIP(hipMemcpyAsync(h_inst_comp_.p, d_bytes_.p, B * 4 * ell * 48, hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipMemcpyAsync(h_mcomp_.p, d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
-    wait_stream();
+    wait_side();
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       s.rnd = rand + p * nrand * 32;
       s.comp.assign((size_t)NS * 48, 0);
       memcpy(&s.comp[SL_M * 48], &mcomp[p * 48], 48);
-      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
-      for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
-      s.tr.append_point_bytes("curdleproofs_step1", &s.comp[SL_M * 48]);
-      s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
+      s.tr.load_state(h_tstate_.p + p * 27);
+      s.vec_a.resize(ell);
+      memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
       const uint32_t* perm = permutation + p * ell;
       s.a_perm.resize(ell);
       for (size_t i = 0; i < ell; i++) s.a_perm[i] = s.vec_a[perm[i]];
@@ -1840,13 +1867,14 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     d_comp_.ensure(B * 48);
     uint32_t* mdst = h_u32_.p + npts;
     for (size_t p = 0; p < B; p++) mdst[p] = slot_index(p, SL_M);
+    d_mcomp_.ensure(B * 48);
     CPX_HIP(hipMemcpyAsync(d_dst_.p, mdst, B * 4, hipMemcpyHostToDevice, stream_));
-    launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
+    launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_mcomp_.p, stream_);
+    transcript_prefix_async(B);   // side stream: transcript prefix + copies of the compressed bytes
     const uint8_t* status = h_status_.p;
     CPX_HIP(hipMemcpyAsync(h_status_.p, d_status_.p, npts, hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipMemcpyAsync(h_inst_comp_.p, d_bytes_.p, B * 4 * ell * 48, hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipMemcpyAsync(h_mcomp_.p, d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
     wait_stream();
+    wait_side();
     for (size_t p = 0; p < B; p++)
       for (int q = 0; q < NPP; q++)
         if (status[p * NPP + q]) st[p].bad = true;
@@ -1868,9 +1896,9 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
     // curdleproofs.rs:218: the randomiser must not have wiped the ciphertexts
     if (ic[2 * ell * 48] == ID0) s.reject = true;
-    for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
-    s.tr.append_point_bytes("curdleproofs_step1", &mcomp[p * 48]);
-    s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
+    s.tr.load_state(h_tstate_.p + p * 27);   // instance + M absorbed, vec_a drawn: hashed on the device (k_transcript_step1)
+    s.vec_a.resize(ell);
+    memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
     // same_permutation_argument.rs:131-145
     s.tr.append_point_bytes("same_perm_step1", P(SL_A));
     s.tr.append_point_bytes("same_perm_step1", &mcomp[p * 48]);

@@ -159,7 +159,7 @@ class Engine {
   // second stream + private staging for work that is off the critical path of the phase sequence
   struct SideBufs {
     hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr, ev2 = nullptr;
     DevBuf<MsmTask> tasks;
     DevBuf<SmulTask> stasks;
     DevBuf<Fr> scal;
@@ -197,6 +197,8 @@ class Engine {
     std::chrono::steady_clock::time_point t0_;
   };
   void wait_stream();
+  void wait_side();                          // blocks on the side stream's event (side_.ev)
+  void transcript_prefix_async(size_t B);
   // per-device host baton between engines (engine.cpp)
   void baton_register(int delta);
   void baton_acquire();
@@ -278,6 +280,11 @@ class Engine {
   PinBuf<uint8_t> h_comp_;
   PinBuf<uint8_t> h_inst_comp_, h_mcomp_, h_pts_, h_status_;   // compressed instance vectors / M, proof points in, decompression status
   PinBuf<uint32_t> h_u32_;
+  DevBuf<uint8_t> d_mcomp_;                 // compressed M of every proof
+  DevBuf<uint64_t> d_tstate_;               // transcript states after the prefix [B][27]
+  DevBuf<Fr> d_veca_;                       // vec_a [B][ell]
+  PinBuf<uint64_t> h_tstate_;
+  PinBuf<Fr> h_veca_;
   DevBuf<uint8_t> d_vin_;
   DevBuf<uint32_t> d_vdst_;
   std::map<std::vector<uint32_t>, uint32_t*> idx_cache_;

@@ -110,6 +110,9 @@ struct BigMsmPlan {
 BigMsmPlan big_msm_plan(size_t n);
 void launch_big_msm(const BigMsmPlan& p, const Aff* d_pp, const uint32_t* d_idx, const Fr* d_scalars, size_t n, TAff* d_conv, uint32_t* d_keys,
                     uint32_t* d_vals, void* d_sort_temp, uint32_t* d_bounds, TJac* d_buckets, const TJac* d_extra, int nextra, Jac* d_out, hipStream_t s);
+// transcript prefix of every proof: absorbs the compressed instance ([nproofs][4*ell*48] + [nproofs][48] for M), draws vec_a;
+// d_state: [nproofs][27] u64 (25 STROBE lanes, pos, pos_begin), d_vec_a: [nproofs][ell] Fr
+void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s);
 void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s);
 void launch_bench_fpmul(Fp* d_data, int blocks, int iters, hipStream_t s);
 void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s);

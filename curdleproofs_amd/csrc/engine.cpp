@@ -261,6 +261,15 @@ void Engine::wait_stream() {
 
 // Transcript prefix of every loaded proof on the side stream (after the main stream has produced d_bytes_ / d_mcomp_):
 // k_transcript_step1, then the copies the host needs (state, vec_a, compressed instance vectors, compressed M).
+// Small batches hash on the host instead (device_prefix(B) false): a lone transcript is latency-bound on the GPU
+// (~4 us per permutation) while the host has idle cores (~0.25 us per permutation).
+bool Engine::device_prefix(size_t B) const {
+  static const size_t min_batch = [] {
+    const char* e = getenv("CPX_DEVICE_TRANSCRIPT_MIN_BATCH");
+    return e ? (size_t)atol(e) : (size_t)32;
+  }();
+  return B >= min_batch;
+}
 void Engine::transcript_prefix_async(size_t B) {
   d_tstate_.ensure(B * 27);
   d_veca_.ensure(B * ell_);
@@ -269,9 +278,11 @@ void Engine::transcript_prefix_async(size_t B) {
   if (!side_.ev2) CPX_HIP(hipEventCreateWithFlags(&side_.ev2, hipEventDisableTiming));
   CPX_HIP(hipEventRecord(side_.ev2, stream_));
   CPX_HIP(hipStreamWaitEvent(side_.stream, side_.ev2, 0));
-  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, (int)B, (int)ell_, d_tstate_.p, d_veca_.p, side_.stream);
-  CPX_HIP(hipMemcpyAsync(h_tstate_.p, d_tstate_.p, B * 27 * sizeof(uint64_t), hipMemcpyDeviceToHost, side_.stream));
-  CPX_HIP(hipMemcpyAsync(h_veca_.p, d_veca_.p, B * ell_ * sizeof(Fr), hipMemcpyDeviceToHost, side_.stream));
+  if (device_prefix(B)) {
+    launch_transcript_step1(d_bytes_.p, d_mcomp_.p, (int)B, (int)ell_, d_tstate_.p, d_veca_.p, side_.stream);
+    CPX_HIP(hipMemcpyAsync(h_tstate_.p, d_tstate_.p, B * 27 * sizeof(uint64_t), hipMemcpyDeviceToHost, side_.stream));
+    CPX_HIP(hipMemcpyAsync(h_veca_.p, d_veca_.p, B * ell_ * sizeof(Fr), hipMemcpyDeviceToHost, side_.stream));
+  }
   CPX_HIP(hipMemcpyAsync(h_inst_comp_.p, d_bytes_.p, B * 4 * ell_ * 48, hipMemcpyDeviceToHost, side_.stream));
   CPX_HIP(hipMemcpyAsync(h_mcomp_.p, d_mcomp_.p, B * 48, hipMemcpyDeviceToHost, side_.stream));
   CPX_HIP(hipEventRecord(side_.ev, side_.stream));
@@ -1340,15 +1351,23 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, d_tbltmp_.p, stream_);
     tock();
     const uint8_t* mcomp = h_mcomp_.p;
+    const bool dev_prefix = device_prefix(B);
     wait_side();
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       s.rnd = rand + p * nrand * 32;
       s.comp.assign((size_t)NS * 48, 0);
       memcpy(&s.comp[SL_M * 48], &mcomp[p * 48], 48);
-      s.tr.load_state(h_tstate_.p + p * 27);
-      s.vec_a.resize(ell);
-      memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
+      if (dev_prefix) {   // instance + M absorbed, vec_a drawn: hashed on the device (k_transcript_step1)
+        s.tr.load_state(h_tstate_.p + p * 27);
+        s.vec_a.resize(ell);
+        memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
+      } else {
+        const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
+        for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
+        s.tr.append_point_bytes("curdleproofs_step1", &s.comp[SL_M * 48]);
+        s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
+      }
       const uint32_t* perm = permutation + p * ell;
       s.a_perm.resize(ell);
       for (size_t i = 0; i < ell; i++) s.a_perm[i] = s.vec_a[perm[i]];
@@ -1884,6 +1903,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
   std::vector<uint8_t> comp;
 
   // -- V1a: transcript up to the grand-product beta
+  const bool dev_prefix = device_prefix(B);
   parallel_for(B, [&](size_t p) {
     VState& s = st[p];
     s.pb = proofs + p * psz;
@@ -1896,9 +1916,15 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
     // curdleproofs.rs:218: the randomiser must not have wiped the ciphertexts
     if (ic[2 * ell * 48] == ID0) s.reject = true;
-    s.tr.load_state(h_tstate_.p + p * 27);   // instance + M absorbed, vec_a drawn: hashed on the device (k_transcript_step1)
-    s.vec_a.resize(ell);
-    memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
+    if (dev_prefix) {   // instance + M absorbed, vec_a drawn: hashed on the device (k_transcript_step1)
+      s.tr.load_state(h_tstate_.p + p * 27);
+      s.vec_a.resize(ell);
+      memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
+    } else {
+      for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
+      s.tr.append_point_bytes("curdleproofs_step1", &mcomp[p * 48]);
+      s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
+    }
     // same_permutation_argument.rs:131-145
     s.tr.append_point_bytes("same_perm_step1", P(SL_A));
     s.tr.append_point_bytes("same_perm_step1", &mcomp[p * 48]);

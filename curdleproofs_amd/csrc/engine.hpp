@@ -199,6 +199,7 @@ class Engine {
   void wait_stream();
   void wait_side();                          // blocks on the side stream's event (side_.ev)
   void transcript_prefix_async(size_t B);
+  bool device_prefix(size_t B) const;         // hash the transcript prefix on the GPU (large batches) or on the host
   // per-device host baton between engines (engine.cpp)
   void baton_register(int delta);
   void baton_acquire();

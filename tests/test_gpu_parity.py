@@ -411,10 +411,11 @@ def test_fused_batch_verifier_window_plans(window):
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"CPX_PROVER": "fold"}, {"CPX_FIX_BITS": "8"}])
+@pytest.mark.parametrize("env", [{"CPX_PROVER": "fold"}, {"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_TRANSCRIPT_MIN_BATCH": "1"}])
 def test_engine_variants_stay_bit_exact(env):
-    # the reference-shaped fold prover (basis folds + shrinking MSMs) and the 8-bit fixed-base table are alternative
-    # engine configurations; both must reproduce the reference KAT and the oracle's verdicts
+    # the reference-shaped fold prover (basis folds + shrinking MSMs), the 8-bit fixed-base table and the device-side
+    # transcript prefix (k_transcript_step1, normally used from 32 proofs per batch on) are alternative engine
+    # configurations; all must reproduce the reference KAT and the oracle's verdicts
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",

@@ -414,7 +414,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   for (size_t i = 0; i < nt; i++) {
     const TblReq& r = reqs[i];
     soff[i] = total;
-    total += r.seg0.n + r.seg1.n;
+    if (!r.dev) total += r.seg0.n + r.seg1.n;
     pfirst[i] = (uint32_t)nparts;
     const bool f0 = is_crs(r.seg0), f1 = is_crs(r.seg1);
     if (needs_tbl(r)) {
@@ -451,9 +451,12 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   const TblSeg none{nullptr, nullptr, 0, 0};
   parallel_for(nt, [&](size_t i) {
     const TblReq& r = reqs[i];
-    Fr* d = hs + soff[i];
-    for (uint32_t j = 0; j < r.seg0.n; j++) d[j] = r.s0[j].f;
-    for (uint32_t j = 0; j < r.seg1.n; j++) d[r.seg0.n + j] = r.s1[j].f;
+    const Fr* sbase = r.dev ? r.dev : d_scal_.p + soff[i];   // where this request's scalars are (or will be) on the device
+    if (!r.dev) {
+      Fr* d = hs + soff[i];
+      for (uint32_t j = 0; j < r.seg0.n; j++) d[j] = r.s0[j].f;
+      for (uint32_t j = 0; j < r.seg1.n; j++) d[r.seg0.n + j] = r.s1[j].f;
+    }
     const bool f0 = is_crs(r.seg0), f1 = is_crs(r.seg1);
     uint32_t slot = pfirst[i];
     if (tt_index[i] != ~0u) {
@@ -461,7 +464,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
       // the shifted-table task keeps the scalar layout of the request; fixed-base segments are emptied
       t.seg[0] = f0 ? TblSeg{r.seg0.base, r.seg0.idx, r.seg0.copy_stride, 0} : r.seg0;
       t.seg[1] = f1 ? none : r.seg1;
-      t.scalars = d_scal_.p + soff[i] + (f0 ? r.seg0.n : 0);
+      t.scalars = sbase + (f0 ? r.seg0.n : 0);
       if (f0) {   // seg0 removed: its scalars are skipped, seg1 becomes the only segment
         t.seg[0] = f1 ? none : r.seg1;
         t.seg[1] = none;
@@ -472,18 +475,18 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
       slot += tbl_parts;
     }
     if (f0) {
-      hf[ft_index[2 * i]] = FixTask{r.seg0.idx, d_scal_.p + soff[i], (uint32_t)(r.seg0.base - c_lo), r.seg0.n, 0, slot};
+      hf[ft_index[2 * i]] = FixTask{r.seg0.idx, sbase, (uint32_t)(r.seg0.base - c_lo), r.seg0.n, 0, slot};
       slot += fix_parts;
     }
     if (f1) {
-      hf[ft_index[2 * i + 1]] = FixTask{r.seg1.idx, d_scal_.p + soff[i] + r.seg0.n, (uint32_t)(r.seg1.base - c_lo), r.seg1.n, 0, slot};
+      hf[ft_index[2 * i + 1]] = FixTask{r.seg1.idx, sbase + r.seg0.n, (uint32_t)(r.seg1.base - c_lo), r.seg1.n, 0, slot};
       slot += fix_parts;
     }
     hp[i] = pfirst[i];
     hp[nt + i] = pcount[i];
     hp[2 * nt + i] = r.dst != ~0u ? r.dst : dummy_dst;
   });
-  CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
+  if (b_scal) CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
   if (ntt) CPX_HIP(hipMemcpyAsync(d_ttasks_.p, ht, b_tt, hipMemcpyHostToDevice, stream_));
   if (nft) CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_pfirst_.p, hp, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
@@ -1579,6 +1582,12 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   }
 
   // -- P4: D, B_c, B_d
+  h_rvec_.ensure(B * 4 * n);
+  h_rgam_.ensure(B * 2);
+  d_rvec_.ensure(B * 4 * n);
+  d_rgam_.ensure(B * 2);
+  d_rbeta_.ensure(B);
+  d_rout_.ensure(B * (2 * n + 2));
   {
     std::vector<TblReq> reqs;
     for (size_t p = 0; p < B; p++) {
@@ -1606,41 +1615,47 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       }
       s.SG.assign(n, S::one());
       s.SGp = s.u;
+      // the round vectors live on the device from here on: c | d | SG | SGp
+      Fr* v = h_rvec_.p + p * 4 * n;
+      for (size_t i = 0; i < n; i++) {
+        v[i] = s.c[i].f;
+        v[n + i] = s.d[i].f;
+        v[2 * n + i] = s.SG[i].f;
+        v[3 * n + i] = s.SGp[i].f;
+      }
+      h_rgam_.p[p] = s.beta_i.f;
     });
+    CPX_HIP(hipMemcpyAsync(d_rvec_.p, h_rvec_.p, B * 4 * n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_rbeta_.p, h_rgam_.p, B * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    wait_stream();   // h_rgam_ is reused for the round challenges
   }
 
-  // -- P5: IPA rounds as MSMs over the original bases
+  // -- P5: IPA rounds as MSMs over the original bases.  The Fr side of a round (cross-term scalars, inner products,
+  //    folds of c and d, fold-coefficient updates) runs on the device (k_ipa_round_scalars / k_ipa_round_fold); the
+  //    host hashes the four points of the round and returns gamma, gamma^-1.
   for (size_t j = 0; j < L; j++) {
     const size_t half = n >> (j + 1);
     std::vector<uint32_t> hi, lo;
     for (size_t k = 0; k < n; k++) ((k & half) ? hi : lo).push_back((uint32_t)k);
     const uint32_t* d_hi = idx_list(hi);
     const uint32_t* d_lo = idx_list(lo);
-    const size_t hn = n / 2;
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      const S* cL = s.c.data();
-      const S* cR = cL + half;
-      const S* dL = s.d.data();
-      const S* dR = dL + half;
-      for (int q = 0; q < 4; q++) s.scal[q].resize(hn);
-      for (size_t t = 0; t < hn; t++) {
-        const size_t kh = hi[t], kl = lo[t];
-        const size_t ih = kh & (half - 1), il = kl & (half - 1);
-        s.scal[0][t] = cL[ih] * s.SG[kh];     // L_C : G_R with c_L
-        s.scal[1][t] = dR[il] * s.SGp[kl];    // L_D : G'_L with d_R
-        s.scal[2][t] = cR[il] * s.SG[kl];     // R_C : G_L with c_R
-        s.scal[3][t] = dL[ih] * s.SGp[kh];    // R_D : G'_R with d_L
-      }
-      s.scal[4] = {s.beta_i * host::inner_product(cL, dR, half), s.beta_i * host::inner_product(cR, dL, half)};
-    });
+    const size_t hn = n / 2, per = 4 * hn + 2;
+    launch_ipa_round_scalars(d_rvec_.p, (int)B, (int)n, (int)half, d_rbeta_.p, d_rout_.p, stream_);
     std::vector<TblReq> reqs;
     for (size_t p = 0; p < B; p++) {
-      ProverState& s = st[p];
-      reqs.push_back({cseg(0, (uint32_t)hn, d_hi), s.scal[0].data(), cseg(0, 1, iH), &s.scal[4][0]});
-      reqs.push_back({cseg(0, (uint32_t)hn, d_lo), s.scal[1].data(), none, nullptr});
-      reqs.push_back({cseg(0, (uint32_t)hn, d_lo), s.scal[2].data(), cseg(0, 1, iH), &s.scal[4][1]});
-      reqs.push_back({cseg(0, (uint32_t)hn, d_hi), s.scal[3].data(), none, nullptr});
+      const Fr* o = d_rout_.p + p * per;   // [L_C (hn), beta<c_L,d_R> | L_D (hn) | R_C (hn), beta<c_R,d_L> | R_D (hn)]
+      TblReq r0{cseg(0, (uint32_t)hn, d_hi), nullptr, cseg(0, 1, iH), nullptr};
+      r0.dev = o;
+      TblReq r1{cseg(0, (uint32_t)hn, d_lo), nullptr, none, nullptr};
+      r1.dev = o + hn + 1;
+      TblReq r2{cseg(0, (uint32_t)hn, d_lo), nullptr, cseg(0, 1, iH), nullptr};
+      r2.dev = o + 2 * hn + 1;
+      TblReq r3{cseg(0, (uint32_t)hn, d_hi), nullptr, none, nullptr};
+      r3.dev = o + 3 * hn + 2;
+      reqs.push_back(r0);
+      reqs.push_back(r1);
+      reqs.push_back(r2);
+      reqs.push_back(r3);
     }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
@@ -1649,16 +1664,17 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       for (int q = 0; q < 4; q++) take(p, order[q], p * 4 + q);
       for (int q : order) s.tr.append_point_bytes("ipa_loop", &s.comp[(size_t)q * 48]);
       const S gamma = s.tr.get_and_append_challenge("ipa_gamma");
-      const S gamma_inv = gamma.inverse();
-      for (size_t i = 0; i < half; i++) {
-        s.c[i] += gamma_inv * s.c[half + i];
-        s.d[i] += gamma * s.d[half + i];
-      }
-      for (size_t t = 0; t < hn; t++) {
-        s.SG[hi[t]] *= gamma;
-        s.SGp[hi[t]] *= gamma_inv;
-      }
+      h_rgam_.p[2 * p] = gamma.f;
+      h_rgam_.p[2 * p + 1] = gamma.inverse().f;
     });
+    CPX_HIP(hipMemcpyAsync(d_rgam_.p, h_rgam_.p, B * 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    launch_ipa_round_fold(d_rvec_.p, (int)B, (int)n, (int)half, d_rgam_.p, stream_);
+    if (j + 1 == L) {   // c_final, d_final (inner_product_argument.rs:188-195)
+      CPX_HIP(hipMemcpy2DAsync(h_rvec_.p, 2 * sizeof(Fr), d_rvec_.p, 4 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
+      CPX_HIP(hipMemcpy2DAsync(h_rvec_.p + 1, 2 * sizeof(Fr), d_rvec_.p + n, 4 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
+      wait_stream();
+    }
+    // no sync otherwise: h_rgam_ is rewritten only after the next round's run_tbl_phase has synchronised the stream
   }
 
   // -- P6 (host only): SameScalar transcript, SameMSM step 1
@@ -1676,8 +1692,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     }   // R, S and the four T_2 commitments from the side stream
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      s.c_final = s.c[0];
-      s.d_final = s.d[0];
+      memcpy(s.c_final.f.v, &h_rvec_.p[2 * p], sizeof(Fr));       // c[0], d[0] after the last fold (device-resident vectors)
+      memcpy(s.d_final.f.v, &h_rvec_.p[2 * p + 1], sizeof(Fr));
       const int side_slots[6] = {SL_R, SL_S, SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2()};
       for (int q : side_slots) memcpy(&s.comp[(size_t)q * 48], side_.hcomp.p + (p * (size_t)CWN + (q - CW0)) * 48, 48);
       const int pts[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
@@ -1711,10 +1727,16 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       s.x[ell + 2] = s.draw(I_VR + ell + 2) + s.alpha_m * s.draw(I_RT);
       s.x[ell + 3] = s.draw(I_VR + ell + 3) + s.alpha_m * s.draw(I_RU);
       s.SM.assign(n, S::one());
+      Fr* v = h_rvec_.p + p * 2 * n;   // device-resident round vectors: x | SM
+      for (size_t i = 0; i < n; i++) {
+        v[i] = s.x[i].f;
+        v[n + i] = s.SM[i].f;
+      }
     });
+    CPX_HIP(hipMemcpyAsync(d_rvec_.p, h_rvec_.p, B * 2 * n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
   }
 
-  // -- P7: SameMSM rounds
+  // -- P7: SameMSM rounds; the Fr side (cross-term scalars, fold of x, fold-coefficient update) on the device
   for (size_t j = 0; j < L; j++) {
     const size_t half = n >> (j + 1);
     std::vector<uint32_t> hi, lo, ghi, glo;
@@ -1727,25 +1749,21 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     const uint32_t* d_ghi = idx_list(ghi);
     const uint32_t* d_glo = idx_list(glo);
     const size_t hn = n / 2;
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      s.scal[0].resize(hn);
-      s.scal[1].resize(hn);
-      for (size_t t = 0; t < hn; t++) {
-        const size_t kh = hi[t], kl = lo[t];
-        s.scal[0][t] = s.x[kh & (half - 1)] * s.SM[kh];            // L_* : right-half bases with x_L
-        s.scal[1][t] = s.x[(kl & (half - 1)) + half] * s.SM[kl];   // R_* : left-half bases with x_R
-      }
-    });
+    launch_smsm_round_scalars(d_rvec_.p, (int)B, (int)n, (int)half, d_rout_.p, stream_);
     std::vector<TblReq> reqs;
     for (size_t p = 0; p < B; p++) {
-      ProverState& s = st[p];
-      reqs.push_back({cseg(0, (uint32_t)hn, d_ghi), s.scal[0].data(), none, nullptr});          // L_A
-      reqs.push_back({pseg(p, O_T, (uint32_t)hn, d_hi), s.scal[0].data(), none, nullptr});      // L_T
-      reqs.push_back({pseg(p, O_U, (uint32_t)hn, d_hi), s.scal[0].data(), none, nullptr});      // L_U
-      reqs.push_back({cseg(0, (uint32_t)hn, d_glo), s.scal[1].data(), none, nullptr});          // R_A
-      reqs.push_back({pseg(p, O_T, (uint32_t)hn, d_lo), s.scal[1].data(), none, nullptr});      // R_T
-      reqs.push_back({pseg(p, O_U, (uint32_t)hn, d_lo), s.scal[1].data(), none, nullptr});      // R_U
+      const Fr* oL = d_rout_.p + p * 2 * hn;   // [L_* scalars (hn) | R_* scalars (hn)]
+      const Fr* oR = oL + hn;
+      TblReq r[6] = {{cseg(0, (uint32_t)hn, d_ghi), nullptr, none, nullptr},       // L_A
+                     {pseg(p, O_T, (uint32_t)hn, d_hi), nullptr, none, nullptr},   // L_T
+                     {pseg(p, O_U, (uint32_t)hn, d_hi), nullptr, none, nullptr},   // L_U
+                     {cseg(0, (uint32_t)hn, d_glo), nullptr, none, nullptr},       // R_A
+                     {pseg(p, O_T, (uint32_t)hn, d_lo), nullptr, none, nullptr},   // R_T
+                     {pseg(p, O_U, (uint32_t)hn, d_lo), nullptr, none, nullptr}};  // R_U
+      for (int q = 0; q < 6; q++) {
+        r[q].dev = q < 3 ? oL : oR;
+        reqs.push_back(r[q]);
+      }
     }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
@@ -1754,10 +1772,15 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       for (int i = 0; i < 6; i++) take(p, order[i], p * 6 + i);
       for (int q : order) s.tr.append_point_bytes("same_msm_loop", &s.comp[(size_t)q * 48]);
       const S gamma = s.tr.get_and_append_challenge("same_msm_gamma");
-      const S gamma_inv = gamma.inverse();
-      for (size_t i = 0; i < half; i++) s.x[i] += gamma_inv * s.x[half + i];
-      for (size_t t = 0; t < hn; t++) s.SM[hi[t]] *= gamma;
+      h_rgam_.p[2 * p] = gamma.f;
+      h_rgam_.p[2 * p + 1] = gamma.inverse().f;
     });
+    CPX_HIP(hipMemcpyAsync(d_rgam_.p, h_rgam_.p, B * 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    launch_smsm_round_fold(d_rvec_.p, (int)B, (int)n, (int)half, d_rgam_.p, stream_);
+    if (j + 1 == L) {   // x_final (same_multiscalar_argument.rs:138-141)
+      CPX_HIP(hipMemcpy2DAsync(h_rvec_.p, sizeof(Fr), d_rvec_.p, 2 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
+      wait_stream();
+    }
   }
 
   // -- serialise (identical to the fold prover)
@@ -1785,7 +1808,11 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     sc(s.z_t);
     sc(s.z_u);
     for (int q = sm.BA(); q < sm.BA() + 3 + 6 * (int)L; q++) pt(q);
-    sc(s.x[0]);
+    {
+      S xf;   // x[0] after the last fold (device-resident vector)
+      memcpy(xf.f.v, &h_rvec_.p[p], sizeof(Fr));
+      sc(xf);
+    }
   });
   flush_timers();
 }

@@ -155,6 +155,7 @@ class Engine {
     TblSeg seg1;
     const host::S* s1;
     uint32_t dst = ~0u;       // optional: index into d_pp_ receiving the affine result
+    const Fr* dev = nullptr;  // optional: the seg0.n + seg1.n scalars already sit in device memory (s0 / s1 unused)
   };
   // second stream + private staging for work that is off the critical path of the phase sequence
   struct SideBufs {
@@ -281,6 +282,8 @@ class Engine {
   PinBuf<uint8_t> h_comp_;
   PinBuf<uint8_t> h_inst_comp_, h_mcomp_, h_pts_, h_status_;   // compressed instance vectors / M, proof points in, decompression status
   PinBuf<uint32_t> h_u32_;
+  DevBuf<Fr> d_rvec_, d_rout_, d_rgam_, d_rbeta_;   // device-resident round vectors, per-round scalars, challenges
+  PinBuf<Fr> h_rvec_, h_rgam_;
   DevBuf<uint8_t> d_mcomp_;                 // compressed M of every proof
   DevBuf<uint64_t> d_tstate_;               // transcript states after the prefix [B][27]
   DevBuf<Fr> d_veca_;                       // vec_a [B][ell]

@@ -110,6 +110,13 @@ struct BigMsmPlan {
 BigMsmPlan big_msm_plan(size_t n);
 void launch_big_msm(const BigMsmPlan& p, const Aff* d_pp, const uint32_t* d_idx, const Fr* d_scalars, size_t n, TAff* d_conv, uint32_t* d_keys,
                     uint32_t* d_vals, void* d_sort_temp, uint32_t* d_bounds, TJac* d_buckets, const TJac* d_extra, int nextra, Jac* d_out, hipStream_t s);
+// Fr algebra of the prover's log rounds on device-resident vectors (kernels.hip: "Fr algebra of the log rounds"):
+// IPA vec [nproofs][4][n] = c | d | SG | SGp, out [nproofs][4 (n/2) + 2]; SameMSM vec [nproofs][2][n] = x | SM, out [nproofs][n];
+// gam [nproofs][2] = gamma, gamma^-1
+void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s);
+void launch_ipa_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s);
+void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr* d_out, hipStream_t s);
+void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s);
 // transcript prefix of every proof: absorbs the compressed instance ([nproofs][4*ell*48] + [nproofs][48] for M), draws vec_a;
 // d_state: [nproofs][27] u64 (25 STROBE lanes, pos, pos_begin), d_vec_a: [nproofs][ell] Fr
 void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s);

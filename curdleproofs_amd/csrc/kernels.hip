@@ -767,6 +767,95 @@ __global__ __launch_bounds__(64) void k_sum_jac(const Jac* __restrict__ in, int 
   flag[0] = acc.is_identity() ? 1 : 0;
 }
 
+// ------------------------------------------------------------------ Fr algebra of the log rounds on the device
+// The prover's per-round scalar vectors (cross-term scalars = vector entry x fold coefficient, the two inner products,
+// the folds of c, d / x and the updates of the fold coefficients S) are elementwise Fr work on vectors that never need
+// to leave the GPU: the host only hashes the round's L/R points and sends back the challenge gamma and its inverse.
+// Round j of n = 2^L elements: half = n >> (j+1); original base k has bit `half` set (hi) or clear (lo); the t-th
+// lo index is kl = (t / half) * 2 half + t % half, the t-th hi index kh = kl + half (t < n/2).
+//
+// IPA (inner_product_argument.rs:150-186 in all-MSM form).  vec: [B][4][n] = c | d | SG | SGp.
+// out per proof: [ L_C scalars (n/2), beta<c_L,d_R> | L_D (n/2) | R_C (n/2), beta<c_R,d_L> | R_D (n/2) ]
+__global__ __launch_bounds__(128) void k_ipa_round_scalars(const Fr* __restrict__ vec, int n, int half, const Fr* __restrict__ beta, Fr* __restrict__ out) {
+  __shared__ Fr red[2][128];
+  const int p = blockIdx.x, hn = n / 2;
+  const Fr* c = vec + (size_t)p * 4 * n;
+  const Fr* d = c + n;
+  const Fr* SG = d + n;
+  const Fr* SGp = SG + n;
+  Fr* o = out + (size_t)p * (4 * hn + 2);
+  Fr ip1 = Fr::zero(), ip2 = Fr::zero();
+  for (int t = threadIdx.x; t < hn; t += blockDim.x) {
+    const int kl = (t / half) * 2 * half + (t % half), kh = kl + half;
+    const int ih = kh & (half - 1), il = kl & (half - 1);
+    o[t] = fe_mul(c[ih], SG[kh]);                          // L_C : right-half bases with c_L
+    o[hn + 1 + t] = fe_mul(d[half + il], SGp[kl]);         // L_D : left-half bases (rescaled) with d_R
+    o[2 * hn + 1 + t] = fe_mul(c[half + il], SG[kl]);      // R_C : left-half bases with c_R
+    o[3 * hn + 2 + t] = fe_mul(d[ih], SGp[kh]);            // R_D : right-half bases with d_L
+  }
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    ip1 = fe_add(ip1, fe_mul(c[i], d[half + i]));
+    ip2 = fe_add(ip2, fe_mul(c[half + i], d[i]));
+  }
+  red[0][threadIdx.x] = ip1;
+  red[1][threadIdx.x] = ip2;
+  __syncthreads();
+  for (int sft = blockDim.x / 2; sft >= 1; sft >>= 1) {
+    if ((int)threadIdx.x < sft) {
+      red[0][threadIdx.x] = fe_add(red[0][threadIdx.x], red[0][threadIdx.x + sft]);
+      red[1][threadIdx.x] = fe_add(red[1][threadIdx.x], red[1][threadIdx.x + sft]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    o[hn] = fe_mul(beta[p], red[0][0]);
+    o[3 * hn + 1] = fe_mul(beta[p], red[1][0]);
+  }
+}
+// gam: [B][2] = gamma, gamma^-1.  c_L += gamma^-1 c_R, d_L += gamma d_R, SG[hi] *= gamma, SGp[hi] *= gamma^-1
+__global__ __launch_bounds__(128) void k_ipa_round_fold(Fr* __restrict__ vec, int n, int half, const Fr* __restrict__ gam) {
+  const int p = blockIdx.x, hn = n / 2;
+  Fr* c = vec + (size_t)p * 4 * n;
+  Fr* d = c + n;
+  Fr* SG = d + n;
+  Fr* SGp = SG + n;
+  const Fr g = gam[2 * p], gi = gam[2 * p + 1];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    c[i] = fe_add(c[i], fe_mul(gi, c[half + i]));
+    d[i] = fe_add(d[i], fe_mul(g, d[half + i]));
+  }
+  for (int t = threadIdx.x; t < hn; t += blockDim.x) {
+    const int kh = (t / half) * 2 * half + (t % half) + half;
+    SG[kh] = fe_mul(SG[kh], g);
+    SGp[kh] = fe_mul(SGp[kh], gi);
+  }
+}
+// SameMSM (same_multiscalar_argument.rs:99-136 in all-MSM form).  vec: [B][2][n] = x | SM.
+// out per proof: [ L_* scalars (n/2) | R_* scalars (n/2) ]
+__global__ __launch_bounds__(128) void k_smsm_round_scalars(const Fr* __restrict__ vec, int n, int half, Fr* __restrict__ out) {
+  const int p = blockIdx.x, hn = n / 2;
+  const Fr* x = vec + (size_t)p * 2 * n;
+  const Fr* SM = x + n;
+  Fr* o = out + (size_t)p * 2 * hn;
+  for (int t = threadIdx.x; t < hn; t += blockDim.x) {
+    const int kl = (t / half) * 2 * half + (t % half), kh = kl + half;
+    o[t] = fe_mul(x[kh & (half - 1)], SM[kh]);                    // L_* : right-half bases with x_L
+    o[hn + t] = fe_mul(x[(kl & (half - 1)) + half], SM[kl]);      // R_* : left-half bases with x_R
+  }
+}
+// gam: [B][2] = gamma, gamma^-1.  x_L += gamma^-1 x_R, SM[hi] *= gamma
+__global__ __launch_bounds__(128) void k_smsm_round_fold(Fr* __restrict__ vec, int n, int half, const Fr* __restrict__ gam) {
+  const int p = blockIdx.x, hn = n / 2;
+  Fr* x = vec + (size_t)p * 2 * n;
+  Fr* SM = x + n;
+  const Fr g = gam[2 * p], gi = gam[2 * p + 1];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) x[i] = fe_add(x[i], fe_mul(gi, x[half + i]));
+  for (int t = threadIdx.x; t < hn; t += blockDim.x) {
+    const int kh = (t / half) * 2 * half + (t % half) + half;
+    SM[kh] = fe_mul(SM[kh], g);
+  }
+}
+
 // ------------------------------------------------------------------ transcript prefix on the device
 // Every prover / verifier transcript starts by absorbing the compressed instance (4 vectors of ell points and M, 48 KB
 // at ell = 252) and drawing the ell challenges of vec_a (curdleproofs.rs:78-83, :213-222): ~770 Keccak permutations
@@ -1080,6 +1169,18 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s) {
   if (n <= 0) return;
   CPX_LAUNCH(k_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in, n, d_out, d_dst_index, d_status, check_subgroup);
+}
+void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s) {
+  if (nproofs > 0) CPX_LAUNCH(k_ipa_round_scalars, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_beta, d_out);
+}
+void launch_ipa_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s) {
+  if (nproofs > 0) CPX_LAUNCH(k_ipa_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_gam);
+}
+void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr* d_out, hipStream_t s) {
+  if (nproofs > 0) CPX_LAUNCH(k_smsm_round_scalars, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_out);
+}
+void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s) {
+  if (nproofs > 0) CPX_LAUNCH(k_smsm_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_gam);
 }
 void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s) {
   if (nproofs <= 0) return;

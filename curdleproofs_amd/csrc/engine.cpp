@@ -1583,6 +1583,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
 
   // -- P4: D, B_c, B_d
   h_rvec_.ensure(B * 4 * n);
+  h_rfin_.ensure(B * 3);   // c_final, d_final, x_final of every proof
   h_rgam_.ensure(B * 2);
   d_rvec_.ensure(B * 4 * n);
   d_rgam_.ensure(B * 2);
@@ -1670,8 +1671,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(d_rgam_.p, h_rgam_.p, B * 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
     launch_ipa_round_fold(d_rvec_.p, (int)B, (int)n, (int)half, d_rgam_.p, stream_);
     if (j + 1 == L) {   // c_final, d_final (inner_product_argument.rs:188-195)
-      CPX_HIP(hipMemcpy2DAsync(h_rvec_.p, 2 * sizeof(Fr), d_rvec_.p, 4 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
-      CPX_HIP(hipMemcpy2DAsync(h_rvec_.p + 1, 2 * sizeof(Fr), d_rvec_.p + n, 4 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
+      CPX_HIP(hipMemcpy2DAsync(h_rfin_.p, 3 * sizeof(Fr), d_rvec_.p, 4 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
+      CPX_HIP(hipMemcpy2DAsync(h_rfin_.p + 1, 3 * sizeof(Fr), d_rvec_.p + n, 4 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
       wait_stream();
     }
     // no sync otherwise: h_rgam_ is rewritten only after the next round's run_tbl_phase has synchronised the stream
@@ -1692,8 +1693,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     }   // R, S and the four T_2 commitments from the side stream
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      memcpy(s.c_final.f.v, &h_rvec_.p[2 * p], sizeof(Fr));       // c[0], d[0] after the last fold (device-resident vectors)
-      memcpy(s.d_final.f.v, &h_rvec_.p[2 * p + 1], sizeof(Fr));
+      memcpy(s.c_final.f.v, &h_rfin_.p[3 * p], sizeof(Fr));       // c[0], d[0] after the last fold (device-resident vectors)
+      memcpy(s.d_final.f.v, &h_rfin_.p[3 * p + 1], sizeof(Fr));
       const int side_slots[6] = {SL_R, SL_S, SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2()};
       for (int q : side_slots) memcpy(&s.comp[(size_t)q * 48], side_.hcomp.p + (p * (size_t)CWN + (q - CW0)) * 48, 48);
       const int pts[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
@@ -1778,7 +1779,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(d_rgam_.p, h_rgam_.p, B * 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
     launch_smsm_round_fold(d_rvec_.p, (int)B, (int)n, (int)half, d_rgam_.p, stream_);
     if (j + 1 == L) {   // x_final (same_multiscalar_argument.rs:138-141)
-      CPX_HIP(hipMemcpy2DAsync(h_rvec_.p, sizeof(Fr), d_rvec_.p, 2 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
+      CPX_HIP(hipMemcpy2DAsync(h_rfin_.p + 2, 3 * sizeof(Fr), d_rvec_.p, 2 * n * sizeof(Fr), sizeof(Fr), B, hipMemcpyDeviceToHost, stream_));
       wait_stream();
     }
   }
@@ -1810,7 +1811,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     for (int q = sm.BA(); q < sm.BA() + 3 + 6 * (int)L; q++) pt(q);
     {
       S xf;   // x[0] after the last fold (device-resident vector)
-      memcpy(xf.f.v, &h_rvec_.p[p], sizeof(Fr));
+      memcpy(xf.f.v, &h_rfin_.p[3 * p + 2], sizeof(Fr));
       sc(xf);
     }
   });

@@ -283,7 +283,7 @@ class Engine {
   PinBuf<uint8_t> h_inst_comp_, h_mcomp_, h_pts_, h_status_;   // compressed instance vectors / M, proof points in, decompression status
   PinBuf<uint32_t> h_u32_;
   DevBuf<Fr> d_rvec_, d_rout_, d_rgam_, d_rbeta_;   // device-resident round vectors, per-round scalars, challenges
-  PinBuf<Fr> h_rvec_, h_rgam_;
+  PinBuf<Fr> h_rvec_, h_rgam_, h_rfin_;
   DevBuf<uint8_t> d_mcomp_;                 // compressed M of every proof
   DevBuf<uint64_t> d_tstate_;               // transcript states after the prefix [B][27]
   DevBuf<Fr> d_veca_;                       // vec_a [B][ell]

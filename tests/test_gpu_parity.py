@@ -268,6 +268,13 @@ def test_prove_verify_ell252_batch(ctx, orc, oracle_vectors):
     assert hashlib.sha256(proofs[0]).hexdigest() == oracle_vectors["252"]["proof_sha256"]
 
 
+def test_prove_verify_batch40_ell28(ctx, orc):
+    # 40 independent instances (BASELINE config 4 recipe: instance i from StdRng(i)): large enough for the engine's
+    # batch paths (transcript prefix on the device from 32 proofs on, multi-chunk host loops); every proof must equal
+    # the oracle's bytes and verify
+    _prove_and_check(ctx, orc, 28, list(range(100, 140)))
+
+
 def test_prove_verify_ell1020_single(ctx, orc, oracle_vectors):
     # BASELINE config 3 (ell = 1020, n = 1024, 10 rounds, seed 0): proof bytes equal the oracle's, 5888 B
     crs, insts, proofs = _prove_and_check(ctx, orc, 1020, [0])

@@ -115,13 +115,13 @@ __device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
 //  k_to_table   converts every base of every task to the table form once (2 products per coordinate) into a
 //               scratch array (task.conv_off); the 8 waves of a task then gather 112-B points from it (L2).
 //  k_msm_accw   barrier-free single-wave groups as in k_msm_tblw: a wave owns 8 windows of one task, lane =
-//               (window, bucket); the digit rows of the whole task (<= 1024 points per pass) sit in LDS, so lanes
+//               (window, bucket); the digit rows of the whole task (<= 1344 points per pass) sit in LDS, so lanes
 //               only re-synchronise once per task and the slowest lane is decided over the whole task.  Windows
 //               carry different weights here (no pre-shifted copies), so buckets cannot be shared across windows:
 //               output = 64 window sums per task, folded by the Horner tails below.
 // The previous one-group-per-task version (512 threads, LDS-staged points, 4 barriers per 256 points) spent 37 %
 // of its wave-cycles waiting and, at one 86 KB group per CU, left no room for other kernels' waves to fill in.
-constexpr int ACW_CHUNK = 1024;
+constexpr int ACW_CHUNK = 1344;   // 8 digit rows of 1344 bytes = the 64 x 168 B the reduction needs anyway; one pass for the verifier's 1191-point tasks
 constexpr int ACW_LDS = 64 * (int)sizeof(TJac) > 8 * ACW_CHUNK ? 64 * (int)sizeof(TJac) : 8 * ACW_CHUNK;
 
 __global__ __launch_bounds__(64) void k_to_table(const MsmTask* __restrict__ tasks, TAff* __restrict__ conv) {

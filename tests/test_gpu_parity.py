@@ -268,6 +268,11 @@ def test_prove_verify_ell252_batch(ctx, orc, oracle_vectors):
     assert hashlib.sha256(proofs[0]).hexdigest() == oracle_vectors["252"]["proof_sha256"]
 
 
+def test_prove_verify_ell60(ctx, orc):
+    # curdleproofs.rs:336-378 (N = 64, ell = 60): whole-shuffle round trip, here bit-exact against the oracle
+    _prove_and_check(ctx, orc, 60, [0, 7])
+
+
 def test_prove_verify_batch40_ell28(ctx, orc):
     # 40 independent instances (BASELINE config 4 recipe: instance i from StdRng(i)): large enough for the engine's
     # batch paths (transcript prefix on the device from 32 proofs on, multi-chunk host loops); every proof must equal

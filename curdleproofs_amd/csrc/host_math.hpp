@@ -64,6 +64,85 @@ inline void mul(const uint32_t* a32, const uint32_t* b32, uint32_t* out32) {
   }
   memcpy(out32, bw ? t : s, 32);
 }
+// a^-1 mod r by the binary extended Euclidean algorithm on 4 x u64 (canonical integers, 0 < a < r): ~510 halvings
+// and ~255 subtractions of 256-bit integers, ~3x faster than Fermat's a^(r-2) (380 Montgomery products).
+inline void inv_canonical(const uint64_t* a_in, uint64_t* out) {
+  uint64_t u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u[i] = a_in[i];
+    v[i] = P[i];
+  }
+  auto is_one = [](const uint64_t* w) { return w[0] == 1 && (w[1] | w[2] | w[3]) == 0; };
+  auto is_zero = [](const uint64_t* w) { return (w[0] | w[1] | w[2] | w[3]) == 0; };
+  auto halve = [](uint64_t* w, uint64_t top) {
+    w[0] = (w[0] >> 1) | (w[1] << 63);
+    w[1] = (w[1] >> 1) | (w[2] << 63);
+    w[2] = (w[2] >> 1) | (w[3] << 63);
+    w[3] = (w[3] >> 1) | (top << 63);
+  };
+  auto halve_mod = [&](uint64_t* x) {
+    uint64_t carry = 0;
+    if (x[0] & 1) {
+      u128 c = 0;
+      for (int i = 0; i < 4; i++) {
+        c += (u128)x[i] + P[i];
+        x[i] = (uint64_t)c;
+        c >>= 64;
+      }
+      carry = (uint64_t)c;
+    }
+    halve(x, carry);
+  };
+  auto geq = [](const uint64_t* a, const uint64_t* b) {
+    for (int i = 3; i >= 0; i--)
+      if (a[i] != b[i]) return a[i] > b[i];
+    return true;
+  };
+  auto sub = [](uint64_t* a, const uint64_t* b) {
+    uint64_t bw = 0;
+    for (int i = 0; i < 4; i++) {
+      const u128 d = (u128)a[i] - b[i] - bw;
+      a[i] = (uint64_t)d;
+      bw = (uint64_t)(d >> 64) & 1;
+    }
+    return bw;
+  };
+  auto sub_mod = [&](uint64_t* a, const uint64_t* b) {
+    if (sub(a, b)) {
+      u128 c = 0;
+      for (int i = 0; i < 4; i++) {
+        c += (u128)a[i] + P[i];
+        a[i] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+  };
+  if (is_zero(u)) {
+    for (int i = 0; i < 4; i++) out[i] = 0;
+    return;
+  }
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1)) {
+      halve(u, 0);
+      halve_mod(x1);
+    }
+    while (!(v[0] & 1)) {
+      halve(v, 0);
+      halve_mod(x2);
+    }
+    if (geq(u, v)) {
+      sub(u, v);
+      sub_mod(x1, x2);
+    } else {
+      sub(v, u);
+      sub_mod(x2, x1);
+    }
+  }
+  const uint64_t* r = is_one(u) ? x1 : x2;
+  for (int i = 0; i < 4; i++) out[i] = r[i];
+}
+// R^3 mod r (R = 2^256): Montgomery-form inverse = inv_canonical(X) * R^3 / R
+static constexpr uint64_t R3[4] = {0xc62c1807439b73afULL, 0x1b3e0d188cf06990ULL, 0x73d13c71c7b5f418ULL, 0x6e2a5bb9c8db33e9ULL};
 }  // namespace fr64
 
 // ---- Fr sugar ----
@@ -103,7 +182,16 @@ struct S {   // a scalar in Montgomery form
     }
     return r;
   }
-  S inverse() const {   // Fermat, a^(r-2); 0 -> 0
+  S inverse() const {   // binary Euclid on the Montgomery value X = a R: X^-1 = a^-1 R^-1, times R^3 -> a^-1 R; 0 -> 0
+    uint64_t x[4], y[4];
+    memcpy(x, f.v, 32);
+    fr64::inv_canonical(x, y);
+    S t, r3;
+    memcpy(t.f.v, y, 32);
+    memcpy(r3.f.v, fr64::R3, 32);
+    return t * r3;
+  }
+  S inverse_fermat() const {   // a^(r-2); kept as the cross-check of inverse() in the tests
     const uint64_t e[4] = {fr64::P[0] - 2, fr64::P[1], fr64::P[2], fr64::P[3]};
     return pow_limbs(e, 4);
   }

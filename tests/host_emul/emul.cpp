@@ -55,6 +55,18 @@ void emul_host_fr_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n
     memcpy(out + 32 * i, z.f.v, 32);
   }
 }
+// Euclid inverse of the host Fr against the Fermat chain; returns the number of mismatches
+int emul_host_fr_inv_check(const uint8_t* a, size_t n) {
+  int bad = 0;
+  for (size_t i = 0; i < n; i++) {
+    host::S x;
+    memcpy(x.f.v, a + 32 * i, 32);
+    const host::S e = x.inverse(), f = x.inverse_fermat();
+    if (memcmp(e.f.v, f.f.v, 32) != 0) bad++;
+    if (!x.is_zero() && !((e * x) == host::S::one())) bad++;
+  }
+  return bad;
+}
 void emul_fr_inv(const uint8_t* a, uint8_t* out) {
   host::S s;
   memcpy(s.f.v, a, 32);

@@ -25,6 +25,7 @@ def emul():
     L.emul_fp_mul.argtypes = [vp, vp, vp, sz]
     L.emul_fr_mul.argtypes = [vp, vp, vp, sz]
     L.emul_host_fr_mul.argtypes = [vp, vp, vp, sz]
+    L.emul_host_fr_inv_check.argtypes = [vp, sz]
     L.emul_msm.argtypes = [vp, vp, sz, vp]
     L.emul_smul.argtypes = [vp, vp, vp, vp]
     L.emul_challenges.argtypes = [vp, sz, vp]
@@ -228,3 +229,4 @@ def test_host_fr_product(emul, orc):
     o = _o(len(s))
     emul.emul_host_fr_mul(_b(s), _b(t), o, len(s) // 32)
     assert bytes(o) == orc.fr_mul(s, t)
+    assert emul.emul_host_fr_inv_check(_b(s), len(s) // 32) == 0     # binary-Euclid inverse == Fermat, x * x^-1 == 1

@@ -1,0 +1,37 @@
+"""The committed bench line (profiles/r01_bench.json, produced by `python bench.py` on an MI355X) carries every field
+of the driver's contract, and bench.py's command line accepts the driver's flags."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    with open(os.path.join(ROOT, "profiles", "r01_bench.json")) as f:
+        d = json.loads(f.read())
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].split(",")[0].startswith(base["metric"].split(" at ")[0])      # "shuffle proofs/sec (prove+verify)"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    assert d["all_verified"] is True and c["gpu_proof_bit_exact"] is True
+
+
+def test_bench_cli_accepts_driver_flags():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout

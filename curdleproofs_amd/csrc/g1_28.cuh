@@ -89,6 +89,50 @@ CPX_PT_FN Jac28 jac28_add(const Jac28& p, const Jac28& q) {
   return r;
 }
 
+// ---- extended Jacobian ("XYZZ": x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2) accumulators for the bucket loops ----
+// A mixed addition is 8M + 2S (madd-2008-s) instead of the Jacobian 7M + 4S: 3738 instead of 3948 limb products.
+// Magnitudes: |X| <= 6.3, |Y| <= 2.7, ZZ and ZZZ are products; the largest operand product is R (<= 4.5) x (Q - X3)
+// (<= 8.1).  The zero test for "same x" rides on the product ZZ3 = ZZ1 * PP.
+struct Xyzz28 {
+  F28 x, y, zz, zzz;
+  CPX_HD bool is_identity() const { return zz.is_zero_exact(); }
+  static CPX_HD Xyzz28 identity() { return Xyzz28{f28_one(), f28_one(), F28::zero(), F28::zero()}; }
+};
+CPX_PT_FN Xyzz28 xyzz28_dbl_affine(const Aff28& q) {   // mdbl-2008-s-1: 2 * (x, y)
+  const F28 u = f28_shl<1>(q.y), v = f28_sqr(u), w = f28_mul(u, v), s = f28_mul(q.x, v);
+  const F28 xx = f28_sqr(q.x), m = f28_add(f28_shl<1>(xx), xx);
+  Xyzz28 r;
+  r.x = f28_sub(f28_sqr(m), f28_shl<1>(s));
+  r.y = f28_sub(f28_mul(m, f28_sub(s, r.x)), f28_mul(w, q.y));
+  r.zz = v;
+  r.zzz = w;
+  return r;
+}
+CPX_PT_FN Xyzz28 xyzz28_add_mixed(const Xyzz28& p, const Aff28& q) {
+  if (q.is_identity()) return p;
+  if (p.is_identity()) return Xyzz28{q.x, q.y, f28_one(), f28_one()};
+  const F28 u2 = f28_mul(q.x, p.zz), s2 = f28_mul(q.y, p.zzz);
+  const F28 pp_ = f28_sub(u2, p.x), rr = f28_sub(s2, p.y);
+  const F28 pp2 = f28_sqr(pp_);
+  const F28 zz3 = f28_mul(p.zz, pp2);
+  if (f28_product_is_zero(zz3)) {   // same x: P = +-Q
+    if (f28_product_is_zero(f28_mul(rr, f28_one()))) return xyzz28_dbl_affine(q);
+    return Xyzz28::identity();
+  }
+  const F28 ppp = f28_mul(pp_, pp2), qq = f28_mul(p.x, pp2);
+  Xyzz28 r;
+  r.x = f28_sub(f28_sub(f28_sqr(rr), ppp), f28_shl<1>(qq));
+  r.y = f28_sub(f28_mul(rr, f28_sub(qq, r.x)), f28_mul(p.y, ppp));
+  r.zz = zz3;
+  r.zzz = f28_mul(p.zzz, ppp);
+  return r;
+}
+// same point in Jacobian coordinates with Z = ZZ: (X ZZ, Y ZZZ, ZZ)
+CPX_HD Jac28 xyzz28_to_jac(const Xyzz28& p) {
+  if (p.is_identity()) return Jac28::identity();
+  return Jac28{f28_mul(p.x, p.zz), f28_mul(p.y, p.zzz), p.zz};
+}
+
 CPX_HD Aff28 jac28_to_affine_with_zinv(const Jac28& p, const F28& zinv) {
   const F28 zi2 = f28_sqr(zinv);
   return Aff28{f28_mul(p.x, zi2), f28_mul(f28_mul(p.y, zi2), zinv)};

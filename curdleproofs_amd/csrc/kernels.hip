@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, 2) void k_msm_accw(const MsmTask* __restrict__ 
   const int lane = threadIdx.x;
   const int wl = lane >> 3, mag = (lane & 7) + 1;
   const TAff* pts = conv + task.conv_off;
-  TJac acc = TJac::identity();
+  TAcc xacc = TAcc::identity();
 
   for (uint32_t base = 0; base < task.n; base += ACW_CHUNK) {
     const int m = min((uint32_t)ACW_CHUNK, task.n - base);
@@ -166,11 +166,12 @@ __global__ __launch_bounds__(64, 2) void k_msm_accw(const MsmTask* __restrict__ 
       if (!__any(have)) break;
       if (have) {
         const TAff q = pts[base + i];
-        acc = t_add_mixed(acc, t_cneg(q, d < 0));
+        xacc = t_acc_add_mixed(xacc, t_cneg(q, d < 0));
         i++;
       }
     }
   }
+  TJac acc = t_acc_to_jac(xacc);
   __syncthreads();
   red[lane] = acc;
   __syncthreads();
@@ -234,7 +235,7 @@ template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const Tbl
   const int lane = threadIdx.x;
   const int mag = (lane & 7) + 1, sl = lane >> 3;
   const uint32_t ntot = task.seg[0].n + task.seg[1].n;
-  TJac acc = TJac::identity();
+  TAcc xacc = TAcc::identity();
 
   for (uint32_t base = 0; base < ntot; base += TBW_CHUNK) {
     const int m = min((uint32_t)TBW_CHUNK, ntot - base);
@@ -266,11 +267,12 @@ template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const Tbl
       if (!__any(have)) break;
       if (have) {
         const TAff q = *tbl_point(task, base + i, (uint32_t)(w0 + j));
-        acc = t_add_mixed(acc, t_cneg(q, d < 0));
+        xacc = t_acc_add_mixed(xacc, t_cneg(q, d < 0));
         i += 8;
       }
     }
   }
+  TJac acc = t_acc_to_jac(xacc);
   __syncthreads();
   red[lane] = acc;
   __syncthreads();
@@ -346,7 +348,7 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
   const int wl = lane / LPW, sl = lane % LPW;
   const uint32_t w = (uint32_t)(wg * FIX_WPW + wl);
   const TAff* wtab = tab + (size_t)w * M * nc;
-  TJac acc = TJac::identity();
+  TAcc xacc = TAcc::identity();
 
   for (uint32_t base = 0; base < task.n; base += FIX_CHUNK) {
     const int m = min((uint32_t)FIX_CHUNK, task.n - base);
@@ -367,10 +369,11 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
       TAff p0 = TAff::identity(), p1 = TAff::identity();
       if (d0) p0 = wtab[(size_t)((d0 < 0 ? -d0 : d0) - 1) * nc + task.off + (task.idx ? task.idx[g0] : g0)];
       if (d1) p1 = wtab[(size_t)((d1 < 0 ? -d1 : d1) - 1) * nc + task.off + (task.idx ? task.idx[g1] : g1)];
-      if (d0) acc = t_add_mixed(acc, t_cneg(p0, d0 < 0));
-      if (d1) acc = t_add_mixed(acc, t_cneg(p1, d1 < 0));
+      if (d0) xacc = t_acc_add_mixed(xacc, t_cneg(p0, d0 < 0));
+      if (d1) xacc = t_acc_add_mixed(xacc, t_cneg(p1, d1 < 0));
     }
   }
+  TJac acc = t_acc_to_jac(xacc);
   __syncthreads();
   red[lane] = acc;
   __syncthreads();
@@ -717,14 +720,14 @@ __global__ __launch_bounds__(64, 2) void k_big_accum(const uint32_t* __restrict_
                                                      const TAff* __restrict__ conv, uint32_t nbuckets, TJac* __restrict__ buckets) {
   const uint32_t b = blockIdx.x * 64 + threadIdx.x;
   if (b >= nbuckets) return;
-  TJac acc = TJac::identity();
+  TAcc acc = TAcc::identity();
   const uint32_t e = end[b];
   for (uint32_t j = start[b]; j < e; j++) {
     const uint32_t v = vals[j];
     const TAff q = conv[v & 0x7fffffffu];
-    acc = t_add_mixed(acc, t_cneg(q, (v >> 31) != 0));
+    acc = t_acc_add_mixed(acc, t_cneg(q, (v >> 31) != 0));
   }
-  buckets[b] = acc;
+  buckets[b] = t_acc_to_jac(acc);
 }
 // One level of the per-window reduction  sum_b b * B_b.  A segment of m = 2^s consecutive buckets is summarised by
 // (T, S) = (sum_j (j+1) x_j, sum_j x_j); K neighbouring segments combine into one of length K m:

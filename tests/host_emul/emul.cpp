@@ -233,6 +233,24 @@ void emul_f28_msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_
   memcpy(out, &r, 96);
   mags[0] = mx; mags[1] = my; mags[2] = mz;
 }
+// bucket accumulation in XYZZ coordinates: sum of +-P_i (sign from the low bit of the scalar's first limb), with
+// repeated and opposite points mixed in; returns the affine sum (standard form) and the largest magnitudes seen
+void emul_f28_xyzz_sum(const uint8_t* bases, size_t n, const uint8_t* signs, uint8_t* out, double* mags) {
+  const Aff* P = reinterpret_cast<const Aff*>(bases);
+  Xyzz28 acc = Xyzz28::identity();
+  double mx = 0, my = 0;
+  for (size_t i = 0; i < n; i++) {
+    acc = xyzz28_add_mixed(acc, aff28_cneg(aff28_from_std(P[i]), signs[i] & 1));
+    mx = std::max(mx, f28_mag(acc.x));
+    my = std::max(my, f28_mag(acc.y));
+  }
+  const Jac28 j = xyzz28_to_jac(acc);
+  Aff r = Aff::identity();
+  if (!j.is_identity()) r = aff28_to_std(jac28_to_affine_with_zinv(j, f28_inv(j.z)));
+  memcpy(out, &r, 96);
+  mags[0] = mx;
+  mags[1] = my;
+}
 // exceptional cases of the complete formulas: P+P, P+(-P), P+O, O+P in mixed and Jacobian form -> 8 affine outputs
 void emul_f28_edges(const uint8_t* base, uint8_t* out /*8*96*/) {
   Aff p;

@@ -31,6 +31,7 @@ def emul():
     L.emul_challenges.argtypes = [vp, sz, vp]
     L.emul_f28_mul.argtypes = [vp, vp, vp, sz]
     L.emul_f28_msm.argtypes = [vp, vp, sz, vp, vp]
+    L.emul_f28_xyzz_sum.argtypes = [vp, sz, vp, vp, vp]
     return L
 
 
@@ -230,3 +231,24 @@ def test_host_fr_product(emul, orc):
     emul.emul_host_fr_mul(_b(s), _b(t), o, len(s) // 32)
     assert bytes(o) == orc.fr_mul(s, t)
     assert emul.emul_host_fr_inv_check(_b(s), len(s) // 32) == 0     # binary-Euclid inverse == Fermat, x * x^-1 == 1
+
+
+def test_f28_xyzz_accumulation(emul, orc):
+    """Extended-Jacobian bucket accumulation (xyzz28_add_mixed): random points, P + P, P - P, identities."""
+    rng = orc.rng(91)
+    pts = [rng.g1_affine(1) for _ in range(12)]
+    seq = [pts[0], pts[1], pts[1], pts[2], bytes(AFF), pts[3], pts[3], pts[4]] + pts[5:] + [pts[0], pts[2]]
+    signs = bytes([0, 0, 0, 1, 0, 0, 1, 0] + [i & 1 for i in range(len(pts) - 5)] + [1, 0])      # pts[3] - pts[3] cancels; pts[1] doubles
+    assert len(signs) == len(seq)
+    o = _o(AFF)
+    mags = (ctypes.c_double * 2)()
+    emul.emul_f28_xyzz_sum(_b(b"".join(seq)), len(seq), _b(signs), o, mags)
+    rm1 = orc.fr_from_canonical_bytes((0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001 - 1).to_bytes(32, "little"))
+    scal = b"".join(rm1 if sg else orc.fr_from_u64(1) for sg in signs)
+    want = orc.g1_to_affine(orc.g1_msm(b"".join(seq), scal, naive=True))
+    assert bytes(o) == want
+    assert mags[0] <= 6.3 and mags[1] <= 2.7, list(mags)
+    # a bucket that starts with the same point twice, then its negation twice: back to the identity
+    seq2 = [pts[6], pts[6], pts[6], pts[6]]
+    emul.emul_f28_xyzz_sum(_b(b"".join(seq2)), 4, _b(bytes([0, 0, 1, 1])), o, mags)
+    assert bytes(o) == bytes(AFF)

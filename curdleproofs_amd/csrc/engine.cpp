@@ -394,7 +394,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   if (!nt) return;
   const bool fix = fix_bits_ && fixtab();
   const TAff* c_lo = ctab();
-  const TAff* c_hi = ctab() + (size_t)copies_ * (n_ + 3);
+  const TAff* c_hi = ctab() + (size_t)copies_ * nc();
   auto is_crs = [&](const TblSeg& sg) { return fix && sg.n && sg.base >= c_lo && sg.base < c_hi; };
   auto needs_tbl = [&](const TblReq& r) { return !fix || (r.seg0.n && !is_crs(r.seg0)) || (r.seg1.n && !is_crs(r.seg1)); };
   size_t ntt_total = 0, nft_total = 0;
@@ -441,7 +441,9 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   d_pcount_.ensure(nt);
   d_comp_.ensure(nt * 48);
   const size_t b_scal = total * sizeof(Fr), b_tt = ntt * sizeof(TblTask), b_ft = nft * sizeof(FixTask);
-  h_stage_.ensure(b_scal + b_tt + b_ft + 3 * nt * sizeof(uint32_t));
+  bool any_add = false;
+  for (const TblReq& r : reqs) any_add |= r.add[0] != ~0u;
+  h_stage_.ensure(b_scal + b_tt + b_ft + 6 * nt * sizeof(uint32_t));
   d_dst_.ensure(nt);
   const uint32_t dummy_dst = slot_index(0, SlotMap(L_).TMP(7));   // results nobody reads land in a scratch slot
   Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
@@ -485,7 +487,12 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     hp[i] = pfirst[i];
     hp[nt + i] = pcount[i];
     hp[2 * nt + i] = r.dst != ~0u ? r.dst : dummy_dst;
+    for (int j = 0; j < 3; j++) hp[3 * nt + 3 * i + j] = r.add[j];
   });
+  if (any_add) {
+    d_padd_.ensure(3 * nt);
+    CPX_HIP(hipMemcpyAsync(d_padd_.p, hp + 3 * nt, 3 * nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  }
   if (b_scal) CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
   if (ntt) CPX_HIP(hipMemcpyAsync(d_ttasks_.p, ht, b_tt, hipMemcpyHostToDevice, stream_));
   if (nft) CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
@@ -494,7 +501,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   if (nft) {
     tick(fix_bits_ == 16 ? (fix_wpw == 16 ? "k_msm_fix<16, 16>" : "k_msm_fix<16, 8>") : (fix_wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>"), 128.0 * pts_fix, pts_fix);
-    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)(n_ + 3), d_tpart_.p, stream_);
+    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
     tock();
   }
   if (ntt) {
@@ -503,7 +510,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     tock();
   }
   tick("k_finalize_ranges", 0, (double)nt);
-  launch_finalize_ranges(d_tpart_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
+  launch_finalize_ranges(d_tpart_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_, any_add ? d_padd_.p : nullptr);
   tock();
   if (comp_out) {
     h_comp_.ensure(nt * 48);
@@ -562,7 +569,7 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
     static std::mutex reg_mu;
     static std::vector<std::weak_ptr<CrsTables>> registry;
     std::lock_guard<std::mutex> lk(reg_mu);
-    const size_t NC = n + 3;
+    const size_t NC = nc();
     const int want_fix = fix_bits_;   // the verifier needs the table whichever prover is selected
     std::vector<uint8_t> key(points, points + (ell + 7) * sizeof(Aff));
     crs_tab_.reset();
@@ -583,6 +590,8 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
       tab->ctab.ensure((size_t)copies_ * NC);
       std::vector<Aff> row(NC);
       for (size_t i = 0; i < n + 3; i++) row[i] = pts[i];   // G | Hvec | H | G_t | G_u
+      row[n + 3] = crs_single_[3];                          // G_sum, H_sum (crs.rs:46-47): B, D are built from them
+      row[n + 4] = crs_single_[4];
       DevBuf<Aff> d_row;
       d_row.ensure(NC);
       CPX_HIP(hipMemcpy(d_row.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
@@ -803,7 +812,7 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
     const size_t NP = np();
     d_ptab_.ensure(batch * (size_t)copies_ * NP);
     d_psrc_.ensure(batch * NP);
-    d_tbltmp_.ensure(std::max(batch * NP, n_ + 3) * (size_t)(copies_ - 1));
+    d_tbltmp_.ensure(batch * NP * (size_t)(copies_ - 1));
     tails.assign(batch * 8, Aff::identity());
     for (size_t p = 0; p < batch; p++) tails[8 * p + 2] = tails[8 * p + 7] = crs_single_[0];
     const size_t spitch = NP * sizeof(Aff);
@@ -1325,11 +1334,6 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   gb[ell + 2] = (uint32_t)(n + 1);
   gb[ell + 3] = (uint32_t)(n + 2);
   const uint32_t* iGb = idx_list(gb);
-  std::vector<uint32_t> ap(n + 2);   // A' : G | Hvec | G_t | G_u
-  for (size_t i = 0; i < n; i++) ap[i] = (uint32_t)i;
-  ap[n] = (uint32_t)(n + 1);
-  ap[n + 1] = (uint32_t)(n + 2);
-  const uint32_t* iAp = idx_list(ap);
   const TblSeg none{nullptr, nullptr, 0, 0};
 
   // -- P0: compressed instance vectors, M -> affine (into table slot 0), then the per-proof tables.  The transcript
@@ -1439,12 +1443,12 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       const S* ru = &s.scal[2][1];
       const S* ra = &s.scal[2][2];
       const S* rb = &s.scal[2][3];
-      reqs.push_back({cseg(0, (uint32_t)n), s.scal[0].data(), none, nullptr});                       // A
+      reqs.push_back({cseg(0, (uint32_t)n), s.scal[0].data(), none, nullptr, slot_index(p, SL_A)});  // A (kept as a point: B and A' add it)
       reqs.push_back({cseg(0, (uint32_t)n, iGb), s.scal[1].data(), none, nullptr});                   // B_a (same_multiscalar_argument.rs:80)
       reqs.push_back({pseg(p, O_T, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_t
       reqs.push_back({pseg(p, O_U, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_u
-      reqs.push_back({cseg(0, 1, iGt), rt, none, nullptr});                                           // cm_T.T_1 = r_t G_t
-      reqs.push_back({cseg(0, 1, iGu), ru, none, nullptr});                                           // cm_U.T_1
+      reqs.push_back({cseg(0, 1, iGt), rt, none, nullptr, slot_index(p, SL_CMT1)});                   // cm_T.T_1 = r_t G_t
+      reqs.push_back({cseg(0, 1, iGu), ru, none, nullptr, slot_index(p, SL_CMU1)});                   // cm_U.T_1
       reqs.push_back({cseg(0, 1, iGt), ra, none, nullptr});                                           // cm_A.T_1
       reqs.push_back({cseg(0, 1, iGu), rb, none, nullptr});                                           // cm_B.T_1
       // r * H halves of the four T_2 commitments, kept as affine points for the side-stream scalar multiplications
@@ -1452,14 +1456,13 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       reqs.push_back({cseg(0, 1, iH), ru, none, nullptr, slot_index(p, sm.TMP(1))});
       reqs.push_back({cseg(0, 1, iH), ra, none, nullptr, slot_index(p, sm.TMP(2))});
       reqs.push_back({cseg(0, 1, iH), rb, none, nullptr, slot_index(p, sm.TMP(3))});
-      reqs.push_back({cseg(0, (uint32_t)(n + 2), iAp), s.scal[0].data(), none, nullptr});             // A'
     }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      const int ids[13] = {SL_A, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), -1, -1, -1, -1, sm.APRIME()};
-      for (int i = 0; i < 13; i++)
-        if (ids[i] >= 0) take(p, ids[i], p * 13 + i);
+      const int ids[12] = {SL_A, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), -1, -1, -1, -1};
+      for (int i = 0; i < 12; i++)
+        if (ids[i] >= 0) take(p, ids[i], p * 12 + i);
       // same_permutation_argument.rs:60-83
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_A * 48]);
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_M * 48]);
@@ -1473,13 +1476,9 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
         s.factors[i] = s.a_perm[i] + S::from_u64(perm[i]) * s.alpha_sp + s.beta_sp;
         s.gprod *= s.factors[i];
       }
-      // B = A + alpha M + beta * sum(G)  ->  (a' + beta | r_a') over G | Hvec, alpha on M
-      s.scal[5].resize(n);
-      for (size_t i = 0; i < ell; i++) s.scal[5][i] = s.a_perm[i] + s.beta_sp;
-      s.scal[5][ell] = s.draw(I_AB);
-      s.scal[5][ell + 1] = s.draw(I_AB + 1);
-      s.scal[5][ell + 2] = S::zero();
-      s.scal[5][ell + 3] = S::zero();
+      // B = A + alpha M + beta * sum(G) (same_permutation_argument.rs:75-76): the point A of phase 1 plus two
+      // single-point terms (G_sum sits in the CRS tables)
+      s.scal[5] = {s.beta_sp};
       s.scal[6] = {s.alpha_sp};
     });
   }
@@ -1505,14 +1504,24 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipEventRecord(side_.ev, side_.stream));
   }
 
-  // -- P2: B
+  // -- P2: B, and A' = A + cm_T.T_1 + cm_U.T_1 (curdleproofs.rs:134) as a sum of three points of phase 1
   {
     std::vector<TblReq> reqs;
-    for (size_t p = 0; p < B; p++) reqs.push_back({cseg(0, (uint32_t)n), st[p].scal[5].data(), pseg(p, O_M, 1), st[p].scal[6].data()});
+    for (size_t p = 0; p < B; p++) {
+      TblReq rb{cseg(n + 3, 1), st[p].scal[5].data(), pseg(p, O_M, 1), st[p].scal[6].data(), slot_index(p, SL_B)};
+      rb.add[0] = slot_index(p, SL_A);
+      TblReq ra{none, nullptr, none, nullptr};
+      ra.add[0] = slot_index(p, SL_A);
+      ra.add[1] = slot_index(p, SL_CMT1);
+      ra.add[2] = slot_index(p, SL_CMU1);
+      reqs.push_back(rb);
+      reqs.push_back(ra);
+    }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      take(p, SL_B, p);
+      take(p, SL_B, p * 2);
+      take(p, sm.APRIME(), p * 2 + 1);
       s.tr.append_point_bytes("gprod_step1", &s.comp[SL_B * 48]);
       s.tr.append_scalar("gprod_step1", s.gprod);
       s.alpha_g = s.tr.get_and_append_challenge("gprod_alpha");
@@ -1559,10 +1568,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       const S beta_l1 = pbm * s.beta_g, beta_l = pbm;
       for (size_t i = 0; i < N_BLINDERS; i++) s.d[ell + i] = beta_l1 * s.rb_plus_alpha[i];
       s.z_ip = s.r_p * beta_l1 + s.gprod * beta_l - S::one();
-      // D = B - beta^-1 sum(G) + alpha sum(Hvec)  ->  (a' + beta_sp - beta_g^-1 | r_a' + alpha_g) over G | Hvec, alpha_sp on M
-      s.scal[0].resize(n);
-      for (size_t i = 0; i < ell; i++) s.scal[0][i] = s.scal[5][i] - s.beta_g_inv;
-      for (size_t i = ell; i < n; i++) s.scal[0][i] = s.scal[5][i] + s.alpha_g;
+      // D = B - beta^-1 sum(G) + alpha sum(Hvec) (grand_product_argument.rs:132): the point B plus two single-point terms
+      s.scal[0] = {-s.beta_g_inv, s.alpha_g};
       // generate_ipa_blinders (inner_product_argument.rs:42-82)
       SVec r(n), zz(n);
       for (size_t i = 0; i < n; i++) r[i] = s.draw(I_IR + i);
@@ -1593,7 +1600,9 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     std::vector<TblReq> reqs;
     for (size_t p = 0; p < B; p++) {
       ProverState& s = st[p];
-      reqs.push_back({cseg(0, (uint32_t)n), s.scal[0].data(), pseg(p, O_M, 1), s.scal[6].data()});
+      TblReq rd{cseg(n + 3, 2), s.scal[0].data(), none, nullptr};   // G_sum, H_sum are columns n+3, n+4 of the CRS tables
+      rd.add[0] = slot_index(p, SL_B);
+      reqs.push_back(rd);
       reqs.push_back({cseg(0, (uint32_t)n), s.scal[1].data(), none, nullptr});
       reqs.push_back({cseg(0, (uint32_t)n), s.scal[3].data(), none, nullptr});
     }
@@ -2222,7 +2231,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_big_idx_.p, hi, b_idx, hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, sizeof(FixTask), hipMemcpyHostToDevice, stream_));
-    launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)(n_ + 3), d_tpart_.p, stream_);
+    launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
     tick("big_msm", 128.0 * N, (double)N, true);
     launch_big_msm(plan, d_pp_.p, d_big_idx_.p, d_scal_.p, N, d_conv_.p, d_big_keys_.p, d_big_vals_.p, d_big_temp_.p, d_big_bounds_.p, d_big_buckets_.p,
                    d_tpart_.p, fix_parts, d_res_.p, stream_);
@@ -2276,7 +2285,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
     tick(fix_bits_ == 16 ? (fix_wpw == 16 ? "k_msm_fix<16, 16>" : "k_msm_fix<16, 8>") : (fix_wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>"), 128.0 * n * B,
          (double)(n * B));
-    launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)(n_ + 3), d_tpart_.p, stream_);
+    launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
     tock();
     tick("k_msm_accw", 128.0 * NPT * B, (double)(NPT * B));
     launch_msm_accum(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_wsum_.p, stream_);

@@ -156,6 +156,7 @@ class Engine {
     const host::S* s1;
     uint32_t dst = ~0u;       // optional: index into d_pp_ receiving the affine result
     const Fr* dev = nullptr;  // optional: the seg0.n + seg1.n scalars already sit in device memory (s0 / s1 unused)
+    uint32_t add[3] = {~0u, ~0u, ~0u};   // optional: d_pp_ indices of affine points of earlier phases added with coefficient 1
   };
   // second stream + private staging for work that is off the critical path of the phase sequence
   struct SideBufs {
@@ -216,7 +217,8 @@ class Engine {
   size_t np() const { return 1 + 2 * n_; }   // M | T_b | U_b   (R and S are used once: no table)
   TAff* ptab(size_t p) const { return d_ptab_.p + p * (size_t)copies_ * np(); }
   TblSeg pseg(size_t p, size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ptab(p) + off, idx, (uint32_t)np(), cnt}; }
-  TblSeg cseg(size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ctab() + off, idx, (uint32_t)(n_ + 3), cnt}; }
+  TblSeg cseg(size_t off, uint32_t cnt, const uint32_t* idx = nullptr) const { return TblSeg{ctab() + off, idx, (uint32_t)nc(), cnt}; }
+  size_t nc() const { return n_ + 5; }   // CRS table columns: G | Hvec | H | G_t | G_u | G_sum | H_sum
   Aff* pp(size_t p) const { return d_pp_.p + p * pp_stride_; }
   Aff* slot(size_t p, int s) const { return pp(p) + 4 * ell_ + s; }
   uint32_t slot_index(size_t p, int s) const { return (uint32_t)(p * pp_stride_ + 4 * ell_ + s); }
@@ -256,7 +258,7 @@ class Engine {
   DevBuf<TblTask> d_ttasks_;
   int fix_bits_ = 16;        // fixed-base CRS table of multiples: radix 2^16 (13 GB at ell = 252), 2^8 (0.1 GB) or 0 = off
   DevBuf<FixTask> d_ftasks_;
-  DevBuf<uint32_t> d_pfirst_, d_pcount_;
+  DevBuf<uint32_t> d_pfirst_, d_pcount_, d_padd_;
 
   // batch
   size_t B_ = 0;

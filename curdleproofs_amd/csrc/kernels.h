@@ -81,8 +81,9 @@ void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, i
 // shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
 // output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)
+// d_addends (optional): [n][3] indices into d_aff of affine points (results of earlier phases) to add to output o; ~0u = none
 void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
-                            uint8_t* d_comp, hipStream_t s);
+                            uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends = nullptr);
 
 // ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian, table representation) ...
 // d_conv: scratch for the table-form copies of all bases (sum of n over the tasks, addressed by task.conv_off);

@@ -435,7 +435,8 @@ template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* 
 // Thread per request: add its partial sums [first, first + count), normalise (one inversion per work-group),
 // convert to the standard form, scatter the affine point and emit the 48-byte compressed encoding.
 __global__ __launch_bounds__(256) void k_finalize_ranges(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
-                                                         int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp) {
+                                                         int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
+                                                         const uint32_t* __restrict__ addends) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,6 +446,12 @@ __global__ __launch_bounds__(256) void k_finalize_ranges(const TJac* __restrict_
     const uint32_t c = count[g];
     if (c) p = src[0];
     for (uint32_t j = 1; j < c; j++) p = t_add(p, src[j]);
+    if (addends) {   // up to three already-normalised points of out_aff (results of earlier phases) added with coefficient 1
+      for (int j = 0; j < 3; j++) {
+        const uint32_t a = addends[3 * g + j];
+        if (a != ~0u) p = t_add_mixed(p, t_from_std(out_aff[a]));
+      }
+    }
   }
   const bool inf = p.is_identity();
   const TF zinv = t_block_batch_inverse(p.z, buf);
@@ -1144,9 +1151,9 @@ void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, T
   else CPX_LAUNCH(k_fix_build<8>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
 }
 void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
-                            uint8_t* d_comp, hipStream_t s) {
+                            uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends) {
   if (n <= 0) return;
-  CPX_LAUNCH(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp);
+  CPX_LAUNCH(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
 }
 void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
                         TblTmp* d_tmp, hipStream_t s) {

@@ -1982,16 +1982,23 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     s.scal[1] = {S::one(), S::one(), S::one()};          // A' (curdleproofs.rs:258)
   });
 
-  // -- V1b: D and A' are hashed into the transcript, so they are needed as bytes
+  // -- V1b: D = B - beta^-1 sum(G) + alpha sum(H) (grand_product_argument.rs:223) and A' = A + cm_T.T_1 + cm_U.T_1
+  //    (curdleproofs.rs:258) are hashed into the transcript, so they are needed as bytes: sums of decompressed proof
+  //    points plus two fixed-base terms (G_sum, H_sum are columns of the CRS tables)
   {
-    const uint32_t* iD = idx_list({(uint32_t)SL_B, (uint32_t)SL_GSUM, (uint32_t)SL_HSUM});
-    const uint32_t* iAp = idx_list({(uint32_t)SL_A, (uint32_t)SL_CMT1, (uint32_t)SL_CMU1});
-    std::vector<MsmReq> reqs;
+    const TblSeg none{nullptr, nullptr, 0, 0};
+    std::vector<TblReq> reqs;
     for (size_t p = 0; p < B; p++) {
-      reqs.push_back({slot(p, 0), iD, st[p].scal[0].data(), 3, slot_index(p, sm.D())});
-      reqs.push_back({slot(p, 0), iAp, st[p].scal[1].data(), 3, slot_index(p, sm.APRIME())});
+      TblReq rd{cseg(n + 3, 2), st[p].scal[0].data() + 1, none, nullptr, slot_index(p, sm.D())};
+      rd.add[0] = slot_index(p, SL_B);
+      TblReq ra{none, nullptr, none, nullptr, slot_index(p, sm.APRIME())};
+      ra.add[0] = slot_index(p, SL_A);
+      ra.add[1] = slot_index(p, SL_CMT1);
+      ra.add[2] = slot_index(p, SL_CMU1);
+      reqs.push_back(rd);
+      reqs.push_back(ra);
     }
-    run_msm_phase(reqs, &comp);
+    run_tbl_phase(reqs, &comp);
   }
 
   // -- V1c: rest of the transcript and the scalars of the accumulated check

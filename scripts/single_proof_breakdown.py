@@ -1,0 +1,18 @@
+import sys, time, os
+sys.path.insert(0, os.getcwd())
+import curdleproofs_amd as cpx
+from tests.oracle_lib import Oracle
+orc = Oracle()
+ell = 252
+crs = orc.generate_crs_points(ell); inst = orc.make_instance(ell, 0, crs)
+ctx = cpx.Context(0); ctx.set_crs(ell, crs)
+ctx.load_batch(inst["vec_R"], inst["vec_S"], inst["vec_T"], inst["vec_U"], inst["M"])
+for rep in range(3):
+    proofs = ctx.prove_batch(inst["permutation"], inst["k"], inst["vec_m_blinders"], inst["prover_rand"])
+ctx.set_profiling(True); ctx.reset_stats()
+t0 = time.perf_counter()
+proofs = ctx.prove_batch(inst["permutation"], inst["k"], inst["vec_m_blinders"], inst["prover_rand"])
+t1 = time.perf_counter()
+print("prove %.1f ms" % ((t1 - t0) * 1e3))
+for k, v in sorted(ctx.stats().items(), key=lambda kv: -kv[1]["ms"]):
+    if v["launches"]: print("%-22s %7.2f ms x%d" % (k, v["ms"], v["launches"]))

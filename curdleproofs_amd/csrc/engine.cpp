@@ -185,7 +185,7 @@ void WorkerPool::run(size_t n, const std::function<void(size_t)>& f) {
 }
 
 template <class F> void Engine::parallel_for(size_t n, F&& f) {
-  if (n <= 1) {
+  if (n < 16) {   // a handful of items: waking the pool (tens of sleeping threads) costs more than the work
     for (size_t i = 0; i < n; i++) f(i);
     return;
   }
@@ -388,6 +388,22 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
   wait_stream();   // staging buffer reuse safety
 }
 
+// kernel names as rocprofv3 reports the template instantiations (statistics keys)
+static const char* fix_kernel_name(int bits, int wpw) {
+  if (bits == 16) return wpw == 16 ? "k_msm_fix<16, 16>" : wpw == 8 ? "k_msm_fix<16, 8>" : wpw == 4 ? "k_msm_fix<16, 4>" : "k_msm_fix<16, 2>";
+  return wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>";
+}
+static const char* tblw_kernel_name(int wpw) {
+  switch (wpw) {
+    case 64: return "k_msm_tblw<64>";
+    case 32: return "k_msm_tblw<32>";
+    case 16: return "k_msm_tblw<16>";
+    case 8: return "k_msm_tblw<8>";
+    case 4: return "k_msm_tblw<4>";
+    default: return "k_msm_tblw<2>";
+  }
+}
+
 // Table-backed MSM phase: every request is one work-group of k_msm_tbl; results are normalised + compressed.
 void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out) {
   const size_t nt = reqs.size();
@@ -500,12 +516,12 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   if (nft) {
-    tick(fix_bits_ == 16 ? (fix_wpw == 16 ? "k_msm_fix<16, 16>" : "k_msm_fix<16, 8>") : (fix_wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>"), 128.0 * pts_fix, pts_fix);
+    tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * pts_fix, pts_fix);
     launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
     tock();
   }
   if (ntt) {
-    tick(tbl_wpw == 64 ? "k_msm_tblw<64>" : tbl_wpw == 32 ? "k_msm_tblw<32>" : tbl_wpw == 16 ? "k_msm_tblw<16>" : "k_msm_tblw<8>", 128.0 * pts_tbl, pts_tbl);
+    tick(tblw_kernel_name(tbl_wpw), 128.0 * pts_tbl, pts_tbl);
     launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_tpart_.p, stream_);
     tock();
   }
@@ -2290,7 +2306,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_tasks_.p, hm, b_mt, hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
-    tick(fix_bits_ == 16 ? (fix_wpw == 16 ? "k_msm_fix<16, 16>" : "k_msm_fix<16, 8>") : (fix_wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>"), 128.0 * n * B,
+    tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * n * B,
          (double)(n * B));
     launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
     tock();

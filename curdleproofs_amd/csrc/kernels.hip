@@ -461,6 +461,50 @@ __global__ __launch_bounds__(256) void k_finalize_ranges(const TJac* __restrict_
   if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
 }
 
+// Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per request.  The lanes add the
+// request's partial sums in a tree (log2(count) dependent additions instead of count), lane 0 adds the affine addends;
+// the inversion is shared by the 4 requests of a work-group.
+__global__ __launch_bounds__(256) void k_finalize_ranges_wave(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
+                                                              int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
+                                                              const uint32_t* __restrict__ addends) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  TF* buf = reinterpret_cast<TF*>(smem);                                     // 2 * 256 field elements (batch inversion)
+  TJac* red = reinterpret_cast<TJac*>(smem + 2 * 256 * sizeof(TF));          // [256]
+  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x * 4 + (tid >> 6);
+  TJac p = TJac::identity();
+  if (g < n) {
+    const TJac* src = part + first[g];
+    const uint32_t c = count[g];
+    for (uint32_t j = lane; j < c; j += 64) p = t_add(p, src[j]);
+  }
+  red[tid] = p;
+  __syncthreads();
+  for (int sft = 32; sft >= 1; sft >>= 1) {
+    const bool has = lane < sft;
+    TJac other;
+    if (has) other = red[tid + sft];
+    __syncthreads();
+    if (has) {
+      p = t_add(p, other);
+      red[tid] = p;
+    }
+    __syncthreads();
+  }
+  const bool owner = lane == 0 && g < n;
+  if (owner && addends) {
+    for (int j = 0; j < 3; j++) {
+      const uint32_t a = addends[3 * g + j];
+      if (a != ~0u) p = t_add_mixed(p, t_from_std(out_aff[a]));
+    }
+  }
+  const bool inf = p.is_identity();
+  const TF zinv = t_block_batch_inverse(owner ? p.z : t_one(), buf);
+  if (!owner) return;
+  const Aff a = inf ? Aff::identity() : t_to_std(t_to_affine(p, zinv));
+  if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
+  if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
+}
+
 // ------------------------------------------------------------------ table construction
 // Scratch of the build kernels in structure-of-arrays form: word k of entry c of thread g lives at
 // ((c * TMP_WORDS + k) * nthreads + g), so the 64 lanes of a wave store / load 256 contiguous bytes per
@@ -1110,11 +1154,14 @@ int msm_tblw_windows_per_wave(int ntasks) {
   static const int forced = [] {   // CPX_TBW_WPW=8|16|32|64 pins the grouping (tests exercise every instantiation)
     const char* e = getenv("CPX_TBW_WPW");
     const int v = e ? atoi(e) : 0;
-    return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 0;
+    return (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 0;
   }();
   if (forced) return forced;
   for (int wpw = 64; wpw > 8; wpw >>= 1)
     if ((long)ntasks * (64 / wpw) >= min_waves) return wpw;
+  // a few proofs in flight: latency matters, so spread a task over as many (short) waves as the GPU can hold at once
+  if ((long)ntasks * 32 <= 2048) return 2;
+  if ((long)ntasks * 16 <= 2048) return 4;
   return 8;
 }
 void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, hipStream_t s) {
@@ -1124,6 +1171,8 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, 
     case 64: CPX_LAUNCH(k_msm_tblw<64>, grid, block, tbw_lds(64), s, d_tasks, d_part); break;
     case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, tbw_lds(32), s, d_tasks, d_part); break;
     case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, tbw_lds(16), s, d_tasks, d_part); break;
+    case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, tbw_lds(4), s, d_tasks, d_part); break;
+    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, tbw_lds(2), s, d_tasks, d_part); break;
     default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, tbw_lds(8), s, d_tasks, d_part); break;
   }
 }
@@ -1133,13 +1182,20 @@ int msm_fix_windows_per_wave(int ntasks, int cbits) {
     const char* e = getenv("CPX_FIX_MIN_WAVES");
     return e ? atol(e) : 4096L;   // two waves per SIMD
   }();
-  return (long)ntasks * (w / 16) >= min_waves ? 16 : 8;
+  if ((long)ntasks * (w / 16) >= min_waves) return 16;
+  if (cbits == 16) {   // a few proofs in flight: more, shorter waves per task
+    if ((long)ntasks * 8 <= 2048) return 2;
+    if ((long)ntasks * 4 <= 2048) return 4;
+  }
+  return 8;
 }
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;
   const size_t lds = 64 * sizeof(TJac);   // 10,752 B >= 16 * FIX_CHUNK * 2 = 8,192 B of digit rows
   const dim3 grid(ntasks * (256 / cbits / wpw)), block(64);
   if (cbits == 16 && wpw == 16) CPX_LAUNCH((k_msm_fix<16, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
+  else if (cbits == 16 && wpw == 4) CPX_LAUNCH((k_msm_fix<16, 4>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
+  else if (cbits == 16 && wpw == 2) CPX_LAUNCH((k_msm_fix<16, 2>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
   else if (cbits == 16) CPX_LAUNCH((k_msm_fix<16, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
   else if (wpw == 16) CPX_LAUNCH((k_msm_fix<8, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
   else CPX_LAUNCH((k_msm_fix<8, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
@@ -1153,6 +1209,11 @@ void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, T
 void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends) {
   if (n <= 0) return;
+  if (n <= 512) {   // a few proofs: wave per request (tree over the partial sums)
+    const size_t lds = 2 * 256 * sizeof(TF) + 256 * sizeof(TJac);
+    CPX_LAUNCH(k_finalize_ranges_wave, dim3((n + 3) / 4), dim3(256), lds, s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
+    return;
+  }
   CPX_LAUNCH(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
 }
 void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies,

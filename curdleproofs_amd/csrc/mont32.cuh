@@ -337,23 +337,6 @@ CPX_HD void words_inv_mod_p(const uint32_t* a_in, uint32_t* out) {
     CPX_UNROLL for (int i = 1; i < N; i++) o |= w[i];
     return o == 0;
   };
-  auto halve = [](uint32_t* w, uint32_t top) {   // (top:w) >> 1
-    CPX_UNROLL for (int i = 0; i < N - 1; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
-    w[N - 1] = (w[N - 1] >> 1) | (top << 31);
-  };
-  auto halve_mod = [&](uint32_t* x) {            // x / 2 mod p
-    uint32_t carry = 0;
-    if (x[0] & 1u) {
-      uint64_t c = 0;
-      CPX_UNROLL for (int i = 0; i < N; i++) {
-        c += (uint64_t)x[i] + FpCfg::P[i];
-        x[i] = (uint32_t)c;
-        c >>= 32;
-      }
-      carry = (uint32_t)c;
-    }
-    halve(x, carry);
-  };
   auto geq = [](const uint32_t* a, const uint32_t* b) {
     for (int i = N - 1; i >= 0; i--) {
       if (a[i] != b[i]) return a[i] > b[i];
@@ -379,18 +362,31 @@ CPX_HD void words_inv_mod_p(const uint32_t* a_in, uint32_t* out) {
       }
     }
   };
-  // u + v loses at least one bit per halving: <= 2 * 384 halvings in total.  The budget only matters for the
+  // k trailing zero bits at once (1 <= k <= 31): w >>= k;  x = x / 2^k mod p by adding the multiple m p that clears the
+  // low k bits (m = x * (-p^-1) mod 2^k), then shifting — one multiply-accumulate pass instead of k add-and-halve passes
+  auto shift_k = [](uint32_t* w, uint32_t top, int k) {   // (top:w) >> k
+    CPX_UNROLL for (int i = 0; i < N - 1; i++) w[i] = (w[i] >> k) | (w[i + 1] << (32 - k));
+    w[N - 1] = (w[N - 1] >> k) | (top << (32 - k));
+  };
+  auto strip = [&](uint32_t* w, uint32_t* x) {
+    const int k = __builtin_ctz(w[0] | 0x80000000u);      // low word 0: take 31 bits now, the loop comes back for the rest
+    shift_k(w, 0, k);
+    const uint32_t m = (x[0] * FpCfg::INV) & ((1u << k) - 1u);
+    uint64_t c = 0;
+    CPX_UNROLL for (int i = 0; i < N; i++) {
+      c += (uint64_t)m * FpCfg::P[i] + x[i];
+      x[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    shift_k(x, (uint32_t)c, k);
+    return k;
+  };
+  // u + v loses at least one bit per halving: <= 2 * 384 halved bits in total.  The budget only matters for the
   // invalid input a = 0 (never produced by the callers), which must not spin forever on a GPU.
   int budget = 4 * 384;
   while (!is_one(u) && !is_one(v) && budget > 0) {
-    while (!(u[0] & 1u) && budget-- > 0) {
-      halve(u, 0);
-      halve_mod(x1);
-    }
-    while (!(v[0] & 1u) && budget-- > 0) {
-      halve(v, 0);
-      halve_mod(x2);
-    }
+    while (!(u[0] & 1u) && budget > 0) budget -= strip(u, x1);
+    while (!(v[0] & 1u) && budget > 0) budget -= strip(v, x2);
     budget--;
     if (geq(u, v)) {
       sub(u, v);

@@ -13,6 +13,7 @@
 // Exact zero is all-limbs-zero; a product is = 0 mod p iff it equals 0 or p (it cannot reach -p).
 #pragma once
 #include "mont32.cuh"
+#include "modinv30.cuh"
 
 namespace cpx {
 
@@ -217,12 +218,12 @@ CPX_HD Fp f28_to_std(const F28& a) {
   f28_canonical_words(f28_mul(a, f28_const(F28Cfg::C_OUT)), r.v);   // x * 2^384, canonical
   return r;
 }
-// Inverse of a lazy PRODUCT-range value by the binary Euclidean algorithm (mont32.cuh: words_inv_mod_p):
+// Inverse of a lazy value by batched division steps (modinv30.cuh):
 // X = a 2^392 -> X^-1 = a^-1 2^-392 as a plain integer -> one product with 2^1176 gives a^-1 2^392.
 CPX_HD F28 f28_inv_euclid(const F28& a) {
   uint32_t w[12], iw[12];
   f28_canonical_words(f28_mul(a, f28_one()), w);   // any lazy input: one product brings it into the canonicalisable range
-  words_inv_mod_p(w, iw);
+  words_inv_mod_p_divsteps(w, iw);
   return f28_mul(f28_from_words(iw), f28_const(F28Cfg::C_INV));
 }
 

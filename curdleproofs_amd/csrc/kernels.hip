@@ -34,10 +34,10 @@
 namespace cpx {
 
 // ------------------------------------------------------------------ inversion on device
-// One inversion per work-group by the binary Euclidean algorithm (mont32.cuh): ~0.12 ms of single-wave latency
-// instead of the ~0.55 ms of Fermat's a^(p-2) (571 dependent products); callers amortise it over a whole
-// work-group (batch inversion below).
-__device__ __noinline__ Fp fp_inv_device(const Fp& a) { return fe_inv_euclid(a); }
+// One inversion per work-group by batched division steps (modinv30.cuh): ~0.05 ms of single-wave latency instead of
+// the ~0.25 ms of the binary Euclidean algorithm or the ~0.55 ms of Fermat's a^(p-2) (571 dependent products);
+// callers amortise it over a whole work-group (batch inversion below).
+__device__ __noinline__ Fp fp_inv_device(const Fp& a) { return fe_inv_divsteps(a); }
 
 // In-work-group batch inversion.  Every thread passes its z (any value; zero is treated as 1 and
 // returns an unspecified value the caller must ignore).  `buf` holds 2 * blockDim.x Fp values.

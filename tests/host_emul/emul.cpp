@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../curdleproofs_amd/csrc/g1.cuh"
 #include "../../curdleproofs_amd/csrc/tarith.cuh"
+#include "../../curdleproofs_amd/csrc/modinv30.cuh"
 #include "../../curdleproofs_amd/csrc/recode.cuh"
 #include "../../curdleproofs_amd/csrc/host_math.hpp"
 
@@ -298,6 +299,20 @@ int emul_inv_euclid(const uint8_t* a, uint8_t* out /*2*48: std form, table form 
   memcpy(out, e.v, 48);
   memcpy(out + 48, e28.v, 48);
   return (memcmp(e.v, f.v, 48) == 0 && memcmp(e28.v, f28v.v, 48) == 0 && memcmp(e.v, e28.v, 48) == 0) ? 1 : 0;
+}
+
+// division-step inversion (modinv30.cuh) against the binary Euclidean one, canonical integers; returns mismatches
+int emul_modinv30_check(const uint8_t* a, size_t n, uint8_t* first_out) {
+  int bad = 0;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t w[12], x[12], y[12];
+    memcpy(w, a + 48 * i, 48);
+    words_inv_mod_p_divsteps(w, x);
+    words_inv_mod_p(w, y);
+    if (i == 0) memcpy(first_out, x, 48);
+    if (memcmp(x, y, 48) != 0) bad++;
+  }
+  return bad;
 }
 
 }  // extern "C"

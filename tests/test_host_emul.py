@@ -17,7 +17,7 @@ FR, AFF, JAC = 32, 96, 144
 
 @pytest.fixture(scope="module")
 def emul():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp", "fp28.cuh", "g1_28.cuh", "tarith.cuh")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp", "fp28.cuh", "g1_28.cuh", "tarith.cuh", "modinv30.cuh", "strobe.cuh")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC])
     L = ctypes.CDLL(LIB)
@@ -26,6 +26,7 @@ def emul():
     L.emul_fr_mul.argtypes = [vp, vp, vp, sz]
     L.emul_host_fr_mul.argtypes = [vp, vp, vp, sz]
     L.emul_host_fr_inv_check.argtypes = [vp, sz]
+    L.emul_modinv30_check.argtypes = [vp, sz, vp]
     L.emul_msm.argtypes = [vp, vp, sz, vp]
     L.emul_smul.argtypes = [vp, vp, vp, vp]
     L.emul_challenges.argtypes = [vp, sz, vp]
@@ -252,3 +253,19 @@ def test_f28_xyzz_accumulation(emul, orc):
     seq2 = [pts[6], pts[6], pts[6], pts[6]]
     emul.emul_f28_xyzz_sum(_b(b"".join(seq2)), 4, _b(bytes([0, 0, 1, 1])), o, mags)
     assert bytes(o) == bytes(AFF)
+
+
+def test_divstep_inversion_matches_euclid(emul):
+    """modinv30.cuh (batched division steps, the inversion of the batch-inversion kernels) vs the binary Euclidean one."""
+    import random
+    rnd = random.Random(11)
+    vals = [1, 2, 3, 4, 5, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 30, (1 << 30) - 1, (1 << 60) + 1, 1 << 380, (1 << 381) - 1,
+            0x3fffffff << 30, P >> 1, P >> 30] + [rnd.randrange(1, P) for _ in range(3000)] + [rnd.randrange(1, 1 << b) for b in range(1, 381, 3)]
+    blob = b"".join(v.to_bytes(48, "little") for v in vals)
+    first = _o(48)
+    assert emul.emul_modinv30_check(_b(blob), len(vals), first) == 0
+    assert int.from_bytes(bytes(first), "little") == pow(vals[0], -1, P)
+    for v in vals[:40]:
+        o = _o(48)
+        emul.emul_modinv30_check(_b(v.to_bytes(48, "little")), 1, o)
+        assert int.from_bytes(bytes(o), "little") == pow(v, -1, P)

@@ -395,7 +395,6 @@ static const char* fix_kernel_name(int bits, int wpw) {
 }
 static const char* tblw_kernel_name(int wpw) {
   switch (wpw) {
-    case 64: return "k_msm_tblw<64>";
     case 32: return "k_msm_tblw<32>";
     case 16: return "k_msm_tblw<16>";
     case 8: return "k_msm_tblw<8>";
@@ -421,7 +420,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   const int fix_wpw = fix ? msm_fix_windows_per_wave((int)nft_total, fix_bits_) : 16;
   const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / fix_wpw) : 0;
   const int tbl_wpw = msm_tblw_windows_per_wave((int)ntt_total);   // windows per wave of the shifted-table kernel
-  const uint32_t tbl_parts = (uint32_t)(64 / tbl_wpw);
+  const uint32_t tbl_parts = (uint32_t)msm_tblw_parts(tbl_wpw);   // partial sums (waves) per task
   // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
   std::vector<size_t> soff(nt);
   std::vector<uint32_t> pfirst(nt), pcount(nt), tt_index(nt, ~0u), ft_index(nt * 2, ~0u);

@@ -239,7 +239,7 @@ class Engine {
   uint8_t crs_H_comp_[48];
 
   // shifted-base tables (all-MSM prover)
-  static constexpr int copies_ = 64;   // table copies per base: 2^(4c) P, one per radix-16 window
+  static constexpr int copies_ = 32;   // table copies per base: 2^(8c) P, one per radix-256 window
   bool use_tables_ = true;
   // CRS tables are immutable once built and large (15 GB at ell = 252): engines on the same device that are
   // given the same CRS share one copy (process-wide registry in engine.cpp).

@@ -36,8 +36,8 @@ struct SmulTask {
 
 // ---- table-backed MSM (no doubling tails) ----
 // Tables and partial sums are in the table kernels' representation (tarith.cuh: TAff / TJac, 28-bit limbs).
-// A table holds, for every base point P_i, the affine copies 2^(4c) * P_i, c = 0..63, copy-major: entry (c, i)
-// at base + c*copy_stride + i.  Every radix-16 window of a scalar has its own copy, so all window sums carry
+// A table holds, for every base point P_i, the affine copies 2^(8c) * P_i, c = 0..31, copy-major: entry (c, i)
+// at base + c*copy_stride + i.  Every radix-256 window of a scalar has its own copy, so all window sums carry
 // weight 1 and no doubling is left in the MSM.
 struct TblSeg {
   const TAff* base;         // copy 0
@@ -55,8 +55,10 @@ struct TblTmp {   // table-build scratch: a Jacobian copy and the running produc
   TJac p;
   TF pre;
 };
-// single-wave work-groups owning wpw (8, 16, 32 or 64) windows each: 64 / wpw per task -> d_part[task.pad + j], j < 64 / wpw
+// single-wave work-groups owning wpw (2 .. 32) windows and one half of the bucket magnitudes each: 64 / wpw per task
+// -> d_part[task.pad + j], j < 64 / wpw
 int msm_tblw_windows_per_wave(int ntasks);
+int msm_tblw_parts(int wpw);   // waves (= partial sums) per task
 void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, hipStream_t s);
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.

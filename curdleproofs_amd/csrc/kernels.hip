@@ -204,18 +204,27 @@ __global__ __launch_bounds__(64, 2) void k_msm_accw(const MsmTask* __restrict__ 
 }
 
 // ------------------------------------------------------------------ table-backed MSM, barrier-free single-wave groups
-// 64-copy tables: every radix-16 window of a scalar has its own pre-shifted copy of the base, so ALL window
-// sums carry weight 1 and a bucket may collect additions from any window.  A single-wave work-group owns WPW
-// consecutive windows of one task; lane = (bucket magnitude b = 1..8, point slice s = 0..7) walks the
-// (window, point) pairs of its slice whose digit is +-b.  More windows per wave = more pairs per lane = better
-// balance (the slowest lane of a wave decides: Binomial(16 WPW, 1/8) at 128 points) and fewer fixed-cost bucket
-// reductions (9 point additions per wave); the launcher picks the largest WPW that still fills the GPU.
-// Waves never wait for each other, and the CU scheduler backfills a finished wave's slot with the next one of
-// the grid (an 8-wave group version idled 67 % of its wave-cycles at barriers / s_waitcnt).  Points are gathered
-// from the table in HBM/L2 (one gather per digit addition); only the digit rows are staged in LDS.
-// Output: one partial sum per wave; k_finalize_ranges adds the partials of a request.
-constexpr int TBW_CHUNK = 128;
-constexpr int tbw_lds(int wpw) { return wpw * TBW_CHUNK > 64 * (int)sizeof(TJac) ? wpw * TBW_CHUNK : 64 * (int)sizeof(TJac); }
+// 32-copy tables: every radix-256 window of a scalar has its own pre-shifted copy 2^(8c) P of the base, so ALL window
+// sums carry weight 1 and a bucket may collect additions from any window: one (scalar, base) pair costs 32 mixed
+// additions, the 128 bucket magnitudes of the signed digits are the only reduction.  (Radix 16 with 64 copies — the
+// previous layout — paid 60 additions per pair.)
+// A single-wave work-group owns WPW consecutive windows of one task and one HALF of the magnitudes: lane l of half h
+// owns bucket |d| = 64 h + l + 1.  With a hit rate of 1/128 per (window, point) pair a lane cannot scan for its
+// digits; the wave sorts instead: every lane recodes one scalar of a 64-point slab, a histogram over the 64
+// magnitudes (LDS atomics) gives the list offsets, a second pass scatters 16-bit (point, window, sign) entries into
+// per-bucket lists in LDS, and every lane then walks its own list — gather the pre-shifted point from the table in
+// HBM/L2, add.  A round takes as many slabs as fit the list (8704 entries = a whole 512-point task of the ell = 252
+// prover), so the slowest lane is decided over the whole task (Binomial(16384, 1/128): ~155 against a mean of 128),
+// not per slab.  Waves never wait for each other and the CU scheduler backfills a finished wave's slot.
+// Reduction per wave: suffix scan over the 64 buckets (6 additions) + tree sum (6) = sum_l (l+1) B_l, plus 64 times
+// the plain sum for the upper half.  Output: one partial sum per wave; k_finalize_ranges adds the partials of a
+// request.
+constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
+constexpr int TBW_CAP = 8704;         // list entries per round
+constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index
+constexpr int TBW_LDS = TBW_CAP * 2 + 2 * 64 * 4;
+static_assert(TBW_CAP * 2 >= 65 * (int)sizeof(TJac), "the reduction buffer aliases the lists");
+static_assert(TBW_CAP >= 64 * TBW_WINDOWS, "one slab always fits");
 
 __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
   const uint32_t n0 = t.seg[0].n;
@@ -224,59 +233,122 @@ __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, u
   return sg.base + (size_t)copy * sg.copy_stride + (sg.idx ? sg.idx[i] : i);
 }
 
+// Signed radix-256 digits of windows [w0, w0 + WPW) of scalar i, biased by 128 and packed four per word: byte w of
+// k + 0x8080...80 (one 256-bit addition) is d_w + 128 with d_w in [-128, 127] and sum d_w 256^w = k.  No carry leaves
+// the top byte: scalars are < r < 2^255 and r's top byte is 0x73.
+template <int WPW> __device__ __forceinline__ void tbw_digits(const TblTask& task, uint32_t i, int w0, uint32_t (&dg)[(WPW + 3) / 4]) {
+  Fr k = task.scalars[i];
+  if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
+  uint32_t carry = 0;
+  CPX_UNROLL for (int w = 0; w < 8; w++) {
+    const uint64_t t = (uint64_t)k.v[w] + 0x80808080u + carry;
+    carry = (uint32_t)(t >> 32);
+    const uint32_t kw = (uint32_t)t;
+    CPX_UNROLL for (int q = 0; q < (WPW + 3) / 4; q++)
+      if (w == (w0 >> 2) + q) dg[q] = kw;
+  }
+  if (WPW < 4) dg[0] >>= 8 * (w0 & 3);
+}
+// bucket of window j within magnitude half h (>= 64: not in this half, or digit 0) and the sign of the digit
+__device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, int h, uint32_t& neg) {
+  const int d = (int)((word >> (8 * (j & 3))) & 255u) - 128;
+  neg = d < 0 ? 1u : 0u;
+  return (uint32_t)((d < 0 ? -d : d) - 1 - 64 * h);
+}
 
 template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, TJac* __restrict__ part) {
-  constexpr int WV = 64 / WPW;   // waves per task
+  constexpr int WV = 2 * TBW_WINDOWS / WPW;   // waves per task: window groups x magnitude halves
+  constexpr int NW = (WPW + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [WPW][TBW_CHUNK]
-  TJac* red = reinterpret_cast<TJac*>(smem);          // [64] (aliases the digits afterwards)
+  uint16_t* list = reinterpret_cast<uint16_t*>(smem);                 // [TBW_CAP]
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + TBW_CAP * 2);    // [64] bucket sizes of the round
+  uint32_t* cur = cnt + 64;                                           // [64] scatter cursors
+  TJac* red = reinterpret_cast<TJac*>(smem);                          // [64] (aliases the lists afterwards)
   const TblTask task = tasks[blockIdx.x / WV];
-  const int wv = blockIdx.x % WV, w0 = wv * WPW;
+  const int wv = blockIdx.x % WV, h = wv & 1, w0 = (wv >> 1) * WPW;
   const int lane = threadIdx.x;
-  const int mag = (lane & 7) + 1, sl = lane >> 3;
   const uint32_t ntot = task.seg[0].n + task.seg[1].n;
   TAcc xacc = TAcc::identity();
 
-  for (uint32_t base = 0; base < ntot; base += TBW_CHUNK) {
-    const int m = min((uint32_t)TBW_CHUNK, ntot - base);
+  uint32_t next = 0;
+  while (next < ntot) {
+    cnt[lane] = 0;
     __syncthreads();
-    for (int t = lane; t < m; t += 64) {
-      Fr k = task.scalars[base + t];
-      if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
-      int8_t d[64];
-      recode_signed16(k.v, d);
-      CPX_UNROLL for (int j = 0; j < WPW; j++) digits[j * TBW_CHUNK + t] = d[w0 + j];
-    }
-    __syncthreads();
-    int j = 0, i = sl;
-    for (;;) {
-      // cheap divergent scan to this lane's next (window, point) pair with digit +-mag
-      int d = 0;
-      while (j < WPW) {
-        const int8_t* row = digits + j * TBW_CHUNK;
-        while (i < m) {
-          d = row[i];
-          if (d == mag || d == -mag) break;
-          i += 8;
+    // histogram over as many 64-point slabs as fit the list
+    uint32_t total = 0, end = next;
+    while (end < ntot && end - next + 64 <= (uint32_t)TBW_ROUND_PTS) {
+      const uint32_t i = end + lane;
+      uint32_t dg[NW];
+      int mine = 0;
+      if (i < ntot) {
+        tbw_digits<WPW>(task, i, w0, dg);
+        CPX_UNROLL for (int j = 0; j < WPW; j++) {
+          uint32_t neg;
+          mine += tbw_bucket(dg[j >> 2], j, h, neg) < 64u ? 1 : 0;
         }
-        if (i < m) break;
-        j++;
-        i = sl;
       }
-      const bool have = j < WPW;
-      if (!__any(have)) break;
-      if (have) {
-        const TAff q = *tbl_point(task, base + i, (uint32_t)(w0 + j));
-        xacc = t_acc_add_mixed(xacc, t_cneg(q, d < 0));
-        i += 8;
+      int ct = mine;
+      CPX_UNROLL for (int m = 32; m >= 1; m >>= 1) ct += __shfl_xor(ct, m, 64);
+      if (total && total + (uint32_t)ct > (uint32_t)TBW_CAP) break;
+      if (i < ntot) {
+        CPX_UNROLL for (int j = 0; j < WPW; j++) {
+          uint32_t neg;
+          const uint32_t b = tbw_bucket(dg[j >> 2], j, h, neg);
+          if (b < 64u) atomicAdd(&cnt[b], 1u);
+        }
+      }
+      total += (uint32_t)ct;
+      end = min(end + 64, ntot);
+    }
+    __syncthreads();
+    // list offsets: exclusive scan of the bucket sizes over the wave
+    const uint32_t mycnt = cnt[lane];
+    uint32_t incl = mycnt;
+    CPX_UNROLL for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    const uint32_t off = incl - mycnt;
+    cur[lane] = off;
+    __syncthreads();
+    for (uint32_t c0 = next; c0 < end; c0 += 64) {
+      const uint32_t i = c0 + lane;
+      if (i < end) {
+        uint32_t dg[NW];
+        tbw_digits<WPW>(task, i, w0, dg);
+        CPX_UNROLL for (int j = 0; j < WPW; j++) {
+          uint32_t neg;
+          const uint32_t b = tbw_bucket(dg[j >> 2], j, h, neg);
+          if (b < 64u) list[atomicAdd(&cur[b], 1u)] = (uint16_t)(((i - next) << 6) | ((uint32_t)j << 1) | neg);
+        }
       }
     }
+    __syncthreads();
+    for (uint32_t k = off; k < off + mycnt; k++) {
+      const uint32_t e = list[k];
+      const TAff q = *tbl_point(task, next + (e >> 6), (uint32_t)w0 + ((e >> 1) & 31u));
+      xacc = t_acc_add_mixed(xacc, t_cneg(q, (e & 1u) != 0));
+    }
+    __syncthreads();
+    next = end;
   }
   TJac acc = t_acc_to_jac(xacc);
   __syncthreads();
   red[lane] = acc;
   __syncthreads();
-  for (int sft = 32; sft >= 8; sft >>= 1) {         // merge the 8 slices of every bucket: lanes 0..7 hold B_1..B_8
+  for (int sft = 1; sft < 64; sft <<= 1) {          // suffix sums S_l = B_l + ... + B_63
+    const bool has = lane + sft < 64;
+    TJac other;
+    if (has) other = red[lane + sft];
+    __syncthreads();
+    if (has) {
+      acc = t_add(acc, other);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) red[64] = acc;                     // the plain sum of the 64 buckets (spare slot behind the tree's)
+  for (int sft = 32; sft >= 1; sft >>= 1) {         // ... summed: sum_l (l + 1) B_l in lane 0
     const bool has = lane < sft;
     TJac other;
     if (has) other = red[lane + sft];
@@ -287,29 +359,14 @@ template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const Tbl
     }
     __syncthreads();
   }
-  for (int sft = 1; sft < 8; sft <<= 1) {           // suffix sums S_b = B_b + ... + B_8 over lanes 0..7
-    const bool has = lane < 8 && lane + sft < 8;
-    TJac other;
-    if (has) other = red[lane + sft];
-    __syncthreads();
-    if (has) {
-      acc = t_add(acc, other);
-      red[lane] = acc;
+  if (lane == 0) {
+    if (h) {                                        // upper half: bucket magnitudes are 64 + (l + 1)
+      TJac plain = red[64];
+      for (int s = 0; s < 6; s++) plain = t_dbl(plain);
+      acc = t_add(acc, plain);
     }
-    __syncthreads();
+    part[task.pad + wv] = acc;   // task.pad = first partial slot of the task
   }
-  for (int sft = 4; sft >= 1; sft >>= 1) {          // ... summed: sum_b b * B_b in lane 0
-    const bool has = lane < sft;
-    TJac other;
-    if (has) other = red[lane + sft];
-    __syncthreads();
-    if (has) {
-      acc = t_add(acc, other);
-      red[lane] = acc;
-    }
-    __syncthreads();
-  }
-  if (lane == 0) part[task.pad + wv] = acc;   // task.pad = first partial slot of the task
 }
 
 // ------------------------------------------------------------------ fixed-base MSM over multiples tables
@@ -1146,34 +1203,35 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
   else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out);
 }
 int msm_tblw_windows_per_wave(int ntasks) {
-  // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2)
+  // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2);
+  // a task always takes 64 / wpw waves (window groups x the two magnitude halves)
   static const long min_waves = [] {
     const char* e = getenv("CPX_TBW_MIN_WAVES");
     return e ? atol(e) : 2048L;
   }();
-  static const int forced = [] {   // CPX_TBW_WPW=8|16|32|64 pins the grouping (tests exercise every instantiation)
+  static const int forced = [] {   // CPX_TBW_WPW=2|4|8|16|32 pins the grouping (tests exercise every instantiation)
     const char* e = getenv("CPX_TBW_WPW");
     const int v = e ? atoi(e) : 0;
-    return (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) ? v : 0;
+    return (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
   }();
   if (forced) return forced;
-  for (int wpw = 64; wpw > 8; wpw >>= 1)
+  for (int wpw = 32; wpw > 8; wpw >>= 1)
     if ((long)ntasks * (64 / wpw) >= min_waves) return wpw;
   // a few proofs in flight: latency matters, so spread a task over as many (short) waves as the GPU can hold at once
   if ((long)ntasks * 32 <= 2048) return 2;
   if ((long)ntasks * 16 <= 2048) return 4;
   return 8;
 }
+int msm_tblw_parts(int wpw) { return 64 / wpw; }
 void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, hipStream_t s) {
   if (ntasks <= 0) return;
   const dim3 grid(ntasks * (64 / wpw)), block(64);
   switch (wpw) {
-    case 64: CPX_LAUNCH(k_msm_tblw<64>, grid, block, tbw_lds(64), s, d_tasks, d_part); break;
-    case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, tbw_lds(32), s, d_tasks, d_part); break;
-    case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, tbw_lds(16), s, d_tasks, d_part); break;
-    case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, tbw_lds(4), s, d_tasks, d_part); break;
-    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, tbw_lds(2), s, d_tasks, d_part); break;
-    default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, tbw_lds(8), s, d_tasks, d_part); break;
+    case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
+    case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
+    case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
+    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
+    default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
   }
 }
 int msm_fix_windows_per_wave(int ntasks, int cbits) {

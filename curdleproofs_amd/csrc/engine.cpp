@@ -403,6 +403,18 @@ static const char* tblw_kernel_name(int wpw) {
   }
 }
 
+// raw lane accumulators of the MSM waves (kernels.h) and their reduction to partial sums in d_tpart_
+void Engine::ensure_raw_sets(size_t nsets) {
+  d_raw_.ensure(std::max<size_t>(nsets, 1) * raw_set_words());
+  d_rawslot_.ensure(std::max<size_t>(nsets, 1));
+  d_rawmid_.ensure(std::max<size_t>(nsets, 1) * 16);
+}
+void Engine::reduce_sets(bool weighted, size_t nsets) {
+  tick("k_reduce_sets", 0, (double)nsets, true);   // two launches (groups of 8 lanes, then the groups of a set)
+  launch_reduce_sets(weighted, d_raw_.p, d_rawslot_.p, (int)nsets, d_rawmid_.p, d_tpart_.p, stream_);
+  tock();
+}
+
 // Table-backed MSM phase: every request is one work-group of k_msm_tbl; results are normalised + compressed.
 void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out) {
   const size_t nt = reqs.size();
@@ -514,15 +526,18 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_pfirst_.p, hp, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  ensure_raw_sets(std::max(nft * fix_parts, ntt * tbl_parts));
   if (nft) {
     tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * pts_fix, pts_fix);
-    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
+    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     tock();
+    reduce_sets(false, nft * fix_parts);
   }
   if (ntt) {
     tick(tblw_kernel_name(tbl_wpw), 128.0 * pts_tbl, pts_tbl);
-    launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_tpart_.p, stream_);
+    launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_raw_.p, d_rawslot_.p, stream_);
     tock();
+    reduce_sets(true, ntt * tbl_parts);
   }
   tick("k_finalize_ranges", 0, (double)nt);
   launch_finalize_ranges(d_tpart_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_, any_add ? d_padd_.p : nullptr);
@@ -612,7 +627,7 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
       CPX_HIP(hipMemcpy(d_row.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
       DevBuf<TblTmp> tmp;   // build scratch, released afterwards
       tmp.ensure(NC * (size_t)(copies_ - 1));
-      launch_table_build(d_row.p, 0, tab->ctab.p, 1, 0, (int)NC, (int)NC, copies_, tmp.p, stream_);
+      launch_table_build(d_row.p, 0, tab->ctab.p, 1, 0, (int)NC, (int)NC, copies_, true, tmp.p, stream_);
       CPX_HIP(hipStreamSynchronize(stream_));
       if (want_fix) {
         // multiples m * 2^(c w) * P, m <= 2^(c-1): shifted copies first, then the multiples
@@ -620,7 +635,7 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
         const size_t M = size_t(1) << (want_fix - 1);
         DevBuf<TAff> d_shift;
         d_shift.ensure((size_t)W * NC);
-        launch_table_build(d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, tmp.p, stream_);
+        launch_table_build(d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, false, tmp.p, stream_);
         tab->fixtab.ensure((size_t)W * M * NC);
         const int chunk = (int)std::min<size_t>(256, M);
         const size_t threads = ((size_t)W * NC + 63) / 64 * 64;
@@ -827,7 +842,7 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
     const size_t NP = np();
     d_ptab_.ensure(batch * (size_t)copies_ * NP);
     d_psrc_.ensure(batch * NP);
-    d_tbltmp_.ensure(batch * NP * (size_t)(copies_ - 1));
+    d_tbltmp_.ensure(batch * NP * (size_t)(copies_ / 2 - 1));   // build scratch: the 15 doubled copies of every point
     tails.assign(batch * 8, Aff::identity());
     for (size_t p = 0; p < batch; p++) tails[8 * p + 2] = tails[8 * p + 7] = crs_single_[0];
     const size_t spitch = NP * sizeof(Aff);
@@ -1370,7 +1385,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     launch_finalize(d_Mjac_.p, (int)B, d_psrc_.p, d_dst_.p, d_mcomp_.p, stream_);
     transcript_prefix_async(B);   // side stream: k_transcript_step1 + copies of its outputs and of the compressed bytes
     tick("k_table_build", 0, (double)(B * NP));
-    launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, d_tbltmp_.p, stream_);
+    launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
     tock();
     const uint8_t* mcomp = h_mcomp_.p;
     const bool dev_prefix = device_prefix(B);
@@ -2253,7 +2268,9 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_big_idx_.p, hi, b_idx, hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, sizeof(FixTask), hipMemcpyHostToDevice, stream_));
-    launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
+    ensure_raw_sets(fix_parts);
+    launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
+    reduce_sets(false, fix_parts);
     tick("big_msm", 128.0 * N, (double)N, true);
     launch_big_msm(plan, d_pp_.p, d_big_idx_.p, d_scal_.p, N, d_conv_.p, d_big_keys_.p, d_big_vals_.p, d_big_temp_.p, d_big_bounds_.p, d_big_buckets_.p,
                    d_tpart_.p, fix_parts, d_res_.p, stream_);
@@ -2307,8 +2324,10 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
     tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * n * B,
          (double)(n * B));
-    launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_tpart_.p, stream_);
+    ensure_raw_sets(B * fix_parts);
+    launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     tock();
+    reduce_sets(false, B * fix_parts);
     tick("k_msm_accw", 128.0 * NPT * B, (double)(NPT * B));
     launch_msm_accum(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_wsum_.p, stream_);
     tock();

@@ -181,6 +181,8 @@ class Engine {
 
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
   void run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out);
+  void ensure_raw_sets(size_t nsets);
+  void reduce_sets(bool weighted, size_t nsets);
   void verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid);
   void batch_prove_fold(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   void batch_prove_tables(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
@@ -239,7 +241,7 @@ class Engine {
   uint8_t crs_H_comp_[48];
 
   // shifted-base tables (all-MSM prover)
-  static constexpr int copies_ = 32;   // table copies per base: 2^(8c) P, one per radix-256 window
+  static constexpr int copies_ = 32;   // table copies per base: 2^(8c) P and z^2 2^(8c) P, c < 16: one per radix-256 window of the split scalar
   bool use_tables_ = true;
   // CRS tables are immutable once built and large (15 GB at ell = 252): engines on the same device that are
   // given the same CRS share one copy (process-wide registry in engine.cpp).
@@ -253,6 +255,8 @@ class Engine {
   const TAff* ctab() const { return crs_tab_ ? crs_tab_->ctab.p : nullptr; }
   const TAff* fixtab() const { return crs_tab_ ? crs_tab_->fixtab.p : nullptr; }
   DevBuf<TAff> d_ptab_;      // per-proof tables [B][copies][NP]
+  DevBuf<uint32_t> d_raw_, d_rawslot_;   // raw lane accumulators of k_msm_tblw / k_msm_fix and their partial-sum slots
+  DevBuf<TJac> d_rawmid_;                // group sums between the two reduction launches
   DevBuf<Aff> d_psrc_;       // their standard-form sources [B][NP] : M | T_b | U_b
   DevBuf<TblTmp> d_tbltmp_;
   DevBuf<TblTask> d_ttasks_;

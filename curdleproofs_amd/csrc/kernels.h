@@ -36,8 +36,9 @@ struct SmulTask {
 
 // ---- table-backed MSM (no doubling tails) ----
 // Tables and partial sums are in the table kernels' representation (tarith.cuh: TAff / TJac, 28-bit limbs).
-// A table holds, for every base point P_i, the affine copies 2^(8c) * P_i, c = 0..31, copy-major: entry (c, i)
-// at base + c*copy_stride + i.  Every radix-256 window of a scalar has its own copy, so all window sums carry
+// A table holds, for every base point P_i, 32 affine copies, copy-major (entry (c, i) at base + c*copy_stride + i):
+// 2^(8c) * P_i for c = 0..15 and z^2 * 2^(8(c-16)) * P_i = -phi(2^(8(c-16)) P_i) for c = 16..31.  A scalar is split as
+// k = +-(+-|t| + q z^2) (glv.cuh); every radix-256 window of |t| and of q has its own copy, so all window sums carry
 // weight 1 and no doubling is left in the MSM.
 struct TblSeg {
   const TAff* base;         // copy 0
@@ -55,14 +56,21 @@ struct TblTmp {   // table-build scratch: a Jacobian copy and the running produc
   TJac p;
   TF pre;
 };
-// single-wave work-groups owning wpw (2 .. 32) windows and one half of the bucket magnitudes each: 64 / wpw per task
-// -> d_part[task.pad + j], j < 64 / wpw
+// single-wave work-groups owning wpw (2 .. 32) windows each: 32 / wpw waves per task, two raw sets per wave
+// -> partial sums d_part[task.pad + j], j < 64 / wpw
 int msm_tblw_windows_per_wave(int ntasks);
 int msm_tblw_parts(int wpw);   // waves (= partial sums) per task
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, hipStream_t s);
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
+// The MSM waves of k_msm_tblw / k_msm_fix leave their 64 lane accumulators as "raw sets" (raw_set_words() 32-bit words
+// each; tblw: 2 sets per wave, fix: 1) plus the partial-sum slot every set belongs to; launch_reduce_sets turns them
+// into d_part[slot] (weighted: bucket sets of k_msm_tblw, plain: k_msm_fix).
+size_t raw_set_words();
+void launch_reduce_sets(bool weighted, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nsets, TJac* d_mid, TJac* d_part, hipStream_t s);   // d_mid: 16 * nsets scratch
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
-void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
+// endo = false: copy c = 2^(256 c / C) P.   endo = true (the tables k_msm_tblw reads): copies 0..C/2-1 = 2^(8c) P and
+// copies C/2.. = their endomorphism images -phi(2^(8c) P) = z^2 2^(8c) P (glv.cuh) — half the doublings.
+void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
                         TblTmp* d_tmp, hipStream_t s);
 
 // ---- fixed-base MSM over a table of multiples (CRS bases) ----
@@ -79,7 +87,7 @@ struct FixTask {
   uint32_t out_first;       // first partial slot of this task; it writes W / wpw partials
 };
 int msm_fix_windows_per_wave(int ntasks, int cbits);
-void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, TJac* d_part, hipStream_t s);
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
 // shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
 // output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)

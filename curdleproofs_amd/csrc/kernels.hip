@@ -29,6 +29,7 @@
 #include "tarith.cuh"
 #include "strobe.cuh"
 #include "recode.cuh"
+#include "glv.cuh"
 #include "kernels.h"
 
 namespace cpx {
@@ -203,152 +204,90 @@ __global__ __launch_bounds__(64, 2) void k_msm_accw(const MsmTask* __restrict__ 
   if (b == 0) wsum[(size_t)(blockIdx.x >> 3) * 64 + w8 * 8 + wl] = acc;
 }
 
-// ------------------------------------------------------------------ table-backed MSM, barrier-free single-wave groups
-// 32-copy tables: every radix-256 window of a scalar has its own pre-shifted copy 2^(8c) P of the base, so ALL window
-// sums carry weight 1 and a bucket may collect additions from any window: one (scalar, base) pair costs 32 mixed
-// additions, the 128 bucket magnitudes of the signed digits are the only reduction.  (Radix 16 with 64 copies — the
-// previous layout — paid 60 additions per pair.)
-// A single-wave work-group owns WPW consecutive windows of one task and one HALF of the magnitudes: lane l of half h
-// owns bucket |d| = 64 h + l + 1.  With a hit rate of 1/128 per (window, point) pair a lane cannot scan for its
-// digits; the wave sorts instead: every lane recodes one scalar of a 64-point slab, a histogram over the 64
-// magnitudes (LDS atomics) gives the list offsets, a second pass scatters 16-bit (point, window, sign) entries into
-// per-bucket lists in LDS, and every lane then walks its own list — gather the pre-shifted point from the table in
-// HBM/L2, add.  A round takes as many slabs as fit the list (8704 entries = a whole 512-point task of the ell = 252
-// prover), so the slowest lane is decided over the whole task (Binomial(16384, 1/128): ~155 against a mean of 128),
-// not per slab.  Waves never wait for each other and the CU scheduler backfills a finished wave's slot.
-// Reduction per wave: suffix scan over the 64 buckets (6 additions) + tree sum (6) = sum_l (l+1) B_l, plus 64 times
-// the plain sum for the upper half.  Output: one partial sum per wave; k_finalize_ranges adds the partials of a
-// request.
-constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
-constexpr int TBW_CAP = 8704;         // list entries per round
-constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index
-constexpr int TBW_LDS = TBW_CAP * 2 + 2 * 64 * 4;
-static_assert(TBW_CAP * 2 >= 65 * (int)sizeof(TJac), "the reduction buffer aliases the lists");
-static_assert(TBW_CAP >= 64 * TBW_WINDOWS, "one slab always fits");
+// ------------------------------------------------------------------ lane accumulators -> partial sums
+// The MSM waves below do not reduce their 64 lane accumulators themselves: an in-wave reduction is a chain of 6-12
+// DEPENDENT point additions during which most lanes idle (a quarter of k_msm_fix's time, a third of k_msm_tblw's at
+// the 128-point tasks of the ell = 252 prover).  They store the raw accumulators ("sets" of 64 extended-Jacobian
+// points, 224 B each) and k_reduce_sets adds them up with
+// every lane busy: 8 threads per set sum 8 entries each (k_reduce_sets), one thread per set combines the 8 group
+// results (k_reduce_groups).
+//   plain    (k_msm_fix):  sum_l A_l
+//   weighted (k_msm_tblw): lane l of set 2k + h holds bucket |d| = 64 h + l + 1  ->  sum_l (64 h + l + 1) A_l,
+//            as running sums per group of 8 (W_g = sum_j (j+1) A_{8g+j}, S_g = sum_j A_{8g+j}) and once more over
+//            the groups: sum_g W_g + 8 sum_g g S_g + 64 h sum_g S_g.
+constexpr int ACC_WORDS = (int)(sizeof(TAcc) / 4);   // 56
+constexpr int RAW_SET_WORDS = ACC_WORDS * 64;
+__device__ __forceinline__ void raw_store(uint32_t* __restrict__ set, int lane, const TAcc& a) { reinterpret_cast<TAcc*>(set)[lane] = a; }
+__device__ __forceinline__ TAcc raw_load(const uint32_t* __restrict__ set, int lane) { return reinterpret_cast<const TAcc*>(set)[lane]; }
 
-__device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
-  const uint32_t n0 = t.seg[0].n;
-  const TblSeg& sg = (g < n0) ? t.seg[0] : t.seg[1];
-  const uint32_t i = (g < n0) ? g : g - n0;
-  return sg.base + (size_t)copy * sg.copy_stride + (sg.idx ? sg.idx[i] : i);
-}
-
-// Signed radix-256 digits of windows [w0, w0 + WPW) of scalar i, biased by 128 and packed four per word: byte w of
-// k + 0x8080...80 (one 256-bit addition) is d_w + 128 with d_w in [-128, 127] and sum d_w 256^w = k.  No carry leaves
-// the top byte: scalars are < r < 2^255 and r's top byte is 0x73.
-template <int WPW> __device__ __forceinline__ void tbw_digits(const TblTask& task, uint32_t i, int w0, uint32_t (&dg)[(WPW + 3) / 4]) {
-  Fr k = task.scalars[i];
-  if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
-  uint32_t carry = 0;
-  CPX_UNROLL for (int w = 0; w < 8; w++) {
-    const uint64_t t = (uint64_t)k.v[w] + 0x80808080u + carry;
-    carry = (uint32_t)(t >> 32);
-    const uint32_t kw = (uint32_t)t;
-    CPX_UNROLL for (int q = 0; q < (WPW + 3) / 4; q++)
-      if (w == (w0 >> 2) + q) dg[q] = kw;
+// Two launches so that no lane idles while a few finish: level 1 = thread per (set, group of 8 lanes), level 2 = thread
+// per set over the 8 group results (mid: [set][8] x {S, W}).
+template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_sets(const uint32_t* __restrict__ raw, int nsets, TJac* __restrict__ mid) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= nsets * 8) return;
+  const int set = t >> 3, g = t & 7;
+  const uint32_t* rs = raw + (size_t)set * RAW_SET_WORDS;
+  TJac run = t_acc_to_jac(raw_load(rs, g * 8 + 7));
+  TJac w = run;
+  for (int j = 6; j >= 0; j--) {
+    run = t_add(run, t_acc_to_jac(raw_load(rs, g * 8 + j)));
+    if (WEIGHTED) w = t_add(w, run);
   }
-  if (WPW < 4) dg[0] >>= 8 * (w0 & 3);
+  mid[(size_t)t * (WEIGHTED ? 2 : 1)] = run;
+  if (WEIGHTED) mid[(size_t)t * 2 + 1] = w;
 }
-// bucket of window j within magnitude half h (>= 64: not in this half, or digit 0) and the sign of the digit
-__device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, int h, uint32_t& neg) {
-  const int d = (int)((word >> (8 * (j & 3))) & 255u) - 128;
-  neg = d < 0 ? 1u : 0u;
-  return (uint32_t)((d < 0 ? -d : d) - 1 - 64 * h);
+template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_groups(const TJac* __restrict__ mid, const uint32_t* __restrict__ slot, int nsets,
+                                                                              TJac* __restrict__ part) {
+  const int set = blockIdx.x * 64 + threadIdx.x;
+  if (set >= nsets) return;
+  const TJac* m = mid + (size_t)set * 8 * (WEIGHTED ? 2 : 1);
+  if (!WEIGHTED) {
+    TJac run = m[7];
+    for (int k = 6; k >= 0; k--) run = t_add(run, m[k]);
+    part[slot[set]] = run;
+    return;
+  }
+  TJac run = m[2 * 7];                          // S_7
+  TJac v = run;
+  for (int k = 6; k >= 1; k--) {
+    run = t_add(run, m[2 * k]);
+    v = t_add(v, run);
+  }
+  run = t_add(run, m[0]);                       // run = sum_g S_g, v = sum_g g S_g
+  for (int d = 0; d < 3; d++) v = t_dbl(v);     // 8 v
+  for (int k = 0; k < 8; k++) v = t_add(v, m[2 * k + 1]);
+  if (set & 1) {                                // upper half of the magnitudes
+    for (int d = 0; d < 6; d++) run = t_dbl(run);
+    v = t_add(v, run);
+  }
+  part[slot[set]] = v;
 }
 
-template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, TJac* __restrict__ part) {
-  constexpr int WV = 2 * TBW_WINDOWS / WPW;   // waves per task: window groups x magnitude halves
-  constexpr int NW = (WPW + 3) / 4;
+// Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per set, the classic tree — suffix
+// scan (weighted sets) + tree sum, 6 + 6 dependent additions instead of the ~40 of the work-efficient form above.
+template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_sets_wave(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ slot, int nsets,
+                                                                                 TJac* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint16_t* list = reinterpret_cast<uint16_t*>(smem);                 // [TBW_CAP]
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + TBW_CAP * 2);    // [64] bucket sizes of the round
-  uint32_t* cur = cnt + 64;                                           // [64] scatter cursors
-  TJac* red = reinterpret_cast<TJac*>(smem);                          // [64] (aliases the lists afterwards)
-  const TblTask task = tasks[blockIdx.x / WV];
-  const int wv = blockIdx.x % WV, h = wv & 1, w0 = (wv >> 1) * WPW;
-  const int lane = threadIdx.x;
-  const uint32_t ntot = task.seg[0].n + task.seg[1].n;
-  TAcc xacc = TAcc::identity();
-
-  uint32_t next = 0;
-  while (next < ntot) {
-    cnt[lane] = 0;
-    __syncthreads();
-    // histogram over as many 64-point slabs as fit the list
-    uint32_t total = 0, end = next;
-    while (end < ntot && end - next + 64 <= (uint32_t)TBW_ROUND_PTS) {
-      const uint32_t i = end + lane;
-      uint32_t dg[NW];
-      int mine = 0;
-      if (i < ntot) {
-        tbw_digits<WPW>(task, i, w0, dg);
-        CPX_UNROLL for (int j = 0; j < WPW; j++) {
-          uint32_t neg;
-          mine += tbw_bucket(dg[j >> 2], j, h, neg) < 64u ? 1 : 0;
-        }
-      }
-      int ct = mine;
-      CPX_UNROLL for (int m = 32; m >= 1; m >>= 1) ct += __shfl_xor(ct, m, 64);
-      if (total && total + (uint32_t)ct > (uint32_t)TBW_CAP) break;
-      if (i < ntot) {
-        CPX_UNROLL for (int j = 0; j < WPW; j++) {
-          uint32_t neg;
-          const uint32_t b = tbw_bucket(dg[j >> 2], j, h, neg);
-          if (b < 64u) atomicAdd(&cnt[b], 1u);
-        }
-      }
-      total += (uint32_t)ct;
-      end = min(end + 64, ntot);
-    }
-    __syncthreads();
-    // list offsets: exclusive scan of the bucket sizes over the wave
-    const uint32_t mycnt = cnt[lane];
-    uint32_t incl = mycnt;
-    CPX_UNROLL for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
-      if (lane >= d) incl += y;
-    }
-    const uint32_t off = incl - mycnt;
-    cur[lane] = off;
-    __syncthreads();
-    for (uint32_t c0 = next; c0 < end; c0 += 64) {
-      const uint32_t i = c0 + lane;
-      if (i < end) {
-        uint32_t dg[NW];
-        tbw_digits<WPW>(task, i, w0, dg);
-        CPX_UNROLL for (int j = 0; j < WPW; j++) {
-          uint32_t neg;
-          const uint32_t b = tbw_bucket(dg[j >> 2], j, h, neg);
-          if (b < 64u) list[atomicAdd(&cur[b], 1u)] = (uint16_t)(((i - next) << 6) | ((uint32_t)j << 1) | neg);
-        }
-      }
-    }
-    __syncthreads();
-    for (uint32_t k = off; k < off + mycnt; k++) {
-      const uint32_t e = list[k];
-      const TAff q = *tbl_point(task, next + (e >> 6), (uint32_t)w0 + ((e >> 1) & 31u));
-      xacc = t_acc_add_mixed(xacc, t_cneg(q, (e & 1u) != 0));
-    }
-    __syncthreads();
-    next = end;
-  }
-  TJac acc = t_acc_to_jac(xacc);
-  __syncthreads();
+  TJac* red = reinterpret_cast<TJac*>(smem);   // [65]
+  const int set = blockIdx.x, lane = threadIdx.x;
+  TJac acc = t_acc_to_jac(raw_load(raw + (size_t)set * RAW_SET_WORDS, lane));
   red[lane] = acc;
   __syncthreads();
-  for (int sft = 1; sft < 64; sft <<= 1) {          // suffix sums S_l = B_l + ... + B_63
-    const bool has = lane + sft < 64;
-    TJac other;
-    if (has) other = red[lane + sft];
-    __syncthreads();
-    if (has) {
-      acc = t_add(acc, other);
-      red[lane] = acc;
+  if (WEIGHTED) {
+    for (int sft = 1; sft < 64; sft <<= 1) {        // suffix sums S_l = A_l + ... + A_63
+      const bool has = lane + sft < 64;
+      TJac other;
+      if (has) other = red[lane + sft];
+      __syncthreads();
+      if (has) {
+        acc = t_add(acc, other);
+        red[lane] = acc;
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    if (lane == 0) red[64] = acc;                   // the plain sum
   }
-  if (lane == 0) red[64] = acc;                     // the plain sum of the 64 buckets (spare slot behind the tree's)
-  for (int sft = 32; sft >= 1; sft >>= 1) {         // ... summed: sum_l (l + 1) B_l in lane 0
+  for (int sft = 32; sft >= 1; sft >>= 1) {         // tree sum (of the suffix sums: sum_l (l + 1) A_l)
     const bool has = lane < sft;
     TJac other;
     if (has) other = red[lane + sft];
@@ -360,13 +299,165 @@ template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const Tbl
     __syncthreads();
   }
   if (lane == 0) {
-    if (h) {                                        // upper half: bucket magnitudes are 64 + (l + 1)
+    if (WEIGHTED && (set & 1)) {                    // upper half: magnitudes 64 + (l + 1)
       TJac plain = red[64];
-      for (int s = 0; s < 6; s++) plain = t_dbl(plain);
+      for (int d = 0; d < 6; d++) plain = t_dbl(plain);
       acc = t_add(acc, plain);
     }
-    part[task.pad + wv] = acc;   // task.pad = first partial slot of the task
+    part[slot[set]] = acc;
   }
+}
+
+// ------------------------------------------------------------------ table-backed MSM, barrier-free single-wave groups
+// 32-copy tables: every radix-256 window of a scalar has its own pre-shifted copy 2^(8c) P of the base, so ALL window
+// sums carry weight 1 and a bucket may collect additions from any window: one (scalar, base) pair costs 32 mixed
+// additions, the 128 bucket magnitudes of the signed digits are the only reduction.  (Radix 16 with 64 copies — the
+// previous layout — paid 60 additions per pair.)
+// A single-wave work-group owns WPW consecutive windows of one task; lane l owns the two buckets |d| = l + 1 and
+// |d| = 64 + l + 1.  With a hit rate of 1/128 per (window, point) pair a lane cannot scan for its digits; the wave
+// sorts instead: every lane recodes one scalar of a 64-point slab, a histogram over the 128 magnitudes (LDS atomics)
+// gives the list offsets, a second pass scatters 16-bit (point, window, sign) entries into per-bucket lists in LDS
+// (bucket l and bucket 64 + l adjacent), and every lane then walks its two lists in ONE loop — gather the pre-shifted
+// point from the table in HBM/L2, add; at the boundary it parks the first accumulator in the raw-set buffer — so the
+// slowest lane is decided over both buckets and all windows (128 points x 32 windows: mean 64 additions, max ~83).
+// A round takes as many slabs as fit the list (8704 entries = 256 points x 32 windows); later rounds of a longer task
+// reload the parked accumulators.  Waves never wait for each other and the CU scheduler backfills a finished wave's
+// slot.  Output: two raw sets per wave (k_reduce_sets turns them into two partial sums, k_finalize_ranges adds the
+// partials of a request).
+constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
+constexpr int TBW_CAP = 8704;         // list entries per round
+constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index
+constexpr int TBW_LDS = TBW_CAP * 2 + 2 * 128 * 4;
+static_assert(TBW_CAP >= 64 * TBW_WINDOWS, "one slab always fits");
+
+__device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
+  const uint32_t n0 = t.seg[0].n;
+  const TblSeg& sg = (g < n0) ? t.seg[0] : t.seg[1];
+  const uint32_t i = (g < n0) ? g : g - n0;
+  return sg.base + (size_t)copy * sg.copy_stride + (sg.idx ? sg.idx[i] : i);
+}
+
+// Signed radix-256 digits of windows [w0, w0 + WPW) of scalar i, biased by 128 and packed four per word.  The scalar
+// is split by the endomorphism first (glv.cuh): k = +-(+-|t| + q z^2), windows 0..15 are the digits of |t| (table copies
+// 2^(8c) P), windows 16..31 those of q (table copies -phi(2^(8c) P) = z^2 2^(8c) P); sg_lo / sg_hi are the signs the
+// two halves carry.
+template <int WPW> __device__ __forceinline__ void tbw_digits(const TblTask& task, uint32_t i, int w0, uint32_t (&dg)[(WPW + 3) / 4], uint32_t& sg_lo,
+                                                              uint32_t& sg_hi) {
+  Fr k = task.scalars[i];
+  if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
+  uint32_t t[4], q[4], bytes[8], nk, nt;
+  glv_split(k.v, t, q, nk, nt);
+  glv_biased_bytes(t, bytes);
+  glv_biased_bytes(q, bytes + 4);
+  sg_lo = nk ^ nt;
+  sg_hi = nk;
+  CPX_UNROLL for (int w = 0; w < 8; w++) {
+    CPX_UNROLL for (int x = 0; x < (WPW + 3) / 4; x++)
+      if (w == (w0 >> 2) + x) dg[x] = bytes[w];
+  }
+  if (WPW < 4) dg[0] >>= 8 * (w0 & 3);
+}
+// list position class of window j's digit: 2 * (|d| - 1 mod 64) + (|d| > 64), or >= 128 for a zero digit
+__device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, uint32_t& neg) {
+  const int d = (int)((word >> (8 * (j & 3))) & 255u) - 128;
+  neg = d < 0 ? 1u : 0u;
+  const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
+  return b < 128u ? 2u * (b & 63u) + (b >> 6) : 128u;
+}
+
+template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot) {
+  constexpr int WV = TBW_WINDOWS / WPW;   // waves per task
+  constexpr int NW = (WPW + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint16_t* list = reinterpret_cast<uint16_t*>(smem);                 // [TBW_CAP]
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + TBW_CAP * 2);    // [128] bucket sizes of the round
+  uint32_t* cur = cnt + 128;                                          // [128] scatter cursors
+  const TblTask task = tasks[blockIdx.x / WV];
+  const int wv = blockIdx.x % WV, w0 = wv * WPW;
+  const int lane = threadIdx.x;
+  const uint32_t ntot = task.seg[0].n + task.seg[1].n;
+  uint32_t* raw0 = raw + (size_t)blockIdx.x * 2 * RAW_SET_WORDS;
+  uint32_t* raw1 = raw0 + RAW_SET_WORDS;
+  if (lane < 2) raw_slot[blockIdx.x * 2 + lane] = task.pad + 2 * wv + lane;   // task.pad = first partial slot of the task
+
+  uint32_t next = 0;
+  bool later = false;   // a later round: the accumulators are parked in raw0 / raw1
+  do {
+    cnt[lane] = 0;
+    cnt[64 + lane] = 0;
+    __syncthreads();
+    // histogram over as many 64-point slabs as fit the list
+    uint32_t total = 0, end = next;
+    while (end < ntot && end - next + 64 <= (uint32_t)TBW_ROUND_PTS) {
+      const uint32_t i = end + lane;
+      uint32_t dg[NW], sg_lo, sg_hi;
+      int mine = 0;
+      if (i < ntot) {
+        tbw_digits<WPW>(task, i, w0, dg, sg_lo, sg_hi);
+        CPX_UNROLL for (int j = 0; j < WPW; j++) {
+          uint32_t neg;
+          mine += tbw_bucket(dg[j >> 2], j, neg) < 128u ? 1 : 0;
+        }
+      }
+      int ct = mine;
+      CPX_UNROLL for (int m = 32; m >= 1; m >>= 1) ct += __shfl_xor(ct, m, 64);
+      if (total && total + (uint32_t)ct > (uint32_t)TBW_CAP) break;
+      if (i < ntot) {
+        CPX_UNROLL for (int j = 0; j < WPW; j++) {
+          uint32_t neg;
+          const uint32_t b = tbw_bucket(dg[j >> 2], j, neg);
+          if (b < 128u) atomicAdd(&cnt[b], 1u);
+        }
+      }
+      total += (uint32_t)ct;
+      end = min(end + 64, ntot);
+    }
+    __syncthreads();
+    // list offsets: exclusive scan of the lanes' two bucket sizes over the wave
+    const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
+    uint32_t incl = c0 + c1;
+    CPX_UNROLL for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    const uint32_t off = incl - (c0 + c1);
+    cur[2 * lane] = off;
+    cur[2 * lane + 1] = off + c0;
+    __syncthreads();
+    for (uint32_t s0 = next; s0 < end; s0 += 64) {
+      const uint32_t i = s0 + lane;
+      if (i < end) {
+        uint32_t dg[NW], sg_lo, sg_hi;
+        tbw_digits<WPW>(task, i, w0, dg, sg_lo, sg_hi);
+        CPX_UNROLL for (int j = 0; j < WPW; j++) {
+          uint32_t neg;
+          const uint32_t b = tbw_bucket(dg[j >> 2], j, neg);
+          neg ^= (w0 + j < 16) ? sg_lo : sg_hi;
+          if (b < 128u) list[atomicAdd(&cur[b], 1u)] = (uint16_t)(((i - next) << 6) | ((uint32_t)j << 1) | neg);
+        }
+      }
+    }
+    __syncthreads();
+    TAcc xacc = later ? raw_load(raw0, lane) : TAcc::identity();
+    const uint32_t cboth = c0 + c1;
+    for (uint32_t k = 0; k < cboth; k++) {
+      if (k == c0) {   // first bucket done: park it, go on with the second
+        raw_store(raw0, lane, xacc);
+        xacc = later ? raw_load(raw1, lane) : TAcc::identity();
+      }
+      const uint32_t e = list[off + k];
+      const TAff q = *tbl_point(task, next + (e >> 6), (uint32_t)w0 + ((e >> 1) & 31u));
+      xacc = t_acc_add_mixed(xacc, t_cneg(q, (e & 1u) != 0));
+    }
+    if (c1 == 0) {
+      raw_store(raw0, lane, xacc);
+      xacc = later ? raw_load(raw1, lane) : TAcc::identity();
+    }
+    raw_store(raw1, lane, xacc);
+    __syncthreads();
+    next = end;
+    later = true;
+  } while (next < ntot);
 }
 
 // ------------------------------------------------------------------ fixed-base MSM over multiples tables
@@ -392,13 +483,12 @@ template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint3
 // task) keeps the fixed 6-step tree reduction small against the per-lane additions (n/4 per lane); 8 windows
 // per wave double the number of waves when the launch would not fill the GPU otherwise.
 template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TAff* __restrict__ tab, int nc,
-                                                                     TJac* __restrict__ part) {
+                                                                     uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot) {
   constexpr int W = 256 / CB, WG = W / FIX_WPW;    // waves per task
   constexpr int LPW = 64 / FIX_WPW;                // lanes (point slices) per window
   constexpr uint32_t M = 1u << (CB - 1);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int16_t* digits = reinterpret_cast<int16_t*>(smem);   // [FIX_WPW][FIX_CHUNK]
-  TJac* red = reinterpret_cast<TJac*>(smem);            // [64] afterwards
   const FixTask task = tasks[blockIdx.x / WG];
   const int wg = blockIdx.x % WG;
   const int lane = threadIdx.x;
@@ -430,22 +520,9 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
       if (d1) xacc = t_acc_add_mixed(xacc, t_cneg(p1, d1 < 0));
     }
   }
-  TJac acc = t_acc_to_jac(xacc);
-  __syncthreads();
-  red[lane] = acc;
-  __syncthreads();
-  for (int sft = 32; sft >= 1; sft >>= 1) {   // plain tree: all entries carry weight 1
-    const bool has = lane < sft;
-    TJac other;
-    if (has) other = red[lane + sft];
-    __syncthreads();
-    if (has) {
-      acc = t_add(acc, other);
-      red[lane] = acc;
-    }
-    __syncthreads();
-  }
-  if (lane == 0) part[task.out_first + wg] = acc;
+  // all entries carry weight 1: the wave's 64 accumulators form one plain raw set (k_reduce_sets adds them up)
+  raw_store(raw + (size_t)blockIdx.x * RAW_SET_WORDS, lane, xacc);
+  if (lane == 0) raw_slot[blockIdx.x] = task.out_first + wg;
 }
 
 // Table of multiples from the shifted copies: thread per (window, base) walks m = 1..M with mixed additions and
@@ -592,14 +669,17 @@ __device__ __forceinline__ void tmp_load(const uint32_t* tmp, size_t nthreads, s
 // of 256 - sb doublings storing every sb-th value; the C-1 Jacobian copies are normalised with the thread's own
 // Montgomery trick plus one inversion per work-group.
 __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
-                                                     int npts, int copy_stride, int copies, TblTmp* __restrict__ tmp_) {
+                                                     int npts, int copy_stride, int copies, int endo, TblTmp* __restrict__ tmp_) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);
   uint32_t* tmp = reinterpret_cast<uint32_t*>(tmp_);
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)rows * npts;
   const bool live = g < total;
-  const int sb = 256 / copies;
+  // endo: the row holds copies / 2 shifted copies 2^(8c) P followed by their images -phi(.) = (beta x, -y) (glv.cuh)
+  const int real = endo ? copies / 2 : copies;
+  const int sb = (endo ? 128 : 256) / real;
+  const TF beta = t_beta();
   TAff* col = nullptr;
   TF prod = t_one();
   bool inf = true;
@@ -611,9 +691,10 @@ __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src
     const TAff P = t_from_std(src[r * src_row_stride + i]);
     col[0] = P;
     inf = P.is_identity();
+    if (endo) col[(size_t)real * copy_stride] = inf ? P : TAff{t_mul(P.x, beta), t_neg(P.y)};
     if (!inf) {
       TJac acc = TJac::from_affine(P);
-      for (int c = 1; c < copies; c++) {
+      for (int c = 1; c < real; c++) {
         for (int s = 0; s < sb; s++) acc = t_dbl(acc);
         tmp_store(tmp, (size_t)total, (size_t)g, c - 1, acc, prod);   // prod = z_1 ... z_{c-1}
         prod = t_mul(prod, acc.z);
@@ -622,7 +703,7 @@ __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src
   }
   TF inv = t_block_batch_inverse(prod, buf);   // 1 / (z_1 ... z_{C-1})
   if (!live) return;
-  for (int c = copies - 1; c >= 1; c--) {
+  for (int c = real - 1; c >= 1; c--) {
     TAff a = TAff::identity();
     if (!inf) {
       TJac p;
@@ -633,6 +714,7 @@ __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src
       a = t_to_affine(p, zinv);
     }
     col[(size_t)c * copy_stride] = a;
+    if (endo) col[(size_t)(real + c) * copy_stride] = inf ? a : TAff{t_mul(a.x, beta), t_neg(a.y)};
   }
 }
 
@@ -1204,7 +1286,7 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
 }
 int msm_tblw_windows_per_wave(int ntasks) {
   // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2);
-  // a task always takes 64 / wpw waves (window groups x the two magnitude halves)
+  // a task takes 32 / wpw waves, each of which leaves two raw sets (-> 64 / wpw partial sums per task)
   static const long min_waves = [] {
     const char* e = getenv("CPX_TBW_MIN_WAVES");
     return e ? atol(e) : 2048L;
@@ -1216,22 +1298,40 @@ int msm_tblw_windows_per_wave(int ntasks) {
   }();
   if (forced) return forced;
   for (int wpw = 32; wpw > 8; wpw >>= 1)
-    if ((long)ntasks * (64 / wpw) >= min_waves) return wpw;
+    if ((long)ntasks * (TBW_WINDOWS / wpw) >= min_waves) return wpw;
   // a few proofs in flight: latency matters, so spread a task over as many (short) waves as the GPU can hold at once
-  if ((long)ntasks * 32 <= 2048) return 2;
-  if ((long)ntasks * 16 <= 2048) return 4;
+  if ((long)ntasks * 16 <= 2048) return 2;
+  if ((long)ntasks * 8 <= 2048) return 4;
   return 8;
 }
 int msm_tblw_parts(int wpw) { return 64 / wpw; }
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, TJac* d_part, hipStream_t s) {
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
   if (ntasks <= 0) return;
-  const dim3 grid(ntasks * (64 / wpw)), block(64);
+  const dim3 grid(ntasks * (TBW_WINDOWS / wpw)), block(64);
   switch (wpw) {
-    case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
-    case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
-    case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
-    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
-    default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, TBW_LDS, s, d_tasks, d_part); break;
+    case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
+    case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
+    case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
+    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
+    default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
+  }
+}
+size_t raw_set_words() { return RAW_SET_WORDS; }
+void launch_reduce_sets(bool weighted, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nsets, TJac* d_mid, TJac* d_part, hipStream_t s) {
+  if (nsets <= 0) return;
+  if (nsets <= 2048) {   // a few proofs: wave per set
+    const size_t lds1 = 65 * sizeof(TJac);
+    if (weighted) CPX_LAUNCH(k_reduce_sets_wave<true>, dim3(nsets), dim3(64), lds1, s, d_raw, d_raw_slot, nsets, d_part);
+    else CPX_LAUNCH(k_reduce_sets_wave<false>, dim3(nsets), dim3(64), lds1, s, d_raw, d_raw_slot, nsets, d_part);
+    return;
+  }
+  const dim3 g1((nsets * 8 + 63) / 64), g2((nsets + 63) / 64), block(64);
+  if (weighted) {
+    CPX_LAUNCH(k_reduce_sets<true>, g1, block, 0, s, d_raw, nsets, d_mid);
+    CPX_LAUNCH(k_reduce_groups<true>, g2, block, 0, s, d_mid, d_raw_slot, nsets, d_part);
+  } else {
+    CPX_LAUNCH(k_reduce_sets<false>, g1, block, 0, s, d_raw, nsets, d_mid);
+    CPX_LAUNCH(k_reduce_groups<false>, g2, block, 0, s, d_mid, d_raw_slot, nsets, d_part);
   }
 }
 int msm_fix_windows_per_wave(int ntasks, int cbits) {
@@ -1247,16 +1347,16 @@ int msm_fix_windows_per_wave(int ntasks, int cbits) {
   }
   return 8;
 }
-void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, TJac* d_part, hipStream_t s) {
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
   if (ntasks <= 0) return;
-  const size_t lds = 64 * sizeof(TJac);   // 10,752 B >= 16 * FIX_CHUNK * 2 = 8,192 B of digit rows
+  const size_t lds = 16 * FIX_CHUNK * 2;   // digit rows
   const dim3 grid(ntasks * (256 / cbits / wpw)), block(64);
-  if (cbits == 16 && wpw == 16) CPX_LAUNCH((k_msm_fix<16, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
-  else if (cbits == 16 && wpw == 4) CPX_LAUNCH((k_msm_fix<16, 4>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
-  else if (cbits == 16 && wpw == 2) CPX_LAUNCH((k_msm_fix<16, 2>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
-  else if (cbits == 16) CPX_LAUNCH((k_msm_fix<16, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
-  else if (wpw == 16) CPX_LAUNCH((k_msm_fix<8, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
-  else CPX_LAUNCH((k_msm_fix<8, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_part);
+  if (cbits == 16 && wpw == 16) CPX_LAUNCH((k_msm_fix<16, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+  else if (cbits == 16 && wpw == 4) CPX_LAUNCH((k_msm_fix<16, 4>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+  else if (cbits == 16 && wpw == 2) CPX_LAUNCH((k_msm_fix<16, 2>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+  else if (cbits == 16) CPX_LAUNCH((k_msm_fix<16, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+  else if (wpw == 16) CPX_LAUNCH((k_msm_fix<8, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+  else CPX_LAUNCH((k_msm_fix<8, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
 }
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
   const int W = 256 / cbits, total = W * nc;
@@ -1274,12 +1374,12 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
   }
   CPX_LAUNCH(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
 }
-void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies,
+void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
                         TblTmp* d_tmp, hipStream_t s) {
   const long total = (long)rows * npts;
   if (total <= 0) return;
   CPX_LAUNCH(k_table_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 2 * 256 * sizeof(TF), s, d_src, src_row_stride, d_table, rows, row_stride, npts,
-                     copy_stride, copies, d_tmp);
+                     copy_stride, copies, endo ? 1 : 0, d_tmp);
 }
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
   if (n <= 0) return;

@@ -29,5 +29,7 @@ typedef Xyzz28 TAcc;
 CPX_HD TAcc t_acc_add_mixed(const TAcc& p, const TAff& q) { return xyzz28_add_mixed(p, q); }
 CPX_HD TJac t_acc_to_jac(const TAcc& p) { return xyzz28_to_jac(p); }
 CPX_HD TF t_inv(const TF& a) { return f28_inv_euclid(a); }
+CPX_HD TF t_neg(const TF& a) { return f28_neg(a); }
+CPX_HD TF t_beta() { return f28_const(F28Cfg::BETA); }   // (x, y) -> (beta x, y) is multiplication by -z^2 on G1 (glv.cuh)
 
 }  // namespace cpx

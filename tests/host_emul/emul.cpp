@@ -8,6 +8,7 @@
 #include "../../curdleproofs_amd/csrc/g1.cuh"
 #include "../../curdleproofs_amd/csrc/tarith.cuh"
 #include "../../curdleproofs_amd/csrc/modinv30.cuh"
+#include "../../curdleproofs_amd/csrc/glv.cuh"
 #include "../../curdleproofs_amd/csrc/recode.cuh"
 #include "../../curdleproofs_amd/csrc/host_math.hpp"
 
@@ -313,6 +314,25 @@ int emul_modinv30_check(const uint8_t* a, size_t n, uint8_t* first_out) {
     if (memcmp(x, y, 48) != 0) bad++;
   }
   return bad;
+}
+
+// endomorphism split of canonical scalars (glv.cuh): per scalar |t| (16 B), q (16 B), neg_k, neg_t (1 B each) and the
+// 32 biased digit bytes the table kernel derives from them
+void emul_glv_split(const uint8_t* k, size_t n, uint8_t* out) {
+  for (size_t i = 0; i < n; i++) {
+    uint32_t w[8], t[4], q[4], nk, nt, bt[4], bq[4];
+    memcpy(w, k + 32 * i, 32);
+    glv_split(w, t, q, nk, nt);
+    glv_biased_bytes(t, bt);
+    glv_biased_bytes(q, bq);
+    uint8_t* o = out + 66 * i;
+    memcpy(o, t, 16);
+    memcpy(o + 16, q, 16);
+    o[32] = (uint8_t)nk;
+    o[33] = (uint8_t)nt;
+    memcpy(o + 34, bt, 16);
+    memcpy(o + 50, bq, 16);
+  }
 }
 
 }  // extern "C"

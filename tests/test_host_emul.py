@@ -12,6 +12,7 @@ SRC = os.path.join(HERE, "host_emul", "emul.cpp")
 LIB = os.path.join(HERE, "host_emul", "_emul.so")
 CSRC = os.path.join(HERE, "..", "curdleproofs_amd", "csrc")
 P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 FR, AFF, JAC = 32, 96, 144
 
 
@@ -27,6 +28,8 @@ def emul():
     L.emul_host_fr_mul.argtypes = [vp, vp, vp, sz]
     L.emul_host_fr_inv_check.argtypes = [vp, sz]
     L.emul_modinv30_check.argtypes = [vp, sz, vp]
+    L.emul_glv_split.argtypes = [vp, sz, vp]
+    L.emul_glv_split.restype = None
     L.emul_msm.argtypes = [vp, vp, sz, vp]
     L.emul_smul.argtypes = [vp, vp, vp, vp]
     L.emul_challenges.argtypes = [vp, sz, vp]
@@ -269,3 +272,25 @@ def test_divstep_inversion_matches_euclid(emul):
         o = _o(48)
         emul.emul_modinv30_check(_b(v.to_bytes(48, "little")), 1, o)
         assert int.from_bytes(bytes(o), "little") == pow(v, -1, P)
+
+
+def test_glv_split(emul):
+    """glv.cuh: k = +-(+-|t| + q z^2) mod r with |t|, q < 2^127, and the signed radix-256 digits of both halves."""
+    import random
+    rnd = random.Random(5)
+    z2 = 0xd201000000010000 ** 2
+    vals = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, (R + 1) // 2, z2, z2 - 1, z2 + 1, z2 // 2, z2 // 2 + 1, R - z2, (R - 1) // 2 - z2 // 2,
+            (1 << 255) % R, (1 << 254), (1 << 128) - 1, 1 << 127] + [rnd.randrange(R) for _ in range(4000)] + [rnd.randrange(1 << b) for b in range(1, 255)]
+    blob = b"".join(v.to_bytes(32, "little") for v in vals)
+    out = _o(66 * len(vals))
+    emul.emul_glv_split(_b(blob), len(vals), out)
+    out = bytes(out)
+    for i, k in enumerate(vals):
+        o = out[66 * i:66 * i + 66]
+        t, q, nk, nt = int.from_bytes(o[:16], "little"), int.from_bytes(o[16:32], "little"), o[32], o[33]
+        assert t < (1 << 127) - (1 << 119) and q < (1 << 127) - (1 << 119), hex(k)
+        assert t <= z2 // 2 + 1
+        v = (-t if nt else t) + q * z2
+        assert (-v if nk else v) % R == k, hex(k)
+        for half, val in ((o[34:50], t), (o[50:66], q)):
+            assert sum((b - 128) << (8 * w) for w, b in enumerate(half)) == val

@@ -342,6 +342,12 @@ def main():
                                 mulmods_per_point=mulmods_per_point,
                                 note="kernel time is measured with all engine contexts sharing the GPU, so it includes the other contexts' kernels; "
                                      "'isolated' repeats the measurement with one context running alone after the timed region")
+        if iso:   # every MSM kernel, one context alone: point-scalar pairs, additions x 11 products against the measured peak
+            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * 11, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * 11.0}
+            roofline["valu"]["isolated_by_kernel"] = {
+                k: dict(pairs_per_proof=v["units"] / (B // K), ms_per_proof_batch=v["ms"],
+                        frac=(v["units"] * per_pair[k.split("<")[0]] / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None)
+                for k, v in iso.items() if k.split("<")[0] in per_pair and v["ms"]}
         if iso and dom in iso and iso[dom]["ms"]:
             ist = iso[dom]
             iso_mm = ist["units"] * mulmods_per_point / (ist["ms"] * 1e-3)

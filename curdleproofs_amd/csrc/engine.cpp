@@ -409,9 +409,9 @@ void Engine::ensure_raw_sets(size_t nsets) {
   d_rawslot_.ensure(std::max<size_t>(nsets, 1));
   d_rawmid_.ensure(std::max<size_t>(nsets, 1) * 16);
 }
-void Engine::reduce_sets(bool weighted, size_t nsets) {
+void Engine::reduce_sets(bool weighted, size_t nsets, TJac* part) {
   tick("k_reduce_sets", 0, (double)nsets, true);   // two launches (groups of 8 lanes, then the groups of a set)
-  launch_reduce_sets(weighted, d_raw_.p, d_rawslot_.p, (int)nsets, d_rawmid_.p, d_tpart_.p, stream_);
+  launch_reduce_sets(weighted, d_raw_.p, d_rawslot_.p, (int)nsets, d_rawmid_.p, part ? part : d_tpart_.p, stream_);
   tock();
 }
 
@@ -2299,12 +2299,13 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     d_scal_.ensure(total);
     d_tasks_.ensure(B);
     d_ftasks_.ensure(B);
-    d_conv_.ensure(B * NPT);
-    d_wsum_.ensure(B * 64);
-    d_part_.ensure(B * 8);
+    d_conv_.ensure(2 * B * NPT);   // points and their endomorphism images
+    d_ttasks_.ensure(B);
+    d_part_.ensure(B * 32);
     d_tpart_.ensure(B * (size_t)fix_parts);
     d_res_.ensure(B);
     d_comp_.ensure(B * 48);
+    ensure_raw_sets(B * std::max<size_t>(fix_parts, 32));
     const size_t b_scal = total * sizeof(Fr), b_mt = B * sizeof(MsmTask), b_ft = B * sizeof(FixTask);
     h_stage_.ensure(b_scal + b_mt + b_ft);
     Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
@@ -2324,18 +2325,16 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
     tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * n * B,
          (double)(n * B));
-    ensure_raw_sets(B * fix_parts);
     launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     tock();
     reduce_sets(false, B * fix_parts);
-    tick("k_msm_accw", 128.0 * NPT * B, (double)(NPT * B));
-    launch_msm_accum(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_wsum_.p, stream_);
+    // per-proof points: used once, so no shifted tables — endomorphism split + radix-256 buckets per window
+    tick("k_msm_tblw<2, true>", 128.0 * NPT * B, (double)(NPT * B));
+    launch_msm_endo(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
     tock();
-    tick("k_msm_tail", 0, (double)B * 8);
-    launch_msm_tail(d_wsum_.p, d_part_.p, nullptr, (int)B * 8, 8, 4, stream_);
-    tock();
+    reduce_sets(true, B * 32, d_part_.p);
     tick("k_msm_tail", 0, (double)B);
-    launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)B, 8, 32, stream_, d_tpart_.p, fix_parts);
+    launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)B, 16, 8, stream_, d_tpart_.p, fix_parts, 2);
     tock();
     tick("k_finalize", 0, (double)B);
     launch_finalize(d_res_.p, (int)B, nullptr, nullptr, d_comp_.p, stream_);

@@ -65,6 +65,11 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_ra
 // each; tblw: 2 sets per wave, fix: 1) plus the partial-sum slot every set belongs to; launch_reduce_sets turns them
 // into d_part[slot] (weighted: bucket sets of k_msm_tblw, plain: k_msm_fix).
 size_t raw_set_words();
+// Bucket MSM over caller-supplied bases with the endomorphism split and radix-256 windows (no shifted copies): 16 waves
+// per task, 32 raw sets per task; after launch_reduce_sets(weighted) the partial sums part[task*32 + 2w + h] carry the
+// weight 2^(8w): launch_msm_tail(part, ..., group 16, shift 8, dup 2) finishes.  d_conv: 2 x (sum of n) TAff scratch
+// (task.conv_off in units of points, as for launch_msm_accum), d_ttasks: ntasks TblTask scratch.
+void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
 void launch_reduce_sets(bool weighted, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nsets, TJac* d_mid, TJac* d_part, hipStream_t s);   // d_mid: 16 * nsets scratch
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
@@ -102,8 +107,9 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_con
 // ... then Horner tails: out[t] = sum_{j<group} 2^(shift*j) in[t*group+j]; (8,4) then (8,32) gives the MSM results.
 // Exactly one of d_out (table representation) / d_out_std (standard form, last stage) is non-null.
 // d_extra (optional): extra_per_out further partial sums added to output t before it is written
+// dup: that many consecutive inputs share a weight (out[t] = sum_j 2^(shift*j) (in[(t*group+j)*dup] + ...)).
 void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra = nullptr,
-                     int extra_per_out = 0);
+                     int extra_per_out = 0, int dup = 1);
 // Jacobian -> affine (+ optional scatter through dst_index) and optional 48-byte compressed form.
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
 // `batch` rows of n points, row r starting at d_in + r*stride; output dense [batch][n][48]

@@ -132,6 +132,27 @@ __global__ __launch_bounds__(64) void k_to_table(const MsmTask* __restrict__ tas
   conv[(size_t)task.conv_off + j] = t_from_std(task.bases[task.idx ? task.idx[j] : j]);
 }
 
+// bases of the endomorphism MSM (k_msm_tblw<2, true>): per task the table-form points followed by their images
+// -phi(P) = (beta x, -y), and the table task describing them (two "copies", stride n; 32 partial sums from task * 32)
+__global__ __launch_bounds__(64) void k_to_table_endo(const MsmTask* __restrict__ tasks, TAff* __restrict__ conv, TblTask* __restrict__ ttasks) {
+  const MsmTask task = tasks[blockIdx.y];
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  TAff* dst = conv + 2 * (size_t)task.conv_off;
+  if (j == 0) {
+    TblTask t;
+    t.seg[0] = TblSeg{dst, nullptr, task.n, task.n};
+    t.seg[1] = TblSeg{nullptr, nullptr, 0, 0};
+    t.scalars = task.scalars;
+    t.flags = task.flags;
+    t.pad = blockIdx.y * 32;
+    ttasks[blockIdx.y] = t;
+  }
+  if (j >= task.n) return;
+  const TAff P = t_from_std(task.bases[task.idx ? task.idx[j] : j]);
+  dst[j] = P;
+  dst[task.n + j] = P.is_identity() ? P : TAff{t_mul(P.x, t_beta()), t_neg(P.y)};
+}
+
 __global__ __launch_bounds__(64, 2) void k_msm_accw(const MsmTask* __restrict__ tasks, const TAff* __restrict__ conv, TJac* __restrict__ wsum) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int8_t* digits = reinterpret_cast<int8_t*>(smem);   // [8][ACW_CHUNK]
@@ -341,8 +362,8 @@ __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, u
 // is split by the endomorphism first (glv.cuh): k = +-(+-|t| + q z^2), windows 0..15 are the digits of |t| (table copies
 // 2^(8c) P), windows 16..31 those of q (table copies -phi(2^(8c) P) = z^2 2^(8c) P); sg_lo / sg_hi are the signs the
 // two halves carry.
-template <int WPW> __device__ __forceinline__ void tbw_digits(const TblTask& task, uint32_t i, int w0, uint32_t (&dg)[(WPW + 3) / 4], uint32_t& sg_lo,
-                                                              uint32_t& sg_hi) {
+template <int WPW, bool PERWIN> __device__ __forceinline__ void tbw_digits(const TblTask& task, uint32_t i, int w0, uint32_t (&dg)[(WPW + 3) / 4],
+                                                                           uint32_t& sg_lo, uint32_t& sg_hi) {
   Fr k = task.scalars[i];
   if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
   uint32_t t[4], q[4], bytes[8], nk, nt;
@@ -351,6 +372,17 @@ template <int WPW> __device__ __forceinline__ void tbw_digits(const TblTask& tas
   glv_biased_bytes(q, bytes + 4);
   sg_lo = nk ^ nt;
   sg_hi = nk;
+  if (PERWIN) {   // w0 = the window: its digit of |t| (entry j = 0) and of q (j = 1)
+    uint32_t bt = 0, bq = 0;
+    CPX_UNROLL for (int w = 0; w < 4; w++) {
+      if (w == (w0 >> 2)) {
+        bt = bytes[w];
+        bq = bytes[4 + w];
+      }
+    }
+    dg[0] = ((bt >> (8 * (w0 & 3))) & 255u) | (((bq >> (8 * (w0 & 3))) & 255u) << 8);
+    return;
+  }
   CPX_UNROLL for (int w = 0; w < 8; w++) {
     CPX_UNROLL for (int x = 0; x < (WPW + 3) / 4; x++)
       if (w == (w0 >> 2) + x) dg[x] = bytes[w];
@@ -365,15 +397,20 @@ __device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, uint32_t& n
   return b < 128u ? 2u * (b & 63u) + (b >> 6) : 128u;
 }
 
-template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot) {
-  constexpr int WV = TBW_WINDOWS / WPW;   // waves per task
+// PERWIN (k_msm_tblw<2, true>): the same wave over bases WITHOUT shifted copies (the verifier's per-proof points, used once):
+// the "table" has two copies, P and -phi(P) (k_to_table_endo), wave w of a task takes digit w of |t| and of q, and the
+// 16 window results carry the weights 2^(8w) (Horner tail, k_msm_tail).
+template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
+                                                                                            uint32_t* __restrict__ raw_slot) {
+  static_assert(!PERWIN || WPW == 2, "one window of each half per wave");
+  constexpr int WV = PERWIN ? 16 : TBW_WINDOWS / WPW;   // waves per task
   constexpr int NW = (WPW + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* list = reinterpret_cast<uint16_t*>(smem);                 // [TBW_CAP]
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + TBW_CAP * 2);    // [128] bucket sizes of the round
   uint32_t* cur = cnt + 128;                                          // [128] scatter cursors
   const TblTask task = tasks[blockIdx.x / WV];
-  const int wv = blockIdx.x % WV, w0 = wv * WPW;
+  const int wv = blockIdx.x % WV, w0 = PERWIN ? wv : wv * WPW;
   const int lane = threadIdx.x;
   const uint32_t ntot = task.seg[0].n + task.seg[1].n;
   uint32_t* raw0 = raw + (size_t)blockIdx.x * 2 * RAW_SET_WORDS;
@@ -393,7 +430,7 @@ template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const Tbl
       uint32_t dg[NW], sg_lo, sg_hi;
       int mine = 0;
       if (i < ntot) {
-        tbw_digits<WPW>(task, i, w0, dg, sg_lo, sg_hi);
+        tbw_digits<WPW, PERWIN>(task, i, w0, dg, sg_lo, sg_hi);
         CPX_UNROLL for (int j = 0; j < WPW; j++) {
           uint32_t neg;
           mine += tbw_bucket(dg[j >> 2], j, neg) < 128u ? 1 : 0;
@@ -428,11 +465,11 @@ template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const Tbl
       const uint32_t i = s0 + lane;
       if (i < end) {
         uint32_t dg[NW], sg_lo, sg_hi;
-        tbw_digits<WPW>(task, i, w0, dg, sg_lo, sg_hi);
+        tbw_digits<WPW, PERWIN>(task, i, w0, dg, sg_lo, sg_hi);
         CPX_UNROLL for (int j = 0; j < WPW; j++) {
           uint32_t neg;
           const uint32_t b = tbw_bucket(dg[j >> 2], j, neg);
-          neg ^= (w0 + j < 16) ? sg_lo : sg_hi;
+          neg ^= (PERWIN ? j == 0 : w0 + j < 16) ? sg_lo : sg_hi;
           if (b < 128u) list[atomicAdd(&cur[b], 1u)] = (uint16_t)(((i - next) << 6) | ((uint32_t)j << 1) | neg);
         }
       }
@@ -446,7 +483,7 @@ template <int WPW> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const Tbl
         xacc = later ? raw_load(raw1, lane) : TAcc::identity();
       }
       const uint32_t e = list[off + k];
-      const TAff q = *tbl_point(task, next + (e >> 6), (uint32_t)w0 + ((e >> 1) & 31u));
+      const TAff q = *tbl_point(task, next + (e >> 6), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & 31u));
       xacc = t_acc_add_mixed(xacc, t_cneg(q, (e & 1u) != 0));
     }
     if (c1 == 0) {
@@ -722,14 +759,15 @@ __global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src
 // out[t] = sum_{j < group} 2^(shift*j) in[t*group + j], one lane per output; the last stage hands the result
 // over in the standard form.
 template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const TJac* __restrict__ in, TJac* __restrict__ out, Jac* __restrict__ out_std, int nout,
-                                                                         int group, int shift, const TJac* __restrict__ extra, int extra_per_out) {
+                                                                         int group, int shift, const TJac* __restrict__ extra, int extra_per_out, int dup) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nout) return;
-  const TJac* src = in + (size_t)t * group;
-  TJac acc = src[group - 1];
+  const TJac* src = in + (size_t)t * group * dup;   // `dup` consecutive inputs share a weight
+  TJac acc = src[(group - 1) * dup];
+  for (int d = 1; d < dup; d++) acc = t_add(acc, src[(group - 1) * dup + d]);
   for (int j = group - 2; j >= 0; j--) {
     for (int s = 0; s < shift; s++) acc = t_dbl(acc);
-    acc = t_add(acc, src[j]);
+    for (int d = 0; d < dup; d++) acc = t_add(acc, src[j * dup + d]);
   }
   for (int j = 0; j < extra_per_out; j++) acc = t_add(acc, extra[(size_t)t * extra_per_out + j]);   // e.g. fixed-base partial sums
   if (STD_OUT) out_std[t] = t_jac_to_std(acc);
@@ -1279,10 +1317,21 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_con
   }
   CPX_LAUNCH(k_msm_accw, dim3(ntasks * 8), dim3(64), ACW_LDS, s, d_tasks, d_conv, d_wsum);
 }
-void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra, int extra_per_out) {
+void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra, int extra_per_out, int dup) {
   if (nout <= 0) return;
-  if (d_out_std) CPX_LAUNCH(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out);
-  else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out);
+  if (d_out_std) CPX_LAUNCH(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out, dup);
+  else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out, dup);
+}
+void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
+  if (ntasks <= 0) return;
+  {
+    hipEvent_t ea = tl_ev_start, eb = tl_ev_stop;   // the profiling events belong to the accumulation kernel
+    tl_ev_start = tl_ev_stop = nullptr;
+    CPX_LAUNCH(k_to_table_endo, dim3((std::max(max_n, 1) + 63) / 64, ntasks), dim3(64), 0, s, d_tasks, d_conv, d_ttasks);
+    tl_ev_start = ea;
+    tl_ev_stop = eb;
+  }
+  CPX_LAUNCH((k_msm_tblw<2, true>), dim3(ntasks * 16), dim3(64), TBW_LDS, s, d_ttasks, d_raw, d_raw_slot);
 }
 int msm_tblw_windows_per_wave(int ntasks) {
   // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2);

@@ -334,21 +334,21 @@ template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_sets_wav
 // sums carry weight 1 and a bucket may collect additions from any window: one (scalar, base) pair costs 32 mixed
 // additions, the 128 bucket magnitudes of the signed digits are the only reduction.  (Radix 16 with 64 copies — the
 // previous layout — paid 60 additions per pair.)
-// A single-wave work-group owns WPW consecutive windows of one task; lane l owns the two buckets |d| = l + 1 and
-// |d| = 64 + l + 1.  With a hit rate of 1/128 per (window, point) pair a lane cannot scan for its digits; the wave
-// sorts instead: every lane recodes one scalar of a 64-point slab, a histogram over the 128 magnitudes (LDS atomics)
-// gives the list offsets, a second pass scatters 16-bit (point, window, sign) entries into per-bucket lists in LDS
-// (bucket l and bucket 64 + l adjacent), and every lane then walks its two lists in ONE loop — gather the pre-shifted
-// point from the table in HBM/L2, add; at the boundary it parks the first accumulator in the raw-set buffer — so the
-// slowest lane is decided over both buckets and all windows (128 points x 32 windows: mean 64 additions, max ~83).
+// A single-wave work-group owns WPW consecutive windows of one task and all 128 buckets, two per lane.  With a hit
+// rate of 1/128 per (window, point) pair a lane cannot scan for its digits; the wave sorts instead: every lane recodes
+// one scalar of a 64-point slab, a histogram over the 128 magnitudes (LDS atomics) gives the list offsets, a second
+// pass scatters 16-bit (point, window, sign) entries into per-bucket lists in LDS.  The buckets are then ranked by
+// size and lane l takes rank l and rank 127 - l (longest with shortest): the lanes' totals differ by a few additions
+// (random pairs: mean 64, slowest lane ~83).  Every lane walks its two lists in ONE loop — gather the pre-shifted
+// point from the table in HBM/L2, add; at the boundary it parks the first accumulator in the raw-set buffer.
 // A round takes as many slabs as fit the list (8704 entries = 256 points x 32 windows); later rounds of a longer task
-// reload the parked accumulators.  Waves never wait for each other and the CU scheduler backfills a finished wave's
-// slot.  Output: two raw sets per wave (k_reduce_sets turns them into two partial sums, k_finalize_ranges adds the
-// partials of a request).
+// reload the parked accumulators (they are kept per bucket).  Waves never wait for each other and the CU scheduler
+// backfills a finished wave's slot.  Output: two raw sets per wave (buckets 1..64, 65..128; k_reduce_sets turns them
+// into two partial sums, k_finalize_ranges adds the partials of a request).
 constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
 constexpr int TBW_CAP = 8704;         // list entries per round
 constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index
-constexpr int TBW_LDS = TBW_CAP * 2 + 2 * 128 * 4;
+constexpr int TBW_LDS = TBW_CAP * 2 + 3 * 128 * 4 + 128;
 static_assert(TBW_CAP >= 64 * TBW_WINDOWS, "one slab always fits");
 
 __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
@@ -389,12 +389,11 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void tbw_digits(const
   }
   if (WPW < 4) dg[0] >>= 8 * (w0 & 3);
 }
-// list position class of window j's digit: 2 * (|d| - 1 mod 64) + (|d| > 64), or >= 128 for a zero digit
+// bucket |d| - 1 of window j's digit, or >= 128 for a zero digit
 __device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, uint32_t& neg) {
   const int d = (int)((word >> (8 * (j & 3))) & 255u) - 128;
   neg = d < 0 ? 1u : 0u;
-  const uint32_t b = (uint32_t)((d < 0 ? -d : d) - 1);
-  return b < 128u ? 2u * (b & 63u) + (b >> 6) : 128u;
+  return (uint32_t)((d < 0 ? -d : d) - 1);   // digit 0 -> 0xffffffff
 }
 
 // PERWIN (k_msm_tblw<2, true>): the same wave over bases WITHOUT shifted copies (the verifier's per-proof points, used once):
@@ -409,12 +408,13 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
   uint16_t* list = reinterpret_cast<uint16_t*>(smem);                 // [TBW_CAP]
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + TBW_CAP * 2);    // [128] bucket sizes of the round
   uint32_t* cur = cnt + 128;                                          // [128] scatter cursors
+  uint32_t* start = cur + 128;                                        // [128] list offsets
+  uint8_t* order = reinterpret_cast<uint8_t*>(start + 128);           // [128] buckets by size
   const TblTask task = tasks[blockIdx.x / WV];
   const int wv = blockIdx.x % WV, w0 = PERWIN ? wv : wv * WPW;
   const int lane = threadIdx.x;
   const uint32_t ntot = task.seg[0].n + task.seg[1].n;
   uint32_t* raw0 = raw + (size_t)blockIdx.x * 2 * RAW_SET_WORDS;
-  uint32_t* raw1 = raw0 + RAW_SET_WORDS;
   if (lane < 2) raw_slot[blockIdx.x * 2 + lane] = task.pad + 2 * wv + lane;   // task.pad = first partial slot of the task
 
   uint32_t next = 0;
@@ -450,17 +450,35 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
       end = min(end + 64, ntot);
     }
     __syncthreads();
-    // list offsets: exclusive scan of the lanes' two bucket sizes over the wave
-    const uint32_t c0 = cnt[2 * lane], c1 = cnt[2 * lane + 1];
-    uint32_t incl = c0 + c1;
-    CPX_UNROLL for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
-      if (lane >= d) incl += y;
+    // list offsets: exclusive scan of the 128 bucket sizes over the wave (lane l scans buckets 2l, 2l + 1)
+    {
+      const uint32_t a0 = cnt[2 * lane], a1 = cnt[2 * lane + 1];
+      uint32_t incl = a0 + a1;
+      CPX_UNROLL for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      const uint32_t o = incl - (a0 + a1);
+      start[2 * lane] = o;
+      start[2 * lane + 1] = o + a0;
+      cur[2 * lane] = o;
+      cur[2 * lane + 1] = o + a0;
+      // which two buckets this lane adds up: the 128 buckets ranked by size, lane l takes rank l and rank 127 - l
+      // (longest with shortest), so the lanes' totals differ by a few additions instead of +-30 %
+      uint32_t r0 = 0, r1 = 0;
+      for (int q = 0; q < 128; q++) {
+        const uint32_t c = cnt[q];
+        r0 += (c < a0 || (c == a0 && q < 2 * lane)) ? 1u : 0u;
+        r1 += (c < a1 || (c == a1 && q < 2 * lane + 1)) ? 1u : 0u;
+      }
+      order[r0] = (uint8_t)(2 * lane);
+      order[r1] = (uint8_t)(2 * lane + 1);
     }
-    const uint32_t off = incl - (c0 + c1);
-    cur[2 * lane] = off;
-    cur[2 * lane + 1] = off + c0;
     __syncthreads();
+    const uint32_t b0 = order[lane], b1 = order[127 - lane];
+    const uint32_t c0 = cnt[b0], c1 = cnt[b1], s0_ = start[b0], s1_ = start[b1];
+    uint32_t* const rb0 = raw0 + (b0 >> 6) * RAW_SET_WORDS;   // bucket b lives in set b / 64 at position b % 64
+    uint32_t* const rb1 = raw0 + (b1 >> 6) * RAW_SET_WORDS;
     for (uint32_t s0 = next; s0 < end; s0 += 64) {
       const uint32_t i = s0 + lane;
       if (i < end) {
@@ -475,22 +493,22 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
       }
     }
     __syncthreads();
-    TAcc xacc = later ? raw_load(raw0, lane) : TAcc::identity();
+    TAcc xacc = later ? raw_load(rb0, b0 & 63) : TAcc::identity();
     const uint32_t cboth = c0 + c1;
     for (uint32_t k = 0; k < cboth; k++) {
       if (k == c0) {   // first bucket done: park it, go on with the second
-        raw_store(raw0, lane, xacc);
-        xacc = later ? raw_load(raw1, lane) : TAcc::identity();
+        raw_store(rb0, b0 & 63, xacc);
+        xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
       }
-      const uint32_t e = list[off + k];
+      const uint32_t e = list[k < c0 ? s0_ + k : s1_ + (k - c0)];
       const TAff q = *tbl_point(task, next + (e >> 6), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & 31u));
       xacc = t_acc_add_mixed(xacc, t_cneg(q, (e & 1u) != 0));
     }
     if (c1 == 0) {
-      raw_store(raw0, lane, xacc);
-      xacc = later ? raw_load(raw1, lane) : TAcc::identity();
+      raw_store(rb0, b0 & 63, xacc);
+      xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
     }
-    raw_store(raw1, lane, xacc);
+    raw_store(rb1, b1 & 63, xacc);
     __syncthreads();
     next = end;
     later = true;

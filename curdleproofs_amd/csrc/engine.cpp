@@ -223,8 +223,8 @@ struct HostBaton {   // FIFO ticket lock
 HostBaton g_batons[64];
 bool baton_enabled() {
   static const bool on = [] {
-    const char* e = getenv("CPX_HOST_BATON");
-    return !e || atoi(e) != 0;
+    const char* e = getenv("CPX_HOST_BATON");   // off by default: with 4 contexts per GPU and 8-24 worker threads each the host phases
+    return e && atoi(e) != 0;                    // of different contexts run side by side faster than one after the other
   }();
   return on;
 }
@@ -395,11 +395,11 @@ static const char* fix_kernel_name(int bits, int wpw) {
 }
 static const char* tblw_kernel_name(int wpw) {
   switch (wpw) {
-    case 32: return "k_msm_tblw<32>";
-    case 16: return "k_msm_tblw<16>";
-    case 8: return "k_msm_tblw<8>";
-    case 4: return "k_msm_tblw<4>";
-    default: return "k_msm_tblw<2>";
+    case 32: return "k_msm_tblw<32, false>";
+    case 16: return "k_msm_tblw<16, false>";
+    case 8: return "k_msm_tblw<8, false>";
+    case 4: return "k_msm_tblw<4, false>";
+    default: return "k_msm_tblw<2, false>";
   }
 }
 
@@ -409,9 +409,9 @@ void Engine::ensure_raw_sets(size_t nsets) {
   d_rawslot_.ensure(std::max<size_t>(nsets, 1));
   d_rawmid_.ensure(std::max<size_t>(nsets, 1) * 16);
 }
-void Engine::reduce_sets(bool weighted, size_t nsets, TJac* part) {
-  tick("k_reduce_sets", 0, (double)nsets, true);   // two launches (groups of 8 lanes, then the groups of a set)
-  launch_reduce_sets(weighted, d_raw_.p, d_rawslot_.p, (int)nsets, d_rawmid_.p, part ? part : d_tpart_.p, stream_);
+void Engine::reduce_sets(size_t nplain, size_t nweighted, TJac* part) {
+  tick("k_reduce_sets", 0, (double)(nplain + nweighted), true);   // up to four launches (groups of 8 lanes, then the groups of a set; plain / bucket sets)
+  launch_reduce_sets(d_raw_.p, d_rawslot_.p, (int)nplain, (int)nweighted, d_rawmid_.p, part ? part : d_tpart_.p, stream_);
   tock();
 }
 
@@ -526,19 +526,19 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_pfirst_.p, hp, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-  ensure_raw_sets(std::max(nft * fix_parts, ntt * tbl_parts));
+  const size_t fix_sets = nft * fix_parts, tbl_sets = ntt * tbl_parts;   // raw sets: [fixed-base waves | bucket sets of the table waves]
+  ensure_raw_sets(fix_sets + tbl_sets);
   if (nft) {
     tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * pts_fix, pts_fix);
     launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     tock();
-    reduce_sets(false, nft * fix_parts);
   }
   if (ntt) {
     tick(tblw_kernel_name(tbl_wpw), 128.0 * pts_tbl, pts_tbl);
-    launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_raw_.p, d_rawslot_.p, stream_);
+    launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_raw_.p + fix_sets * raw_set_words(), d_rawslot_.p + fix_sets, stream_);
     tock();
-    reduce_sets(true, ntt * tbl_parts);
   }
+  reduce_sets(fix_sets, tbl_sets);
   tick("k_finalize_ranges", 0, (double)nt);
   launch_finalize_ranges(d_tpart_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_, any_add ? d_padd_.p : nullptr);
   tock();
@@ -2270,7 +2270,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, sizeof(FixTask), hipMemcpyHostToDevice, stream_));
     ensure_raw_sets(fix_parts);
     launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
-    reduce_sets(false, fix_parts);
+    reduce_sets(fix_parts, 0);
     tick("big_msm", 128.0 * N, (double)N, true);
     launch_big_msm(plan, d_pp_.p, d_big_idx_.p, d_scal_.p, N, d_conv_.p, d_big_keys_.p, d_big_vals_.p, d_big_temp_.p, d_big_bounds_.p, d_big_buckets_.p,
                    d_tpart_.p, fix_parts, d_res_.p, stream_);
@@ -2327,12 +2327,12 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
          (double)(n * B));
     launch_msm_fix(d_ftasks_.p, (int)B, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     tock();
-    reduce_sets(false, B * fix_parts);
+    reduce_sets(B * fix_parts, 0);
     // per-proof points: used once, so no shifted tables — endomorphism split + radix-256 buckets per window
     tick("k_msm_tblw<2, true>", 128.0 * NPT * B, (double)(NPT * B));
     launch_msm_endo(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
     tock();
-    reduce_sets(true, B * 32, d_part_.p);
+    reduce_sets(0, B * 32, d_part_.p);
     tick("k_msm_tail", 0, (double)B);
     launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)B, 16, 8, stream_, d_tpart_.p, fix_parts, 2);
     tock();

@@ -182,7 +182,7 @@ class Engine {
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
   void run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out);
   void ensure_raw_sets(size_t nsets);
-  void reduce_sets(bool weighted, size_t nsets, TJac* part = nullptr);
+  void reduce_sets(size_t nplain, size_t nweighted, TJac* part = nullptr);
   void verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid);
   void batch_prove_fold(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   void batch_prove_tables(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);

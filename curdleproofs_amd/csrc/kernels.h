@@ -63,14 +63,15 @@ int msm_tblw_parts(int wpw);   // waves (= partial sums) per task
 void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
 // The MSM waves of k_msm_tblw / k_msm_fix leave their 64 lane accumulators as "raw sets" (raw_set_words() 32-bit words
 // each; tblw: 2 sets per wave, fix: 1) plus the partial-sum slot every set belongs to; launch_reduce_sets turns them
-// into d_part[slot] (weighted: bucket sets of k_msm_tblw, plain: k_msm_fix).
+// into d_part[slot] (bucket sets of k_msm_tblw: weighted sums; k_msm_fix: plain sums).
 size_t raw_set_words();
 // Bucket MSM over caller-supplied bases with the endomorphism split and radix-256 windows (no shifted copies): 16 waves
 // per task, 32 raw sets per task; after launch_reduce_sets(weighted) the partial sums part[task*32 + 2w + h] carry the
 // weight 2^(8w): launch_msm_tail(part, ..., group 16, shift 8, dup 2) finishes.  d_conv: 2 x (sum of n) TAff scratch
 // (task.conv_off in units of points, as for launch_msm_accum), d_ttasks: ntasks TblTask scratch.
 void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
-void launch_reduce_sets(bool weighted, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nsets, TJac* d_mid, TJac* d_part, hipStream_t s);   // d_mid: 16 * nsets scratch
+// The first nplain sets are plain sums, the following nweighted ones bucket sets (lower / upper half alternating).
+void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s);   // d_mid: 16 TJac per set
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
 // endo = false: copy c = 2^(256 c / C) P.   endo = true (the tables k_msm_tblw reads): copies 0..C/2-1 = 2^(8c) P and

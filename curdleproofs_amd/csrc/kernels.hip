@@ -286,11 +286,11 @@ template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_groups(c
 
 // Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per set, the classic tree — suffix
 // scan (weighted sets) + tree sum, 6 + 6 dependent additions instead of the ~40 of the work-efficient form above.
-template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_sets_wave(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ slot, int nsets,
-                                                                                 TJac* __restrict__ part) {
+__global__ __launch_bounds__(64) void k_reduce_sets_wave(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ slot, int nplain, TJac* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TJac* red = reinterpret_cast<TJac*>(smem);   // [65]
   const int set = blockIdx.x, lane = threadIdx.x;
+  const bool WEIGHTED = set >= nplain;   // sets [0, nplain) are plain (k_msm_fix), the rest bucket sets (k_msm_tblw), lower / upper half alternating
   TJac acc = t_acc_to_jac(raw_load(raw + (size_t)set * RAW_SET_WORDS, lane));
   red[lane] = acc;
   __syncthreads();
@@ -320,7 +320,7 @@ template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_sets_wav
     __syncthreads();
   }
   if (lane == 0) {
-    if (WEIGHTED && (set & 1)) {                    // upper half: magnitudes 64 + (l + 1)
+    if (WEIGHTED && ((set - nplain) & 1)) {         // upper half: magnitudes 64 + (l + 1)
       TJac plain = red[64];
       for (int d = 0; d < 6; d++) plain = t_dbl(plain);
       acc = t_add(acc, plain);
@@ -1384,21 +1384,23 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_ra
   }
 }
 size_t raw_set_words() { return RAW_SET_WORDS; }
-void launch_reduce_sets(bool weighted, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nsets, TJac* d_mid, TJac* d_part, hipStream_t s) {
+void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s) {
+  const int nsets = nplain + nweighted;
   if (nsets <= 0) return;
-  if (nsets <= 2048) {   // a few proofs: wave per set
-    const size_t lds1 = 65 * sizeof(TJac);
-    if (weighted) CPX_LAUNCH(k_reduce_sets_wave<true>, dim3(nsets), dim3(64), lds1, s, d_raw, d_raw_slot, nsets, d_part);
-    else CPX_LAUNCH(k_reduce_sets_wave<false>, dim3(nsets), dim3(64), lds1, s, d_raw, d_raw_slot, nsets, d_part);
+  if (nsets <= 2048) {   // a few proofs: wave per set, both kinds in one launch
+    CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), 65 * sizeof(TJac), s, d_raw, d_raw_slot, nplain, d_part);
     return;
   }
-  const dim3 g1((nsets * 8 + 63) / 64), g2((nsets + 63) / 64), block(64);
-  if (weighted) {
-    CPX_LAUNCH(k_reduce_sets<true>, g1, block, 0, s, d_raw, nsets, d_mid);
-    CPX_LAUNCH(k_reduce_groups<true>, g2, block, 0, s, d_mid, d_raw_slot, nsets, d_part);
-  } else {
-    CPX_LAUNCH(k_reduce_sets<false>, g1, block, 0, s, d_raw, nsets, d_mid);
-    CPX_LAUNCH(k_reduce_groups<false>, g2, block, 0, s, d_mid, d_raw_slot, nsets, d_part);
+  const dim3 block(64);
+  if (nplain > 0) {
+    CPX_LAUNCH(k_reduce_sets<false>, dim3((nplain * 8 + 63) / 64), block, 0, s, d_raw, nplain, d_mid);
+    CPX_LAUNCH(k_reduce_groups<false>, dim3((nplain + 63) / 64), block, 0, s, d_mid, d_raw_slot, nplain, d_part);
+  }
+  if (nweighted > 0) {   // (an even number of plain sets keeps the lower / upper parity of the bucket sets)
+    const uint32_t* raw_w = d_raw + (size_t)nplain * RAW_SET_WORDS;
+    TJac* mid_w = d_mid + (size_t)nplain * 16;
+    CPX_LAUNCH(k_reduce_sets<true>, dim3((nweighted * 8 + 63) / 64), block, 0, s, raw_w, nweighted, mid_w);
+    CPX_LAUNCH(k_reduce_groups<true>, dim3((nweighted + 63) / 64), block, 0, s, mid_w, d_raw_slot + nplain, nweighted, d_part);
   }
 }
 int msm_fix_windows_per_wave(int ntasks, int cbits) {

@@ -674,7 +674,23 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   MsmTask t{db.p, nullptr, ds.p, (uint32_t)n, 0, 0};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
   DevBuf<TAff> conv;
-  conv.ensure(std::max<size_t>(n, 1));
+  conv.ensure(2 * std::max<size_t>(n, 1));
+  if (n >= 64) {   // endomorphism split + radix-256 bucket lists (the verifier's kernel): 32 additions per point
+    DevBuf<TblTask> tt;
+    DevBuf<TJac> part;
+    tt.ensure(1);
+    part.ensure(32);
+    ensure_raw_sets(32);
+    tick("k_msm_tblw<2, true>", 128.0 * n, (double)n);
+    launch_msm_endo(dt.p, 1, (int)n, conv.p, tt.p, d_raw_.p, d_rawslot_.p, stream_);
+    tock();
+    reduce_sets(0, 32, part.p);
+    launch_msm_tail(part.p, nullptr, res.p, 1, 16, 8, stream_, nullptr, 0, 2);
+    CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipStreamSynchronize(stream_));   // before the scratch buffers above go out of scope
+    flush_timers();
+    return;
+  }
   tick("k_msm_accw", 128.0 * n, (double)n);
   launch_msm_accum(dt.p, 1, (int)n, conv.p, w.p, stream_);
   tock();

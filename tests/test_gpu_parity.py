@@ -65,6 +65,44 @@ def test_msm_edge_cases(ctx, orc):
     assert orc.g1_compress_jac(z)[0] == 0xC0
 
 
+def test_msm_endomorphism_path_edge_cases(ctx, orc):
+    """n >= 64 goes through the endomorphism split + radix-256 bucket lists (k_msm_tblw<2, true>, the verifier's kernel):
+    scalars at the edges of the split (0, 1, r - 1, z^2, z^2 / 2, (r +- 1) / 2, 2^128 - 1, all-0x80 digit bytes), identity
+    bases, a repeated (base, scalar) pair, a cancelling pair, and more points than one list round holds."""
+    R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    z2 = 0xd201000000010000 ** 2
+    rng = orc.rng(77)
+    n = 200
+    bases = bytearray(rng.g1_affine(n))
+    scalars = bytearray(rng.fr(n))
+    special = [0, 1, 2, R_ - 1, R_ - 2, z2, z2 - 1, z2 + 1, z2 // 2, z2 // 2 + 1, (R_ - 1) // 2, (R_ + 1) // 2, (1 << 128) - 1, 1 << 127,
+               int.from_bytes(b"\x80" * 31 + b"\x00", "little") % R_, int.from_bytes(b"\x7f" * 31 + b"\x00", "little") % R_, 255, 256, 128, 127,
+               (z2 * (z2 // 2)) % R_, (z2 * 128 + 128) % R_]
+    for i, v in enumerate(special):
+        scalars[(20 + i) * FR:(21 + i) * FR] = orc.fr_from_canonical_bytes(v.to_bytes(32, "little"))
+    ident = bytes(AFF)
+    bases[0:AFF] = ident
+    bases[25 * AFF:26 * AFF] = ident
+    bases[7 * AFF:8 * AFF] = bases[6 * AFF:7 * AFF]           # P, s twice: P + P inside a bucket
+    scalars[7 * FR:8 * FR] = scalars[6 * FR:7 * FR]
+    bases[11 * AFF:12 * AFF] = bases[10 * AFF:11 * AFF]       # +P and -P: cancels
+    scalars[10 * FR:11 * FR] = orc.fr_from_u64(1)
+    scalars[11 * FR:12 * FR] = orc.fr_from_canonical_bytes((R_ - 1).to_bytes(32, "little"))
+    got = ctx.msm(bytes(bases), bytes(scalars))
+    want = orc.g1_msm(bytes(bases), bytes(scalars), naive=True)
+    assert _same_point(orc, got, want)
+    # all-zero scalars / all-identity bases
+    assert orc.g1_compress_jac(ctx.msm(rng.g1_affine(100), bytes(FR * 100)))[0] == 0xC0
+    assert orc.g1_compress_jac(ctx.msm(ident * 100, rng.fr(100)))[0] == 0xC0
+    # several list rounds per wave (272 points fit one round), one scalar repeated (a single bucket takes everything)
+    n = 1500
+    bases = rng.g1_affine(n)
+    scalars = rng.fr(n)
+    assert _same_point(orc, ctx.msm(bases, scalars), orc.g1_msm(bases, scalars))
+    same = scalars[:FR] * n
+    assert _same_point(orc, ctx.msm(bases, same), orc.g1_msm(bases, same))
+
+
 def test_msm_length_mismatch_is_an_error(ctx, orc):
     rng = orc.rng(3)
     with pytest.raises(ValueError):   # util.rs:20 assert_eq!(points.len(), scalars.len())

@@ -623,7 +623,7 @@ template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* 
 
 // Thread per request: add its partial sums [first, first + count), normalise (one inversion per work-group),
 // convert to the standard form, scatter the affine point and emit the 48-byte compressed encoding.
-__global__ __launch_bounds__(256) void k_finalize_ranges(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
+__global__ __launch_bounds__(64) void k_finalize_ranges(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
                                                          int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
                                                          const uint32_t* __restrict__ addends) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -723,7 +723,7 @@ __device__ __forceinline__ void tmp_load(const uint32_t* tmp, size_t nthreads, s
 // Thread per base point: reads the standard-form source point, writes copy 0 in table form, then runs a chain
 // of 256 - sb doublings storing every sb-th value; the C-1 Jacobian copies are normalised with the thread's own
 // Montgomery trick plus one inversion per work-group.
-__global__ __launch_bounds__(256) void k_table_build(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
+__global__ __launch_bounds__(64) void k_table_build(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
                                                      int npts, int copy_stride, int copies, int endo, TblTmp* __restrict__ tmp_) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);
@@ -795,7 +795,7 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const T
 // ------------------------------------------------------------------ normalise + compress
 // Thread per point: Jacobian -> affine (one inversion per work-group) and, optionally, the 48-byte
 // compressed encoding the transcript and the proof bytes need.
-__global__ __launch_bounds__(256) void k_finalize(const Jac* __restrict__ in, int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index,
+__global__ __launch_bounds__(64) void k_finalize(const Jac* __restrict__ in, int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index,
                                                    uint8_t* __restrict__ out_comp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   Fp* buf = reinterpret_cast<Fp*>(smem);
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) void k_compress(const Aff* __restrict__ in, in
 // 96-byte point loads/stores of a wave are contiguous.
 // The arithmetic runs on the table form: the two input points are converted on load (2 products per coordinate)
 // and the result is converted back after the in-group batch inversion.
-constexpr int SMUL_THREADS = 256;
+constexpr int SMUL_THREADS = 64;   // single-wave groups: no whole-CU placement constraint beside the MSM waves of other contexts
 
 __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1441,18 +1441,21 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
     CPX_LAUNCH(k_finalize_ranges_wave, dim3((n + 3) / 4), dim3(256), lds, s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
     return;
   }
-  CPX_LAUNCH(k_finalize_ranges, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
+  CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
 }
 void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
                         TblTmp* d_tmp, hipStream_t s) {
   const long total = (long)rows * npts;
   if (total <= 0) return;
-  CPX_LAUNCH(k_table_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 2 * 256 * sizeof(TF), s, d_src, src_row_stride, d_table, rows, row_stride, npts,
+  // single-wave work-groups: a 256-thread group of this 241-VGPR kernel only ever got one group per CU (38 ms against 19 ms per
+  // 2048 proofs); one inversion per 64 bases instead of per 256 costs ~5 % of a wave's time
+  constexpr int blk = 64;
+  CPX_LAUNCH(k_table_build, dim3((unsigned)((total + blk - 1) / blk)), dim3(blk), 2 * blk * sizeof(TF), s, d_src, src_row_stride, d_table, rows, row_stride, npts,
                      copy_stride, copies, endo ? 1 : 0, d_tmp);
 }
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
   if (n <= 0) return;
-  CPX_LAUNCH(k_finalize, dim3((n + 255) / 256), dim3(256), 2 * 256 * sizeof(Fp), s, d_in, n, d_aff, d_dst_index, d_comp);
+  CPX_LAUNCH(k_finalize, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(Fp), s, d_in, n, d_aff, d_dst_index, d_comp);
 }
 void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s) {
   if (n <= 0 || batch <= 0) return;

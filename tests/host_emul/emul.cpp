@@ -335,4 +335,82 @@ void emul_glv_split(const uint8_t* k, size_t n, uint8_t* out) {
   }
 }
 
+// k_table_build (endo rows) + k_msm_tblw + k_reduce_sets / k_reduce_groups on one task, in the kernels' own arithmetic:
+// 16 shifted copies 2^(8c) P and their images (beta x, -y), scalars split by glv_split, 128 XYZZ buckets shared by all 32
+// windows, then per half the running sums over groups of 8 and over the 8 groups.  perwin != 0: the verifier's variant
+// (k_to_table_endo + k_msm_tblw<2, true>): no shifted copies, one bucket set pair per window, Horner over the 16 windows.
+void emul_msm_endo(const uint8_t* bases, const uint8_t* scalars, size_t n, int perwin, uint8_t* out) {
+  const Aff* P = reinterpret_cast<const Aff*>(bases);
+  const TF beta = t_beta();
+  const int nsetpairs = perwin ? 16 : 1;
+  std::vector<TAcc> bucket((size_t)nsetpairs * 128, TAcc::identity());
+  for (size_t i = 0; i < n; i++) {
+    // table row of point i
+    TAff row[32];
+    const TAff p0 = t_from_std(P[i]);
+    const bool inf = p0.is_identity();
+    TJac acc = TJac::from_affine(p0);
+    for (int c = 0; c < 16; c++) {
+      TAff a = p0;
+      if (c && !inf) {
+        for (int d = 0; d < 8; d++) acc = t_dbl(acc);
+        a = t_to_affine(acc, t_inv(acc.z));
+      }
+      row[c] = a;
+      row[16 + c] = inf ? a : TAff{t_mul(a.x, beta), t_neg(a.y)};
+    }
+    Fr k;
+    memcpy(k.v, scalars + 32 * i, 32);
+    k = fe_from_mont(k);
+    uint32_t t[4], q[4], bytes[8], nk, nt;
+    glv_split(k.v, t, q, nk, nt);
+    glv_biased_bytes(t, bytes);
+    glv_biased_bytes(q, bytes + 4);
+    for (int w = 0; w < 32; w++) {
+      const int d = (int)((bytes[w >> 2] >> (8 * (w & 3))) & 255u) - 128;
+      if (!d) continue;
+      const bool neg = (d < 0) != ((w < 16 ? (nk ^ nt) : nk) != 0);
+      const int b = (d < 0 ? -d : d) - 1;
+      // perwin: copy 0 / 1 of the unshifted point, bucket set pair = window; else copy w, one shared set pair
+      const TAff src = perwin ? row[w < 16 ? 0 : 16] : row[w];
+      TAcc& B = bucket[(size_t)(perwin ? (w & 15) : 0) * 128 + b];
+      B = t_acc_add_mixed(B, t_cneg(src, neg));
+    }
+  }
+  auto reduce_set = [&](const TAcc* A, int upper) {   // k_reduce_sets<true> + k_reduce_groups<true>
+    TJac S[8], W[8];
+    for (int g = 0; g < 8; g++) {
+      TJac run = t_acc_to_jac(A[g * 8 + 7]), w = run;
+      for (int j = 6; j >= 0; j--) {
+        run = t_add(run, t_acc_to_jac(A[g * 8 + j]));
+        w = t_add(w, run);
+      }
+      S[g] = run;
+      W[g] = w;
+    }
+    TJac run = S[7], v = run;
+    for (int g = 6; g >= 1; g--) {
+      run = t_add(run, S[g]);
+      v = t_add(v, run);
+    }
+    run = t_add(run, S[0]);
+    for (int d = 0; d < 3; d++) v = t_dbl(v);
+    for (int g = 0; g < 8; g++) v = t_add(v, W[g]);
+    if (upper) {
+      for (int d = 0; d < 6; d++) run = t_dbl(run);
+      v = t_add(v, run);
+    }
+    return v;
+  };
+  TJac res = TJac::identity();
+  for (int w = nsetpairs - 1; w >= 0; w--) {   // Horner over the windows (one iteration for the table form)
+    if (perwin)
+      for (int d = 0; d < 8; d++) res = t_dbl(res);
+    res = t_add(res, reduce_set(&bucket[(size_t)w * 128], 0));
+    res = t_add(res, reduce_set(&bucket[(size_t)w * 128 + 64], 1));
+  }
+  const Jac r = t_jac_to_std(res);
+  memcpy(out, &r, sizeof r);
+}
+
 }  // extern "C"

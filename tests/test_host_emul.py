@@ -29,6 +29,8 @@ def emul():
     L.emul_host_fr_inv_check.argtypes = [vp, sz]
     L.emul_modinv30_check.argtypes = [vp, sz, vp]
     L.emul_glv_split.argtypes = [vp, sz, vp]
+    L.emul_msm_endo.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+    L.emul_msm_endo.restype = None
     L.emul_glv_split.restype = None
     L.emul_msm.argtypes = [vp, vp, sz, vp]
     L.emul_smul.argtypes = [vp, vp, vp, vp]
@@ -294,3 +296,23 @@ def test_glv_split(emul):
         assert (-v if nk else v) % R == k, hex(k)
         for half, val in ((o[34:50], t), (o[50:66], q)):
             assert sum((b - 128) << (8 * w) for w, b in enumerate(half)) == val
+
+
+@pytest.mark.parametrize("perwin", [0, 1])
+def test_table_msm_kernel_algorithm(emul, orc, perwin):
+    """The table MSM of the prover (shifted copies + endomorphism images, 128 shared buckets) and the verifier's per-window
+    variant, in the kernels' arithmetic, with the two-level weighted reduction of k_reduce_sets / k_reduce_groups."""
+    R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    z2 = 0xd201000000010000 ** 2
+    rng = orc.rng(90 + perwin)
+    n = 24
+    bases = bytearray(rng.g1_affine(n))
+    scalars = bytearray(rng.fr(n))
+    for i, v in enumerate([0, 1, R_ - 1, z2, z2 // 2, z2 // 2 + 1, (R_ - 1) // 2, (R_ + 1) // 2, 128, 129, (z2 * 128 + 128) % R_]):
+        scalars[(4 + i) * FR:(5 + i) * FR] = orc.fr_from_canonical_bytes(v.to_bytes(32, "little"))
+    bases[0:AFF] = bytes(AFF)                                   # identity base
+    bases[3 * AFF:4 * AFF] = bases[2 * AFF:3 * AFF]             # duplicate base + same scalar: P + P in a bucket
+    scalars[3 * FR:4 * FR] = scalars[2 * FR:3 * FR]
+    o = _o(JAC)
+    emul.emul_msm_endo(_b(bytes(bases)), _b(bytes(scalars)), n, perwin, o)
+    assert orc.g1_compress_jac(bytes(o)) == orc.g1_compress_jac(orc.g1_msm(bytes(bases), bytes(scalars), naive=True))

@@ -1450,8 +1450,6 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     side_.scal.ensure(total + 2 * B);
     side_.tasks.ensure(nt);
     side_.stasks.ensure(4 * B);
-    side_.wsum.ensure(nt * 64);
-    side_.part.ensure(nt * 8);
     side_.res.ensure(nt);
     side_.dst.ensure(nt);
     side_.comp.ensure(B * (size_t)CWN * 48);
@@ -1473,10 +1471,16 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, (total + 2 * B) * sizeof(Fr), hipMemcpyHostToDevice, side_.stream));
     CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, side_.stream));
     CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, side_.stream));
-    side_.conv.ensure(2 * total);
-    launch_msm_accum(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.wsum.p, side_.stream);
-    launch_msm_tail(side_.wsum.p, side_.part.p, nullptr, (int)nt * 8, 8, 4, side_.stream);
-    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 8, 32, side_.stream);
+    // endomorphism split + radix-256 bucket lists per window (the verifier's kernel), 32 additions per point instead of 60
+    side_.conv.ensure(4 * total);   // 2 tasks per proof, points and images
+    side_.ttasks.ensure(nt);
+    side_.raw.ensure(nt * 32 * raw_set_words());
+    side_.rawslot.ensure(nt * 32);
+    side_.mid.ensure(nt * 32 * 16);
+    side_.part.ensure(nt * 32);
+    launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
+    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nt * 32, side_.mid.p, side_.part.p, side_.stream);
+    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, side_.stream, nullptr, 0, 2);
     launch_finalize(side_.res.p, (int)nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
   }
 

@@ -165,7 +165,9 @@ class Engine {
     DevBuf<MsmTask> tasks;
     DevBuf<SmulTask> stasks;
     DevBuf<Fr> scal;
-    DevBuf<TJac> wsum, part;
+    DevBuf<TJac> part, mid;
+    DevBuf<TblTask> ttasks;
+    DevBuf<uint32_t> raw, rawslot;
     DevBuf<TAff> conv;
     DevBuf<Jac> res;
     DevBuf<uint32_t> dst;

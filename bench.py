@@ -279,8 +279,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    warm = {}   # kernel statistics of the warm-up launches (only used for the all-launches average rocprofv3 reports)
     if args.warmup:
+        for c in ctxs:
+            c.set_profiling(True)
+            c.reset_stats()
         steps(args.warmup)
+        for c in ctxs:
+            for name, st in c.stats().items():
+                acc = warm.setdefault(name, dict(launches=0, ms=0.0))
+                acc["launches"] += st["launches"]
+                acc["ms"] += st["ms"]
     for c in ctxs:
         c.set_profiling(True)
         c.reset_stats()
@@ -337,6 +346,10 @@ def main():
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, avg_launch_ms=avg_ms, launches=st["launches"], alg_bytes_per_launch=bytes_per_launch,
                         units_per_launch=st["units"] / max(st["launches"], 1),
+                        # every launch of this process (warm-up + timed region + the isolated pass): the population
+                        # `rocprofv3 --kernel-trace --stats` averages over when it wraps this command
+                        avg_launch_ms_all_launches=(st["ms"] + warm.get(dom, {}).get("ms", 0.0) + (iso or {}).get(dom, {}).get("ms", 0.0))
+                        / max(1, st["launches"] + warm.get(dom, {}).get("launches", 0) + (iso or {}).get(dom, {}).get("launches", 0)),
                         note="integer big-number path: VALU (v_mad_i64_i32) bound, the HBM fraction is tiny by construction; "
                              "roofline.valu gives the modular-multiplication roofline (DESIGN.md section 5)")
         # The honest bound of this integer path: modular multiplications on the VALU.  Peak = dependent

@@ -874,7 +874,7 @@ __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restric
 __device__ __noinline__ F28 f28_sqrt_device(const F28& a) { return f28_sqrt_candidate(a); }
 __device__ __noinline__ bool g1_in_subgroup_device(const Aff28& P) { return g1_28_in_subgroup(P); }
 
-__global__ __launch_bounds__(64) void k_decompress(const uint8_t* __restrict__ in, int n, Aff* __restrict__ out,
+__global__ __launch_bounds__(64, 2) void k_decompress(const uint8_t* __restrict__ in, int n, Aff* __restrict__ out,
                                                    const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ status, int check_subgroup) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;

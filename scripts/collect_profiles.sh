@@ -17,6 +17,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_A
 python $R/scripts/pmc_summary.py $(find /tmp/pmc1 -name "*counter_collection.csv" | head -1) $O/r01_pmc_sq.md > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --no-cpu-baseline --synth-cache /tmp/synth.pkl > $O/kt.log 2>&1
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/r01_kernel_stats.csv
+grep -o '{"metric.*' $O/kt.log | head -1 > $O/r01_bench_under_rocprof.json   # the bench line of the SAME process the kernel statistics come from
 python $R/scripts/gpu_busy.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) after_last=k_fix_build from_first=k_compress > $O/r01_gpu_busy.txt 2>&1
 cd $R
 python bench.py --synth-cache /tmp/synth.pkl > $O/bench_default.log 2>&1

@@ -206,7 +206,9 @@ Engine::HostSpan::~HostSpan() {
   st.launches++;
   st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
 }
-// ---- host baton -----------------------------------------------------------------------------------------
+// ---- host baton (off unless CPX_HOST_BATON=1) -----------------------------------------------------------
+// Written for TWO engines per GPU; with the four the bench runs now the host phases of different engines run side
+// by side faster than one after the other (bench.py at 32 cores per rank: 8.5k proofs/s with the baton, 10.7k without).
 // Several engines on one GPU (one host thread each) take turns on the HOST side: an engine holds the device's
 // baton while it runs host work and enqueues kernels, and passes it on whenever it blocks on its stream.  Kernels
 // of different engines still overlap freely on the GPU.  Two effects: the engines fall into anti-phase (one
@@ -415,7 +417,9 @@ void Engine::reduce_sets(size_t nplain, size_t nweighted, TJac* part) {
   tock();
 }
 
-// Table-backed MSM phase: every request is one work-group of k_msm_tbl; results are normalised + compressed.
+// Table-backed MSM phase: the CRS segments of a request go to k_msm_fix, the per-proof segments to k_msm_tblw (one
+// wave per task and window group); k_reduce_sets turns the raw lane accumulators into partial sums, k_finalize_ranges
+// adds them per request, normalises and compresses.
 void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out) {
   const size_t nt = reqs.size();
   if (!nt) return;

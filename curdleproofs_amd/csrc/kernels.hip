@@ -1,10 +1,11 @@
 // gfx950 (MI355X / CDNA4) kernels for the Curdleproofs G1 hot path.
 //
 // Replaces, behind include/cpx.h, the arithmetic the reference reaches through
-//   util::msm                       /root/reference/src/util.rs:19-22             -> k_to_table + k_msm_accw + k_msm_tail
+//   util::msm                       /root/reference/src/util.rs:19-22             -> k_to_table_endo + k_msm_tblw<2, true> + k_reduce_sets
+//                                                                                    + k_msm_tail (fewer than 64 points: k_to_table + k_msm_accw)
 //   the commitments and log-round cross terms of the prover (all MSMs over fixed bases in the batch engine)
 //                                   inner_product_argument.rs:126-127,158-161,
-//                                   same_multiscalar_argument.rs:80-82,107-112 ...  -> k_msm_fix (CRS), k_msm_tblw (per-proof tables)
+//                                   same_multiscalar_argument.rs:80-82,107-112 ...  -> k_msm_fix (CRS), k_msm_tblw (per-proof tables), k_reduce_sets
 //   IPA / SameMSM basis folds       inner_product_argument.rs:174-179,
 //                                   same_multiscalar_argument.rs:126-131            -> k_smul (add operand set; tier 0)
 //   G' rescale / shuffle scaling    grand_product_argument.rs:90-102, util.rs:94-95 -> k_smul (no add operand)
@@ -15,12 +16,14 @@
 // Integer big-number work on the VALU; no MFMA — there is no dense contraction here.  Design notes:
 //  * every group operation runs on the carry-free 28-bit-limb "table form" (fp28.cuh / g1_28.cuh / tarith.cuh);
 //    points enter a kernel through t_from_std and leave through t_to_std / t_jac_to_std;
-//  * MSM work-groups are single waves (no inter-wave barriers): lanes own buckets in registers and walk digit rows
-//    staged in LDS, points are gathered from HBM/L2 tables;
+//  * MSM work-groups are single waves (no inter-wave barriers): lanes own buckets in registers and walk per-bucket
+//    lists sorted into LDS (k_msm_tblw) or digit rows staged in LDS (k_msm_fix, k_msm_accw), points are gathered from
+//    HBM/L2 tables; the lane accumulators are added up by separate work-efficient kernels (k_reduce_sets);
+//  * scalars of the table kernels are split by the G1 endomorphism (glv.cuh): half the doublings in the table build;
 //  * the long doubling chain that combines the windows of a bucket MSM is split out into k_msm_tail, one *lane* per
 //    partial Horner evaluation, so that lanes stay busy across the many independent MSMs of a proof batch;
-//  * Jacobian results are normalised with one inversion per work-group (LDS product scans + binary Euclid on one
-//    wave) instead of the reference's one inversion per point.
+//  * Jacobian results are normalised with one inversion per work-group (LDS product scans + a division-step
+//    inversion, modinv30.cuh) instead of the reference's one inversion per point.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <hip/hip_ext.h>
@@ -111,8 +114,8 @@ __device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
 }
 
 // ------------------------------------------------------------------ MSM over arbitrary bases: bucket accumulation
-// Pippenger with signed radix-16 windows for caller-supplied bases (tier 0, the instance vectors R and S, the
-// verifier's shards).  Two kernels:
+// Pippenger with signed radix-16 windows for small caller-supplied MSMs (tier 0 below 64 points, the CRS sums of
+// set_crs; larger one-off MSMs — the verifier's per-proof points, R and S — take k_msm_tblw<2, true>).  Two kernels:
 //  k_to_table   converts every base of every task to the table form once (2 products per coordinate) into a
 //               scratch array (task.conv_off); the 8 waves of a task then gather 112-B points from it (L2).
 //  k_msm_accw   barrier-free single-wave groups as in k_msm_tblw: a wave owns 8 windows of one task, lane =

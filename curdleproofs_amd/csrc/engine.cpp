@@ -504,6 +504,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
       }
       t.flags = 0;
       t.pad = slot;
+      t.digits = nullptr;
       ht[tt_index[i]] = t;
       slot += tbl_parts;
     }
@@ -682,11 +683,13 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   if (n >= 64) {   // endomorphism split + radix-256 bucket lists (the verifier's kernel): 32 additions per point
     DevBuf<TblTask> tt;
     DevBuf<TJac> part;
+    DevBuf<uint32_t> dig;
     tt.ensure(1);
     part.ensure(32);
+    dig.ensure(9 * n);
     ensure_raw_sets(32);
     tick("k_msm_tblw<2, true>", 128.0 * n, (double)n);
-    launch_msm_endo(dt.p, 1, (int)n, conv.p, tt.p, d_raw_.p, d_rawslot_.p, stream_);
+    launch_msm_endo(dt.p, 1, (int)n, conv.p, dig.p, tt.p, d_raw_.p, d_rawslot_.p, stream_);
     tock();
     reduce_sets(0, 32, part.p);
     launch_msm_tail(part.p, nullptr, res.p, 1, 16, 8, stream_, nullptr, 0, 2);
@@ -1478,11 +1481,12 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     // endomorphism split + radix-256 bucket lists per window (the verifier's kernel), 32 additions per point instead of 60
     side_.conv.ensure(4 * total);   // 2 tasks per proof, points and images
     side_.ttasks.ensure(nt);
+    side_.digits.ensure(9 * 2 * total);
     side_.raw.ensure(nt * 32 * raw_set_words());
     side_.rawslot.ensure(nt * 32);
     side_.mid.ensure(nt * 32 * 16);
     side_.part.ensure(nt * 32);
-    launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
+    launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
     launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nt * 32, side_.mid.p, side_.part.p, side_.stream);
     launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, side_.stream, nullptr, 0, 2);
     launch_finalize(side_.res.p, (int)nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
@@ -2324,6 +2328,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     d_tasks_.ensure(B);
     d_ftasks_.ensure(B);
     d_conv_.ensure(2 * B * NPT);   // points and their endomorphism images
+    d_digits_.ensure(9 * B * NPT);
     d_ttasks_.ensure(B);
     d_part_.ensure(B * 32);
     d_tpart_.ensure(B * (size_t)fix_parts);
@@ -2354,7 +2359,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     reduce_sets(B * fix_parts, 0);
     // per-proof points: used once, so no shifted tables — endomorphism split + radix-256 buckets per window
     tick("k_msm_tblw<2, true>", 128.0 * NPT * B, (double)(NPT * B));
-    launch_msm_endo(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
+    launch_msm_endo(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_digits_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
     tock();
     reduce_sets(0, B * 32, d_part_.p);
     tick("k_msm_tail", 0, (double)B);

@@ -167,7 +167,7 @@ class Engine {
     DevBuf<Fr> scal;
     DevBuf<TJac> part, mid;
     DevBuf<TblTask> ttasks;
-    DevBuf<uint32_t> raw, rawslot;
+    DevBuf<uint32_t> raw, rawslot, digits;
     DevBuf<TAff> conv;
     DevBuf<Jac> res;
     DevBuf<uint32_t> dst;
@@ -259,6 +259,7 @@ class Engine {
   DevBuf<TAff> d_ptab_;      // per-proof tables [B][copies][NP]
   DevBuf<uint32_t> d_raw_, d_rawslot_;   // raw lane accumulators of k_msm_tblw / k_msm_fix and their partial-sum slots
   DevBuf<TJac> d_rawmid_;                // group sums between the two reduction launches
+  DevBuf<uint32_t> d_digits_;            // recoded scalars of the endomorphism bucket MSM (9 words per point)
   DevBuf<Aff> d_psrc_;       // their standard-form sources [B][NP] : M | T_b | U_b
   DevBuf<TblTmp> d_tbltmp_;
   DevBuf<TblTask> d_ttasks_;

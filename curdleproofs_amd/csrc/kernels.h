@@ -51,6 +51,7 @@ struct TblTask {
   const Fr* scalars;        // seg[0].n + seg[1].n scalars
   uint32_t flags;
   uint32_t pad;             // first partial slot of the task; it writes 64 / wpw partials
+  const uint32_t* digits;   // optional: 9 words per scalar (32 biased digit bytes + the two half signs), written by k_to_table_endo
 };
 struct TblTmp {   // table-build scratch: a Jacobian copy and the running product of the previous copies' Z
   TJac p;
@@ -68,8 +69,10 @@ size_t raw_set_words();
 // Bucket MSM over caller-supplied bases with the endomorphism split and radix-256 windows (no shifted copies): 16 waves
 // per task, 32 raw sets per task; after launch_reduce_sets(weighted) the partial sums part[task*32 + 2w + h] carry the
 // weight 2^(8w): launch_msm_tail(part, ..., group 16, shift 8, dup 2) finishes.  d_conv: 2 x (sum of n) TAff scratch
-// (task.conv_off in units of points, as for launch_msm_accum), d_ttasks: ntasks TblTask scratch.
-void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
+// (task.conv_off in units of points, as for launch_msm_accum), d_digits: 9 words per point (the split scalars' digits,
+// recoded once per task instead of once per wave), d_ttasks: ntasks TblTask scratch.
+void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
+                     hipStream_t s);
 // The first nplain sets are plain sums, the following nweighted ones bucket sets (lower / upper half alternating).
 void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s);   // d_mid: 16 TJac per set
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the

@@ -137,10 +137,12 @@ __global__ __launch_bounds__(64) void k_to_table(const MsmTask* __restrict__ tas
 
 // bases of the endomorphism MSM (k_msm_tblw<2, true>): per task the table-form points followed by their images
 // -phi(P) = (beta x, -y), and the table task describing them (two "copies", stride n; 32 partial sums from task * 32)
-__global__ __launch_bounds__(64) void k_to_table_endo(const MsmTask* __restrict__ tasks, TAff* __restrict__ conv, TblTask* __restrict__ ttasks) {
+__global__ __launch_bounds__(64) void k_to_table_endo(const MsmTask* __restrict__ tasks, TAff* __restrict__ conv, uint32_t* __restrict__ digits,
+                                                      TblTask* __restrict__ ttasks) {
   const MsmTask task = tasks[blockIdx.y];
   const uint32_t j = blockIdx.x * 64 + threadIdx.x;
   TAff* dst = conv + 2 * (size_t)task.conv_off;
+  uint32_t* dgs = digits + 9 * (size_t)task.conv_off;
   if (j == 0) {
     TblTask t;
     t.seg[0] = TblSeg{dst, nullptr, task.n, task.n};
@@ -148,9 +150,20 @@ __global__ __launch_bounds__(64) void k_to_table_endo(const MsmTask* __restrict_
     t.scalars = task.scalars;
     t.flags = task.flags;
     t.pad = blockIdx.y * 32;
+    t.digits = dgs;
     ttasks[blockIdx.y] = t;
   }
   if (j >= task.n) return;
+  {   // the scalar's split and its 2 x 16 signed radix-256 digits, once for the 16 waves of the task
+    Fr k = task.scalars[j];
+    if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
+    uint32_t t[4], q[4], bytes[8], nk, nt;
+    glv_split(k.v, t, q, nk, nt);
+    glv_biased_bytes(t, bytes);
+    glv_biased_bytes(q, bytes + 4);
+    CPX_UNROLL for (int w = 0; w < 8; w++) dgs[9 * (size_t)j + w] = bytes[w];
+    dgs[9 * (size_t)j + 8] = (nk ^ nt) | (nk << 1);
+  }
   const TAff P = t_from_std(task.bases[task.idx ? task.idx[j] : j]);
   dst[j] = P;
   dst[task.n + j] = P.is_identity() ? P : TAff{t_mul(P.x, t_beta()), t_neg(P.y)};
@@ -367,6 +380,14 @@ __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, u
 // two halves carry.
 template <int WPW, bool PERWIN> __device__ __forceinline__ void tbw_digits(const TblTask& task, uint32_t i, int w0, uint32_t (&dg)[(WPW + 3) / 4],
                                                                            uint32_t& sg_lo, uint32_t& sg_hi) {
+  if (PERWIN && task.digits) {   // recoded once per task by k_to_table_endo
+    const uint32_t* dgs = task.digits + 9 * (size_t)i;
+    const uint32_t bt = dgs[w0 >> 2], bq = dgs[4 + (w0 >> 2)], sg = dgs[8];
+    dg[0] = ((bt >> (8 * (w0 & 3))) & 255u) | (((bq >> (8 * (w0 & 3))) & 255u) << 8);
+    sg_lo = sg & 1u;
+    sg_hi = sg >> 1;
+    return;
+  }
   Fr k = task.scalars[i];
   if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
   uint32_t t[4], q[4], bytes[8], nk, nt;
@@ -1343,12 +1364,13 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
   if (d_out_std) CPX_LAUNCH(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out, dup);
   else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out, dup);
 }
-void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
+void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
+                     hipStream_t s) {
   if (ntasks <= 0) return;
   {
     hipEvent_t ea = tl_ev_start, eb = tl_ev_stop;   // the profiling events belong to the accumulation kernel
     tl_ev_start = tl_ev_stop = nullptr;
-    CPX_LAUNCH(k_to_table_endo, dim3((std::max(max_n, 1) + 63) / 64, ntasks), dim3(64), 0, s, d_tasks, d_conv, d_ttasks);
+    CPX_LAUNCH(k_to_table_endo, dim3((std::max(max_n, 1) + 63) / 64, ntasks), dim3(64), 0, s, d_tasks, d_conv, d_digits, d_ttasks);
     tl_ev_start = ea;
     tl_ev_stop = eb;
   }

@@ -108,25 +108,32 @@ CPX_PT_FN Xyzz28 xyzz28_dbl_affine(const Aff28& q) {   // mdbl-2008-s-1: 2 * (x,
   r.zzz = w;
   return r;
 }
-CPX_PT_FN Xyzz28 xyzz28_add_mixed(const Xyzz28& p, const Aff28& q) {
+// INL: the ten products inlined instead of called (no argument moves: the out-of-line product takes 28 scalar
+// arguments and returns 14).  Used by the one loop where it pays, k_msm_tblw: +4 % there, and the kernel drops from
+// 256 VGPRs with spills to 231 without; in k_msm_fix (two points in flight) it bought nothing, and inlining
+// everywhere would put several 40 KB loops into the instruction cache two CUs share.
+template <bool INL> CPX_PT_FN Xyzz28 xyzz28_add_mixed_t(const Xyzz28& p, const Aff28& q) {
+  auto mul = [](const F28& a, const F28& b) { return INL ? f28_mul_body(a, b) : f28_mul(a, b); };
+  auto sqr = [](const F28& a) { return INL ? f28_sqr_body(a) : f28_sqr(a); };
   if (q.is_identity()) return p;
   if (p.is_identity()) return Xyzz28{q.x, q.y, f28_one(), f28_one()};
-  const F28 u2 = f28_mul(q.x, p.zz), s2 = f28_mul(q.y, p.zzz);
+  const F28 u2 = mul(q.x, p.zz), s2 = mul(q.y, p.zzz);
   const F28 pp_ = f28_sub(u2, p.x), rr = f28_sub(s2, p.y);
-  const F28 pp2 = f28_sqr(pp_);
-  const F28 zz3 = f28_mul(p.zz, pp2);
+  const F28 pp2 = sqr(pp_);
+  const F28 zz3 = mul(p.zz, pp2);
   if (f28_product_is_zero(zz3)) {   // same x: P = +-Q
     if (f28_product_is_zero(f28_mul(rr, f28_one()))) return xyzz28_dbl_affine(q);
     return Xyzz28::identity();
   }
-  const F28 ppp = f28_mul(pp_, pp2), qq = f28_mul(p.x, pp2);
+  const F28 ppp = mul(pp_, pp2), qq = mul(p.x, pp2);
   Xyzz28 r;
-  r.x = f28_sub(f28_sub(f28_sqr(rr), ppp), f28_shl<1>(qq));
-  r.y = f28_sub(f28_mul(rr, f28_sub(qq, r.x)), f28_mul(p.y, ppp));
+  r.x = f28_sub(f28_sub(sqr(rr), ppp), f28_shl<1>(qq));
+  r.y = f28_sub(mul(rr, f28_sub(qq, r.x)), mul(p.y, ppp));
   r.zz = zz3;
-  r.zzz = f28_mul(p.zzz, ppp);
+  r.zzz = mul(p.zzz, ppp);
   return r;
 }
+CPX_PT_FN Xyzz28 xyzz28_add_mixed(const Xyzz28& p, const Aff28& q) { return xyzz28_add_mixed_t<false>(p, q); }
 // same point in Jacobian coordinates with Z = ZZ: (X ZZ, Y ZZZ, ZZ)
 CPX_HD Jac28 xyzz28_to_jac(const Xyzz28& p) {
   if (p.is_identity()) return Jac28::identity();

@@ -526,7 +526,7 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
       }
       const uint32_t e = list[k < c0 ? s0_ + k : s1_ + (k - c0)];
       const TAff q = *tbl_point(task, next + (e >> 6), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & 31u));
-      xacc = t_acc_add_mixed(xacc, t_cneg(q, (e & 1u) != 0));
+      xacc = t_acc_add_mixed_inl(xacc, t_cneg(q, (e & 1u) != 0));   // products inlined: no argument moves, 231 VGPRs, no scratch
     }
     if (c1 == 0) {
       raw_store(rb0, b0 & 63, xacc);

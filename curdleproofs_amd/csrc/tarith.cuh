@@ -27,6 +27,7 @@ CPX_HD TJac t_jac_from_std(const Jac& p) { return jac28_from_std(p); }
 // bucket accumulators: extended Jacobian coordinates while points are being added, Jacobian for the reductions
 typedef Xyzz28 TAcc;
 CPX_HD TAcc t_acc_add_mixed(const TAcc& p, const TAff& q) { return xyzz28_add_mixed(p, q); }
+CPX_HD TAcc t_acc_add_mixed_inl(const TAcc& p, const TAff& q) { return xyzz28_add_mixed_t<true>(p, q); }
 CPX_HD TJac t_acc_to_jac(const TAcc& p) { return xyzz28_to_jac(p); }
 CPX_HD TF t_inv(const TF& a) { return f28_inv_euclid(a); }
 CPX_HD TF t_neg(const TF& a) { return f28_neg(a); }

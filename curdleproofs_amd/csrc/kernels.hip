@@ -586,17 +586,20 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
     }
     __syncthreads();
     const int16_t* row = digits + wl * FIX_CHUNK;
-    // every lane walks its slice i = sl, sl+LPW, ...: same trip count for all lanes; points fetched two at a time
-    for (int i = sl; i < m; i += 2 * LPW) {
-      const int d0 = row[i];
-      const bool h1 = i + LPW < m;
-      const int d1 = h1 ? row[i + LPW] : 0;
-      const uint32_t g0 = base + i, g1 = base + i + LPW;
-      TAff p0 = TAff::identity(), p1 = TAff::identity();
-      if (d0) p0 = wtab[(size_t)((d0 < 0 ? -d0 : d0) - 1) * nc + task.off + (task.idx ? task.idx[g0] : g0)];
-      if (d1) p1 = wtab[(size_t)((d1 < 0 ? -d1 : d1) - 1) * nc + task.off + (task.idx ? task.idx[g1] : g1)];
-      if (d0) xacc = t_acc_add_mixed(xacc, t_cneg(p0, d0 < 0));
-      if (d1) xacc = t_acc_add_mixed(xacc, t_cneg(p1, d1 < 0));
+    // every lane walks its slice i = sl, sl+LPW, ...: same trip count for all lanes; the gather of the next point is in
+    // flight while the current one is added (products inlined)
+    auto fetch = [&](int i, int& d) {
+      d = i < m ? row[i] : 0;
+      const uint32_t g = base + i;
+      return d ? wtab[(size_t)((d < 0 ? -d : d) - 1) * nc + task.off + (task.idx ? task.idx[g] : g)] : TAff::identity();
+    };
+    int dn;
+    TAff pn = fetch(sl, dn);
+    for (int i = sl; i < m; i += LPW) {
+      const int d = dn;
+      const TAff p = pn;
+      pn = fetch(i + LPW, dn);
+      if (d) xacc = t_acc_add_mixed_inl(xacc, t_cneg(p, d < 0));
     }
   }
   // all entries carry weight 1: the wave's 64 accumulators form one plain raw set (k_reduce_sets adds them up)

@@ -138,19 +138,21 @@ def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, r
     if rank == 0:
         n = ell + 4
         value = world * B * args.steps / dt
-        st = stats["big_msm"]
+        big = stats["big_msm"]["launches"] > 0   # CPX_FUSED_BIG=1: the sort-based wide-window MSM; default: groups of proofs on the endomorphism kernel
+        st = stats["big_msm"] if big else stats["k_msm_tblw<2, true>"]
         avg_ms = st["ms"] / max(st["launches"], 1)
         bpl = st["alg_bytes"] / max(st["launches"], 1)
         ach = bpl / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
         out = dict(metric="shuffle proofs/sec checked by the batched verifier (BASELINE config 5) at ell=%d, BLS12-381" % ell, value=value, unit="proofs/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="int64", data="synthetic",
-                   config=dict(workload="ell=%d: %d proofs per GPU per step in ONE accumulated MSM (%d points per context), "
+                   config=dict(workload="ell=%d: %d proofs per GPU per step in ONE accumulated check (%d points per context), "
                                         "all-gather of one 144-byte partial sum per rank" % (ell, B, (B // K) * (4 * ell + 103 + 10 * (n.bit_length() - 1))),
                                ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K,
                                parallelism="proofs sharded over %d GPU(s); one all-gather (RCCL) of %d x 148 bytes" % (world, world)),
                    all_verified=bool(ok), kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
-                   roofline=dict(bound="hbm", kernel="big_msm (k_big_gather, k_big_keys, radix sort, k_big_bounds, k_big_accum, k_big_combine, k_big_final)",
+                   roofline=dict(bound="hbm", kernel="big_msm (k_big_gather, k_big_keys, radix sort, k_big_bounds, k_big_accum, k_big_combine, k_big_final)" if big
+                                 else "k_msm_tblw<2, true> over groups of proofs",
                                  achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_ms,
                                  launches=st["launches"], alg_bytes_per_launch=bpl, units_per_launch=st["units"] / max(st["launches"], 1)),
                    cpu_baseline=None)

@@ -2259,17 +2259,20 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
         if (!st[p].bad) t += st[p].scal[0][i];
       crs_sum[i] = t;
     });
-    const BigMsmPlan plan = big_msm_plan(N);
+    static const bool sorted_big = getenv("CPX_FUSED_BIG") || getenv("CPX_BIG_WINDOW");   // the sort-based wide-window MSM (kept for A/B and its tests)
+    const BigMsmPlan plan = sorted_big ? big_msm_plan(N) : BigMsmPlan{};
     const int fix_wpw = msm_fix_windows_per_wave(1, fix_bits_);
     const int fix_parts = 256 / fix_bits_ / fix_wpw;
     d_scal_.ensure(N + n);
     d_big_idx_.ensure(N);
-    d_conv_.ensure(N);
-    d_big_keys_.ensure(2 * plan.nkeys);
-    d_big_vals_.ensure(2 * plan.nkeys);
-    d_big_temp_.ensure(plan.sort_temp_bytes + 16);
-    d_big_bounds_.ensure(2 * (size_t)plan.nbuckets);
-    d_big_buckets_.ensure(3 * (size_t)plan.nbuckets + 64);
+    if (sorted_big) {
+      d_conv_.ensure(N);
+      d_big_keys_.ensure(2 * plan.nkeys);
+      d_big_vals_.ensure(2 * plan.nkeys);
+      d_big_temp_.ensure(plan.sort_temp_bytes + 16);
+      d_big_bounds_.ensure(2 * (size_t)plan.nbuckets);
+      d_big_buckets_.ensure(3 * (size_t)plan.nbuckets + 64);
+    }
     d_tpart_.ensure(fix_parts);
     d_ftasks_.ensure(1);
     d_res_.ensure(1);
@@ -2299,10 +2302,41 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     ensure_raw_sets(fix_parts);
     launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     reduce_sets(fix_parts, 0);
-    tick("big_msm", 128.0 * N, (double)N, true);
-    launch_big_msm(plan, d_pp_.p, d_big_idx_.p, d_scal_.p, N, d_conv_.p, d_big_keys_.p, d_big_vals_.p, d_big_temp_.p, d_big_bounds_.p, d_big_buckets_.p,
-                   d_tpart_.p, fix_parts, d_res_.p, stream_);
-    tock();
+    if (sorted_big) {
+      tick("big_msm", 128.0 * N, (double)N, true);
+      launch_big_msm(plan, d_pp_.p, d_big_idx_.p, d_scal_.p, N, d_conv_.p, d_big_keys_.p, d_big_vals_.p, d_big_temp_.p, d_big_bounds_.p, d_big_buckets_.p,
+                     d_tpart_.p, fix_parts, d_res_.p, stream_);
+      tock();
+    } else {
+      // The per-proof points of up to 256 groups of proofs through the endomorphism bucket-list kernel (32 additions per
+      // point like the per-proof verifier, but one bucket reduction and one Horner tail per GROUP of proofs), then two
+      // plain summation levels; the last one adds the fixed-base part and hands the sum over in the standard form.
+      const size_t G = (B + 255) / 256, NT = (B + G - 1) / G, NT16 = (NT + 15) / 16 * 16;
+      d_tasks_.ensure(NT);
+      d_ttasks_.ensure(NT);
+      d_conv_.ensure(2 * N);
+      d_digits_.ensure(9 * N);
+      d_part_.ensure(NT * 32);
+      d_wsum_.ensure(NT16 + NT16 / 16);
+      ensure_raw_sets(std::max<size_t>(NT * 32, fix_parts));
+      std::vector<MsmTask> mt(NT);
+      for (size_t g = 0; g < NT; g++) {
+        const size_t off = g * G * NPT, np = std::min(G, B - g * G) * NPT;
+        mt[g] = MsmTask{d_pp_.p, d_big_idx_.p + off, d_scal_.p + off, (uint32_t)np, 0, (uint32_t)off};
+      }
+      CPX_HIP(hipMemcpyAsync(d_tasks_.p, mt.data(), NT * sizeof(MsmTask), hipMemcpyHostToDevice, stream_));
+      CPX_HIP(hipMemsetAsync(d_wsum_.p, 0, (NT16 + NT16 / 16) * sizeof(TJac), stream_));   // all-zero = identity: pads the summation levels
+      tick("k_msm_tblw<2, true>", 128.0 * N, (double)N);
+      launch_msm_endo(d_tasks_.p, (int)NT, (int)(G * NPT), d_conv_.p, d_digits_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
+      tock();
+      reduce_sets(0, NT * 32, d_part_.p);
+      tick("k_msm_tail", 0, (double)NT, true);
+      launch_msm_tail(d_part_.p, d_wsum_.p, nullptr, (int)NT, 16, 8, stream_, nullptr, 0, 2);                      // windows of a group
+      launch_msm_tail(d_wsum_.p, d_wsum_.p + NT16, nullptr, (int)(NT16 / 16), 16, 0, stream_);                     // 16 groups each
+      launch_msm_tail(d_wsum_.p + NT16, nullptr, d_res_.p, 1, (int)(NT16 / 16), 0, stream_, d_tpart_.p, fix_parts);   // + the fixed-base part
+      tock();
+      CPX_HIP(hipStreamSynchronize(stream_));   // mt (host) was copied asynchronously
+    }
     h_comp_.ensure(sizeof(Jac));
     CPX_HIP(hipMemcpyAsync(h_comp_.p, d_res_.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
     wait_stream();

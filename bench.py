@@ -80,7 +80,7 @@ def cpu_baseline(ell, data, gpu_proof0, budget_s=12.0):
 
 def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, red_dev="cuda"):
     """BASELINE config 5: batched verifier.  Proofs are produced once (untimed); a step = every context's fused
-    verification of its share (one wide-window MSM per context), the per-GPU partial sums added on the GPU, one
+    verification of its share (one accumulated MSM per context), the per-GPU partial sums added on the GPU, one
     all-gather of 144-byte partials over the ranks and the final identity test."""
     import threading
     import curdleproofs_amd as cpx
@@ -138,8 +138,7 @@ def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, r
     if rank == 0:
         n = ell + 4
         value = world * B * args.steps / dt
-        big = stats["big_msm"]["launches"] > 0   # CPX_FUSED_BIG=1: the sort-based wide-window MSM; default: groups of proofs on the endomorphism kernel
-        st = stats["big_msm"] if big else stats["k_msm_tblw<2, true>"]
+        st = stats["k_msm_tblw<2, true>"]   # groups of proofs as tasks of the endomorphism bucket-list kernel
         avg_ms = st["ms"] / max(st["launches"], 1)
         bpl = st["alg_bytes"] / max(st["launches"], 1)
         ach = bpl / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
@@ -151,8 +150,7 @@ def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, r
                                ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K,
                                parallelism="proofs sharded over %d GPU(s); one all-gather (RCCL) of %d x 148 bytes" % (world, world)),
                    all_verified=bool(ok), kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
-                   roofline=dict(bound="hbm", kernel="big_msm (k_big_gather, k_big_keys, radix sort, k_big_bounds, k_big_accum, k_big_combine, k_big_final)" if big
-                                 else "k_msm_tblw<2, true> over groups of proofs",
+                   roofline=dict(bound="hbm", kernel="k_msm_tblw<2, true> over groups of proofs",
                                  achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_ms,
                                  launches=st["launches"], alg_bytes_per_launch=bpl, units_per_launch=st["units"] / max(st["launches"], 1)),
                    cpu_baseline=None)
@@ -178,16 +176,30 @@ def main():
     ap.add_argument("--fused-verify", action="store_true", help="measure BASELINE config 5 instead: the batched verifier (one accumulated MSM over "
                     "all proofs of all GPUs, one all-gather of 144-byte partial sums); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per engine context (0 = cores / (ranks x contexts), clamped to [8, 24])")
+    ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per engine context (0 = cores / (ranks x contexts), clamped to [2, 24])")
     ap.add_argument("--synth-cache", default="", help="pickle file for the synthetic batch (created if missing): keeps profiled runs free of setup kernels")
     ap.add_argument("--ctxs", type=int, default=4, help="engine contexts (HIP streams + host threads) per GPU; the batch is split over them so that "
                     "one context's Fiat-Shamir / scalar work on the host overlaps the other's kernels")
     args = ap.parse_args()
 
+    # --gpus N without a launcher around us: start the N ranks ourselves (one process per GPU, the same command line the
+    # driver uses for N > 1) and hand over; under torch.distributed.run WORLD_SIZE is set and must agree with --gpus.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     # test hooks (a 1-GPU box can rehearse the multi-rank path): CPX_BENCH_DEVICE pins every rank to one device,
     # CPX_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on the same GPU)
     backend = os.environ.get("CPX_BENCH_BACKEND", "nccl")
@@ -197,17 +209,38 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        if not os.environ.get("CPX_BENCH_DRYRUN"):
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus, "process group size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
+        world = dist.get_world_size()   # n_gpus in the output line is what the process group (RCCL) reports
+    if os.environ.get("CPX_BENCH_DRYRUN"):
+        # launcher rehearsal without GPUs (tests/test_bench_contract_cpu.py): the ranks meet, take the max over ranks of a
+        # dummy step time like the real run does, rank 0 reports the world it saw.  No proof is produced: value is null.
+        dt = 1.0 + rank
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            print(json.dumps(dict(dry_run=True, metric="shuffle proofs/sec (prove+verify) at ell=%d, BLS12-381" % args.ell, value=None, n_gpus=world,
+                                  steps=args.steps, warmup=args.warmup, max_over_ranks_dt=dt,
+                                  host_threads_per_context=args.host_threads or max(2, min(24, (os.cpu_count() or 64) // (world * max(1, args.ctxs)))))))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     import curdleproofs_amd as cpx
     import threading
     ell, B, K = args.ell, args.batch, max(1, args.ctxs)
     assert B % K == 0, "--batch must be a multiple of --ctxs"
     ctxs = [cpx.Context(local_rank) for _ in range(K)]          # raises without a GPU: no CPU fallback
-    host_threads = args.host_threads or max(8, min(24, (os.cpu_count() or 64) // (max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))) * K)))
+    # host worker threads per context: the cores of the node divided over ranks x contexts (all ranks share one node)
+    host_threads = args.host_threads or max(2, min(24, (os.cpu_count() or 64) // (world * K)))
     for c in ctxs:
         c.set_host_threads(host_threads)
     ctx = ctxs[0]

@@ -75,7 +75,7 @@ def load_library():
     L.cpx_last_error.argtypes = [vp]
     L.cpx_last_error.restype = ctypes.c_char_p
     L.cpx_device_count.argtypes = []
-    L.cpx_ctx_set_crs.argtypes = [vp, sz, vp]
+    L.cpx_ctx_set_crs.argtypes = [vp, sz, vp, sz]
     L.cpx_crs_sums.argtypes = [vp, vp, vp]
     L.cpx_proof_size.argtypes = [vp]
     L.cpx_proof_size.restype = sz
@@ -154,8 +154,11 @@ class Context:
 
     # ---- CRS (crs.rs:37-58) ----
     def set_crs(self, ell, points):
-        assert len(points) == AFF * (ell + 7), "need ell + 7 affine points"
-        self._check(self._L.cpx_ctx_set_crs(self._h, ell, _in(points)))
+        if len(points) % AFF:
+            raise ValueError("CRS points: 96 bytes per affine point")
+        # crs.rs:40-42 "not enough points" is reported by the library (CPX_ERR_ARG); surplus points are ignored like the reference's slicing
+        self._check(self._L.cpx_ctx_set_crs(self._h, ell, _in(points), len(points) // AFF))
+        points = points[:AFF * (ell + 7)]
         self.ell = ell
         self.n = ell + N_BLINDERS
         self.crs_points = bytes(points)
@@ -189,13 +192,16 @@ class Context:
 
     def fold(self, PL, PR, gamma):
         half = len(PL) // AFF
-        assert len(PR) == len(PL) and len(gamma) == FR
+        if len(PR) != len(PL) or len(PL) % AFF or len(gamma) != FR:
+            raise ValueError("fold: PL / PR must hold the same number of affine points, gamma one scalar")
         b = _in(PL)
         self._check(self._L.cpx_g1_fold(self._h, b, _in(PR), _in(gamma), half))
         return bytes(b)[: AFF * half]
 
     def scale(self, P, scalars):
         n = len(P) // AFF
+        if len(P) % AFF or len(scalars) not in (FR, FR * n):
+            raise ValueError("scale: one shared scalar or one scalar per point")
         stride = 0 if len(scalars) == FR else FR
         o = _out(AFF * n)
         self._check(self._L.cpx_g1_scale(self._h, _in(P), _in(scalars), stride, n, o))
@@ -216,9 +222,14 @@ class Context:
     # ---- tier 2 ----
     def load_batch(self, vec_R, vec_S, vec_T, vec_U, M):
         """Uploads `batch` instances (concatenated per-proof buffers)."""
+        if self.ell is None:
+            raise CpxError(CPX_ERR_STATE, "set_crs first")
         batch = len(M) // JAC
+        if batch == 0 or len(M) % JAC:
+            raise ValueError("M: one Jacobian point (144 bytes) per instance")
         for v in (vec_R, vec_S, vec_T, vec_U):
-            assert len(v) == batch * self.ell * AFF
+            if len(v) != batch * self.ell * AFF:
+                raise ValueError("every instance vector must hold batch * ell affine points (%d bytes), got %d" % (batch * self.ell * AFF, len(v)))
         self._check(self._L.cpx_batch_load(self._h, batch, _in(vec_R), _in(vec_S), _in(vec_T), _in(vec_U), _in(M)))
         self.batch = batch
 
@@ -234,8 +245,13 @@ class Context:
         """CurdleproofsProof::new for every loaded instance; returns a list of serialized proofs
         (or, with raw=True, the ctypes buffer holding all of them back to back)."""
         B, ell, n = self.batch, self.ell, self.n
-        perm = permutations if isinstance(permutations, ctypes.Array) else (ctypes.c_uint32 * (B * ell))(*permutations)
-        assert _len(k) == B * FR and _len(vec_m_blinders) == B * 4 * FR and _len(rand) == B * (3 * n + 9) * FR
+        if not isinstance(permutations, ctypes.Array):
+            if len(permutations) != B * ell:
+                raise ValueError("permutations: batch * ell entries")
+            permutations = (ctypes.c_uint32 * (B * ell))(*permutations)
+        perm = permutations
+        if ctypes.sizeof(perm) != 4 * B * ell or _len(k) != B * FR or _len(vec_m_blinders) != B * 4 * FR or _len(rand) != B * (3 * n + 9) * FR:
+            raise ValueError("prove_batch: per instance ell u32 permutation entries, k (32 B), 4 blinders, 3n+9 random scalars")
         psz = self.proof_size
         out = _out(B * psz)
         self._check(self._L.cpx_batch_prove(self._h, perm, _in(k), _in(vec_m_blinders), _in(rand), out))
@@ -250,7 +266,8 @@ class Context:
         B = self.batch
         psz = self.proof_size
         blob = proofs if isinstance(proofs, ctypes.Array) else b"".join(proofs)
-        assert _len(blob) == B * psz and _len(rand) == B * 8 * FR
+        if _len(blob) != B * psz or _len(rand) != B * 8 * FR:
+            raise ValueError("verify_batch: batch * proof_size proof bytes and 8 random factors per proof")
         verdict = (ctypes.c_int * B)()
         self._check(self._L.cpx_batch_verify(self._h, _in(blob), _in(rand), verdict))
         return list(verdict)
@@ -260,6 +277,8 @@ class Context:
         """BASELINE config 5: one accumulated MSM over all loaded proofs.  `rand`: 12 Fr per proof.
         Returns (partial sum as a 144-byte Jacobian point, number of structurally invalid proofs)."""
         data = proofs if isinstance(proofs, (bytes, bytearray)) or hasattr(proofs, "_length_") else b"".join(proofs)
+        if _len(data) != self.batch * self.proof_size or _len(rand) != self.batch * 12 * FR:
+            raise ValueError("verify_batch_fused: batch * proof_size proof bytes and 12 random factors per proof")
         out = _out(JAC)
         bad = ctypes.c_int(0)
         self._check(self._L.cpx_batch_verify_fused(self._h, _in(data), _in(rand), out, ctypes.byref(bad)))
@@ -268,6 +287,8 @@ class Context:
     def sum_jac(self, points_jac):
         """sum of Jacobian points -> (sum, is_identity)"""
         n = len(points_jac) // JAC
+        if len(points_jac) % JAC:
+            raise ValueError("sum_jac: 144 bytes per point")
         out = _out(JAC)
         flag = ctypes.c_int(0)
         self._check(self._L.cpx_g1_sum_jac(self._h, _in(points_jac), n, out, ctypes.byref(flag)))
@@ -290,7 +311,7 @@ class Context:
         return dict(launches=n.value, ms=ms.value, alg_bytes=by.value, units=un.value)
 
     KERNELS = ("k_msm_tblw<32, false>", "k_reduce_sets", "k_msm_tblw<16, false>", "k_msm_tblw<8, false>", "k_msm_tblw<4, false>", "k_msm_tblw<2, false>", "k_msm_fix<16, 4>", "k_msm_fix<16, 2>", "k_msm_fix<16, 16>", "k_msm_fix<16, 8>", "k_msm_fix<8, 16>", "k_msm_fix<8, 8>",
-               "k_finalize_ranges", "k_table_build", "k_msm_accw", "k_msm_tblw<2, true>", "big_msm", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_wait_baton", "host_prove_wall", "host_verify_wall")
+               "k_finalize_ranges", "k_table_build", "k_msm_accw", "k_msm_tblw<2, true>", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_wait_baton", "host_prove_wall", "host_verify_wall")
 
     def stats(self):
         return {k: self.stat(k) for k in self.KERNELS}

@@ -35,6 +35,9 @@ template <class F> int guarded(cpx_ctx* ctx, F&& f) {
   } catch (const HipError& e) {
     ctx->err = e.what();
     return CPX_ERR_HIP;
+  } catch (const ArgError& e) {
+    ctx->err = e.what();
+    return CPX_ERR_ARG;
   } catch (const std::invalid_argument& e) {
     ctx->err = e.what();
     return CPX_ERR_NOT_POW2;
@@ -85,8 +88,12 @@ void cpx_ctx_destroy(cpx_ctx* ctx) {
 }
 const char* cpx_last_error(const cpx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
-int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points) {
+int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points, size_t n_points) {
   if (!points) return CPX_ERR_ARG;
+  if (n_points < ell + 7) {   // crs.rs:40-42 "not enough points"
+    if (ctx) ctx->err = "CurdleproofsCrs::from_points: not enough points (need ell + 7)";
+    return CPX_ERR_ARG;
+  }
   return guarded(ctx, [&] {
     ctx->eng->set_crs(ell, points);
     return CPX_OK;
@@ -154,6 +161,7 @@ int cpx_accum_check(cpx_accum* acc, const uint8_t C[144], const uint8_t* vec_x, 
   return guarded(acc->ctx, [&] {
     host::S a;
     memcpy(a.f.v, random_factor, 32);
+    if (!host::is_valid_factor(random_factor)) throw ArgError("random_factor must be a non-zero reduced field element (msm_accumulator.rs:44 draws Fr::rand)");
     acc->lhs_points.insert(acc->lhs_points.end(), C, C + 144);
     acc->lhs_scalars.push_back(a);
     for (size_t i = 0; i < n; i++) {

@@ -54,15 +54,21 @@ static inline S S_from_wire(const uint8_t* b) {
 }
 
 Engine::Engine(int device) : device_(device) {
-  CPX_HIP(hipSetDevice(device_));
-  CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  CPX_HIP(hipStreamCreateWithFlags(&side_.stream, hipStreamNonBlocking));
-  CPX_HIP(hipEventCreateWithFlags(&side_.ev, hipEventDisableTiming));
+  try {
+    CPX_HIP(hipSetDevice(device_));
+    CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    CPX_HIP(hipStreamCreateWithFlags(&side_.stream, hipStreamNonBlocking));
+    CPX_HIP(hipEventCreateWithFlags(&side_.ev, hipEventDisableTiming));
+  } catch (...) {   // a half-built engine owns nothing afterwards
+    if (side_.ev) (void)hipEventDestroy(side_.ev);
+    if (side_.stream) (void)hipStreamDestroy(side_.stream);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    throw;
+  }
   baton_register(+1);
-  if (const char* e = getenv("CPX_PROVER")) use_tables_ = std::string(e) != "fold";
   if (const char* e = getenv("CPX_FIX_BITS")) {
     int c = atoi(e);
-    if (c == 8 || c == 16) fix_bits_ = c;   // radix of the fixed-base CRS table (8: 0.1 GB, 16: 15 GB at ell = 252)
+    if (c == 8 || c == 16) fix_bits_cfg_ = fix_bits_ = c;   // radix of the fixed-base CRS table (8: 0.1 GB, 16: 15 GB at ell = 252)
   }
 }
 Engine::~Engine() {
@@ -559,6 +565,17 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
 void Engine::set_crs(size_t ell, const uint8_t* points) {
   const size_t n = ell + N_BLINDERS;
   if (ell == 0 || (n & (n - 1))) throw std::invalid_argument("ell + 4 must be a power of two");
+  try {
+    set_crs_impl(ell, points);
+  } catch (...) {   // e.g. out of device memory while building the tables: the context is left without a CRS, not half-initialised
+    ell_ = n_ = L_ = 0;
+    B_ = 0;
+    crs_tab_.reset();
+    throw;
+  }
+}
+void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
+  const size_t n = ell + N_BLINDERS;
   CPX_HIP(hipSetDevice(device_));
   ell_ = ell;
   n_ = n;
@@ -605,7 +622,17 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
     static std::vector<std::weak_ptr<CrsTables>> registry;
     std::lock_guard<std::mutex> lk(reg_mu);
     const size_t NC = nc();
-    const int want_fix = fix_bits_;   // the verifier needs the table whichever prover is selected
+    int want_fix = fix_bits_cfg_;
+    if (want_fix == 16) {   // 15 GB at ell = 252, 60 GB at ell = 1020: fall back to the radix-2^8 table (0.1 GB / 0.4 GB) when HBM is short
+      size_t free_b = 0, total_b = 0;
+      CPX_HIP(hipMemGetInfo(&free_b, &total_b));
+      const size_t need = (size_t)16 * ((size_t)1 << 15) * NC * sizeof(TAff) + (size_t)(16 * NC + 63) * 256 * sizeof(TblTmp);
+      bool have = false;   // an existing shared table costs nothing
+      for (auto& w : registry)
+        if (auto sp = w.lock()) have |= sp->device == device_ && sp->fix_bits == 16 && sp->key.size() == (ell + 7) * sizeof(Aff) && !memcmp(sp->key.data(), points, sp->key.size());
+      if (!have && need + (need >> 3) > free_b) want_fix = 8;
+    }
+    fix_bits_ = want_fix;
     std::vector<uint8_t> key(points, points + (ell + 7) * sizeof(Aff));
     crs_tab_.reset();
     for (auto it = registry.begin(); it != registry.end();) {
@@ -843,7 +870,6 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
   pp_stride_ = 4 * ell_ + sm.count();
   d_pp_.ensure(batch * pp_stride_);
   d_Mjac_.ensure(batch);
-  for (DevBuf<Aff>* w : {&d_wGi_, &d_wGp_, &d_wGm_, &d_wT_, &d_wU_}) w->ensure(batch * (n_ + 1));
   B_ = batch;
   const size_t vb = ell_ * sizeof(Aff);
   // strided 2-D copies: one per instance vector instead of one per proof
@@ -860,7 +886,7 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
   rows(slot(0, SL_H), pitch, reinterpret_cast<const uint8_t*>(rep.data()), 5 * sizeof(Aff), 5 * sizeof(Aff));
   CPX_HIP(hipMemcpyAsync(d_Mjac_.p, M, batch * sizeof(Jac), hipMemcpyHostToDevice, stream_));
   std::vector<Aff> tails;   // outlives the asynchronous copies below (synchronised at the end of this function)
-  if (use_tables_) {
+  {
     // copy 0 of the per-proof tables: M (filled at prove time) | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
     const size_t NP = np();
     d_ptab_.ensure(batch * (size_t)copies_ * NP);
@@ -899,459 +925,8 @@ struct ProverState {
 
 void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   if (!B_) throw std::logic_error("batch_load first");
-  if (use_tables_) batch_prove_tables(permutation, k_in, m_blinders, rand, proofs_out);
-  else batch_prove_fold(permutation, k_in, m_blinders, rand, proofs_out);
+  batch_prove_tables(permutation, k_in, m_blinders, rand, proofs_out);
 }
-
-// Fold-based prover: mirrors the reference's loop structure (basis folds + shrinking MSMs).
-void Engine::batch_prove_fold(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
-  CPX_HIP(hipSetDevice(device_));
-  const size_t B = B_, ell = ell_, n = n_, L = L_;
-  const SlotMap sm(L);
-  const size_t nrand = 3 * n + 9;
-  const int NS = sm.count();
-  std::vector<ProverState> st(B);
-  std::vector<uint8_t> comp;
-
-  // draw indices: a_blinders 0-1, c_blinders 2-5, ipa r 6.., ipa z 6+n.., r_t, r_u, r_a, r_b, r_k, vec_r
-  const size_t I_AB = 0, I_CB = 2, I_IR = 6, I_IZ = 6 + n, I_RT = 2 * n + 4, I_RU = 2 * n + 5, I_RA = 2 * n + 6, I_RB = 2 * n + 7,
-               I_RK = 2 * n + 8, I_VR = 2 * n + 9;
-
-  // -- reset the folding work vectors (device-to-device)
-  {
-    std::vector<Aff> tail_T(4, Aff::identity()), tail_U(4, Aff::identity());
-    tail_T[2] = crs_single_[0];
-    tail_U[3] = crs_single_[0];
-    DevBuf<Aff> d_tail;
-    d_tail.ensure(8);
-    CPX_HIP(hipMemcpyAsync(d_tail.p, tail_T.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
-    CPX_HIP(hipMemcpyAsync(d_tail.p + 4, tail_U.data(), 4 * sizeof(Aff), hipMemcpyHostToDevice, stream_));
-    for (size_t p = 0; p < B; p++) {
-      CPX_HIP(hipMemcpyAsync(d_wGi_.p + p * (n + 1), d_crs_.p, (n + 1) * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(d_wGm_.p + p * (n + 1), d_crs_gb_.p, n * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(d_wT_.p + p * (n + 1), pp(p) + 2 * ell, ell * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(d_wT_.p + p * (n + 1) + ell, d_tail.p, 4 * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(d_wU_.p + p * (n + 1), pp(p) + 3 * ell, ell * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
-      CPX_HIP(hipMemcpyAsync(d_wU_.p + p * (n + 1) + ell, d_tail.p + 4, 4 * sizeof(Aff), hipMemcpyDeviceToDevice, stream_));
-    }
-    CPX_HIP(hipStreamSynchronize(stream_));   // d_tail goes out of scope
-  }
-
-  // -- P0: compressed instance vectors + M for the transcript (curdleproofs.rs:81-82)
-  std::vector<uint8_t> inst_comp(B * 4 * ell * 48);
-  {
-    d_bytes_.ensure(B * 4 * ell * 48);
-    tick("k_compress", 0, (double)(4 * ell * B));
-    launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
-    tock();
-    d_res_.ensure(B);
-    d_dst_.ensure(B);
-    d_comp_.ensure(B * 48);
-    std::vector<uint32_t> dst(B);
-    for (size_t p = 0; p < B; p++) dst[p] = slot_index(p, SL_M);
-    CPX_HIP(hipMemcpyAsync(d_dst_.p, dst.data(), B * 4, hipMemcpyHostToDevice, stream_));
-    launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
-    std::vector<uint8_t> mcomp(B * 48);
-    CPX_HIP(hipMemcpyAsync(inst_comp.data(), d_bytes_.p, inst_comp.size(), hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipMemcpyAsync(mcomp.data(), d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipStreamSynchronize(stream_));
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      s.rnd = rand + p * nrand * 32;
-      s.comp.assign((size_t)NS * 48, 0);
-      memcpy(&s.comp[SL_M * 48], &mcomp[p * 48], 48);
-      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
-      for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
-      s.tr.append_point_bytes("curdleproofs_step1", &s.comp[SL_M * 48]);
-      s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
-      const uint32_t* perm = permutation + p * ell;
-      s.a_perm.resize(ell);
-      for (size_t i = 0; i < ell; i++) s.a_perm[i] = s.vec_a[perm[i]];
-      // scalars of phase 1
-      s.scal[0] = s.a_perm;                                                   // A over G | Hvec
-      s.scal[0].push_back(s.draw(I_AB));
-      s.scal[0].push_back(s.draw(I_AB + 1));
-      s.scal[0].push_back(S::zero());
-      s.scal[0].push_back(S::zero());
-      s.scal[1].resize(n);                                                    // vec_r of SameMSM
-      for (size_t i = 0; i < n; i++) s.scal[1][i] = s.draw(I_VR + i);
-      s.scal[2] = {s.draw(I_RT), s.draw(I_RU), s.draw(I_RA), s.draw(I_RB)};
-    });
-  }
-
-  auto take = [&](size_t p, int slot_id, size_t req_index) { memcpy(&st[p].comp[(size_t)slot_id * 48], &comp[req_index * 48], 48); };
-  const uint32_t* idx_gt = idx_list({(uint32_t)SL_GT});
-  const uint32_t* idx_gu = idx_list({(uint32_t)SL_GU});
-
-  // -- P1: A, R, S, B_a, B_t, B_u and the four r*G commitments halves
-  {
-    std::vector<MsmReq> reqs;
-    for (size_t p = 0; p < B; p++) {
-      ProverState& s = st[p];
-      reqs.push_back({d_crs_.p, nullptr, s.scal[0].data(), (uint32_t)n, slot_index(p, SL_A)});
-      reqs.push_back({pp(p), nullptr, s.vec_a.data(), (uint32_t)ell, slot_index(p, SL_R)});
-      reqs.push_back({pp(p) + ell, nullptr, s.vec_a.data(), (uint32_t)ell, slot_index(p, SL_S)});
-      reqs.push_back({d_wGm_.p + p * (n + 1), nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, sm.BA())});
-      reqs.push_back({d_wT_.p + p * (n + 1), nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, sm.BT())});
-      reqs.push_back({d_wU_.p + p * (n + 1), nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, sm.BU())});
-      reqs.push_back({slot(p, 0), idx_gt, &s.scal[2][0], 1, slot_index(p, SL_CMT1)});
-      reqs.push_back({slot(p, 0), idx_gu, &s.scal[2][1], 1, slot_index(p, SL_CMU1)});
-      reqs.push_back({slot(p, 0), idx_gt, &s.scal[2][2], 1, slot_index(p, sm.CMA1())});
-      reqs.push_back({slot(p, 0), idx_gu, &s.scal[2][3], 1, slot_index(p, sm.CMB1())});
-    }
-    run_msm_phase(reqs, &comp);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      const int ids[10] = {SL_A, SL_R, SL_S, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1()};
-      for (int i = 0; i < 10; i++) take(p, ids[i], p * 10 + i);
-      // same_permutation_argument.rs:60-83
-      s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_A * 48]);
-      s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_M * 48]);
-      s.tr.append_scalar_vec("same_perm_step1", s.vec_a);
-      s.alpha_sp = s.tr.get_and_append_challenge("same_perm_alpha");
-      s.beta_sp = s.tr.get_and_append_challenge("same_perm_beta");
-      const uint32_t* perm = permutation + p * ell;
-      s.factors.resize(ell);
-      s.gprod = S::one();
-      for (size_t i = 0; i < ell; i++) {
-        s.factors[i] = s.a_perm[i] + S::from_u64(perm[i]) * s.alpha_sp + s.beta_sp;
-        s.gprod *= s.factors[i];
-      }
-      const S kk = S_from_wire(k_in + 32 * p), r_t = s.draw(I_RT), r_u = s.draw(I_RU), r_a = s.draw(I_RA), r_b = s.draw(I_RB), r_k = s.draw(I_RK);
-      s.scal[0] = {S::one(), s.alpha_sp, s.beta_sp};   // B = A + alpha M + beta G_sum  (= msm(G, [beta; ell]), crs.rs:31)
-      s.scal[1] = {kk, r_t};                           // cm_T.T_2 = k R + r_t H     (curdleproofs.rs:115)
-      s.scal[2] = {kk, r_u};                           // cm_U.T_2
-      s.scal[3] = {r_k, r_a};                          // cm_A.T_2                   (same_scalar_argument.rs:60)
-      s.scal[4] = {r_k, r_b};                          // cm_B.T_2
-      s.scal[5] = {S::one(), S::one(), S::one()};      // A' = A + cm_T.T_1 + cm_U.T_1 (curdleproofs.rs:134)
-    });
-  }
-
-  // -- P2: B, the T_2 halves, A'
-  {
-    const uint32_t* iB = idx_list({(uint32_t)SL_A, (uint32_t)SL_M, (uint32_t)SL_GSUM});
-    const uint32_t* iRH = idx_list({(uint32_t)SL_R, (uint32_t)SL_H});
-    const uint32_t* iSH = idx_list({(uint32_t)SL_S, (uint32_t)SL_H});
-    const uint32_t* iAp = idx_list({(uint32_t)SL_A, (uint32_t)SL_CMT1, (uint32_t)SL_CMU1});
-    std::vector<MsmReq> reqs;
-    for (size_t p = 0; p < B; p++) {
-      ProverState& s = st[p];
-      reqs.push_back({slot(p, 0), iB, s.scal[0].data(), 3, slot_index(p, SL_B)});
-      reqs.push_back({slot(p, 0), iRH, s.scal[1].data(), 2, slot_index(p, SL_CMT2)});
-      reqs.push_back({slot(p, 0), iSH, s.scal[2].data(), 2, slot_index(p, SL_CMU2)});
-      reqs.push_back({slot(p, 0), iRH, s.scal[3].data(), 2, slot_index(p, sm.CMA2())});
-      reqs.push_back({slot(p, 0), iSH, s.scal[4].data(), 2, slot_index(p, sm.CMB2())});
-      reqs.push_back({slot(p, 0), iAp, s.scal[5].data(), 3, slot_index(p, sm.APRIME())});
-    }
-    run_msm_phase(reqs, &comp);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      const int ids[6] = {SL_B, SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2(), sm.APRIME()};
-      for (int i = 0; i < 6; i++) take(p, ids[i], p * 6 + i);
-      // grand_product_argument.rs:63-76
-      s.tr.append_point_bytes("gprod_step1", &s.comp[SL_B * 48]);
-      s.tr.append_scalar("gprod_step1", s.gprod);
-      s.alpha_g = s.tr.get_and_append_challenge("gprod_alpha");
-      s.c.assign(1, S::one());
-      for (size_t i = 0; i + 1 < ell; i++) s.c.push_back(s.c[i] * s.factors[i]);
-      s.vec_c_blinders.resize(N_BLINDERS);
-      for (size_t i = 0; i < N_BLINDERS; i++) s.vec_c_blinders[i] = s.draw(I_CB + i);
-      s.scal[0] = s.c;
-      s.scal[0].insert(s.scal[0].end(), s.vec_c_blinders.begin(), s.vec_c_blinders.end());
-    });
-  }
-
-  // -- P3: C
-  {
-    std::vector<MsmReq> reqs;
-    for (size_t p = 0; p < B; p++) reqs.push_back({d_crs_.p, nullptr, st[p].scal[0].data(), (uint32_t)n, slot_index(p, SL_C)});
-    run_msm_phase(reqs, &comp);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      take(p, SL_C, p);
-      // grand_product_argument.rs:78-148
-      const S mb[4] = {S_from_wire(m_blinders + (p * 4 + 0) * 32), S_from_wire(m_blinders + (p * 4 + 1) * 32),
-                       S_from_wire(m_blinders + (p * 4 + 2) * 32), S_from_wire(m_blinders + (p * 4 + 3) * 32)};
-      const S ab[4] = {s.draw(I_AB), s.draw(I_AB + 1), S::zero(), S::zero()};
-      s.rb_plus_alpha.resize(N_BLINDERS);
-      for (size_t i = 0; i < N_BLINDERS; i++) s.rb_plus_alpha[i] = (ab[i] + s.alpha_sp * mb[i]) + s.alpha_g;   // vec_b_blinders + alpha
-      s.r_p = host::inner_product(s.rb_plus_alpha.data(), s.vec_c_blinders.data(), N_BLINDERS);
-      s.tr.append_point_bytes("gprod_step2", &s.comp[SL_C * 48]);
-      s.tr.append_scalar("gprod_step2", s.r_p);
-      s.beta_g = s.tr.get_and_append_challenge("gprod_beta");
-      s.beta_g_inv = s.beta_g.inverse();
-      // u_i = beta^-(i+1) (i < ell), beta^-(ell+1) for the blinder bases: G'_i = u_i G_i
-      s.u.resize(n);
-      S pw = s.beta_g_inv;
-      for (size_t i = 0; i < ell; i++) {
-        s.u[i] = pw;
-        pw *= s.beta_g_inv;
-      }
-      for (size_t i = ell; i < n; i++) s.u[i] = pw;   // pw = beta^-(ell+1)
-      // d = b' - beta powers ; b'_i = b_i beta^(i+1)
-      s.d.resize(n);
-      S pb = s.beta_g, pbm = S::one();
-      for (size_t i = 0; i < ell; i++) {
-        s.d[i] = s.factors[i] * pb - pbm;
-        pbm = pb;
-        pb *= s.beta_g;
-      }
-      const S beta_l1 = pbm * s.beta_g;   // pbm = beta^ell after the loop
-      const S beta_l = pbm;
-      for (size_t i = 0; i < N_BLINDERS; i++) s.d[ell + i] = beta_l1 * s.rb_plus_alpha[i];
-      s.c.insert(s.c.end(), s.vec_c_blinders.begin(), s.vec_c_blinders.end());
-      s.z_ip = s.r_p * beta_l1 + s.gprod * beta_l - S::one();
-      // D = B - beta^-1 G_sum + alpha H_sum (grand_product_argument.rs:132 == :223)
-      s.scal[0] = {S::one(), -s.beta_g_inv, s.alpha_g};
-      // generate_ipa_blinders (inner_product_argument.rs:42-82)
-      SVec r(n), zz(n);
-      for (size_t i = 0; i < n; i++) r[i] = s.draw(I_IR + i);
-      for (size_t i = 0; i + 2 < n; i++) zz[i] = s.draw(I_IZ + i);
-      const S omega = host::inner_product(r.data(), s.d.data(), n) + host::inner_product(zz.data(), s.c.data(), n - 2);
-      const S delta = host::inner_product(r.data(), zz.data(), n - 2);
-      const S inv_c = s.c[n - 2].inverse();
-      const S last_z = (r[n - 2] * inv_c * omega - delta) * ((-r[n - 2]) * inv_c * s.c[n - 1] + r[n - 1]).inverse();
-      const S pen_z = (-inv_c) * (last_z * s.c[n - 1] + omega);
-      zz[n - 2] = pen_z;
-      zz[n - 1] = last_z;
-      s.scal[1] = r;    // r_c  -> B_c over G
-      s.scal[2] = zz;   // r_d  -> B_d over G'
-    });
-  }
-
-  // -- P4: D, G' = u o G, B_c, B_d
-  {
-    // rescaled basis (grand_product_argument.rs:90-102)
-    std::vector<SmulTask> tasks;
-    SVec us(B * n);
-    d_scal_.ensure(std::max<size_t>(B * n, 1));
-    for (size_t p = 0; p < B; p++) {
-      for (size_t i = 0; i < n; i++) us[p * n + i] = st[p].u[i];
-      tasks.push_back(SmulTask{nullptr, d_crs_.p, d_wGp_.p + p * (n + 1), d_scal_.p + p * n, 1, 0});
-    }
-    run_smul(tasks, (int)n, us.data(), us.size(), 224.0 * n * B);
-    const uint32_t* iD = idx_list({(uint32_t)SL_B, (uint32_t)SL_GSUM, (uint32_t)SL_HSUM});
-    std::vector<MsmReq> reqs;
-    for (size_t p = 0; p < B; p++) {
-      ProverState& s = st[p];
-      reqs.push_back({slot(p, 0), iD, s.scal[0].data(), 3, slot_index(p, sm.D())});
-      reqs.push_back({d_crs_.p, nullptr, s.scal[1].data(), (uint32_t)n, slot_index(p, SL_BC)});
-      reqs.push_back({d_wGp_.p + p * (n + 1), nullptr, s.scal[2].data(), (uint32_t)n, slot_index(p, SL_BD)});
-    }
-    run_msm_phase(reqs, &comp);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      take(p, sm.D(), p * 3);
-      take(p, SL_BC, p * 3 + 1);
-      take(p, SL_BD, p * 3 + 2);
-      // inner_product_argument.rs:129-139
-      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_C * 48]);
-      s.tr.append_point_bytes("ipa_step1", &s.comp[sm.D() * 48]);
-      s.tr.append_scalar("ipa_step1", s.z_ip);
-      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_BC * 48]);
-      s.tr.append_point_bytes("ipa_step1", &s.comp[SL_BD * 48]);
-      s.alpha_i = s.tr.get_and_append_challenge("ipa_alpha");
-      s.beta_i = s.tr.get_and_append_challenge("ipa_beta");
-      for (size_t i = 0; i < n; i++) {
-        s.c[i] = s.scal[1][i] + s.alpha_i * s.c[i];
-        s.d[i] = s.scal[2][i] + s.alpha_i * s.d[i];
-      }
-    });
-  }
-
-  // -- P5: IPA rounds (inner_product_argument.rs:150-186)
-  for (size_t j = 0; j < L; j++) {
-    const size_t half = n >> (j + 1);
-    std::vector<uint32_t> il(half + 1), ir(half + 1);
-    for (size_t i = 0; i < half; i++) {
-      il[i] = (uint32_t)(half + i);   // G_R
-      ir[i] = (uint32_t)i;            // G_L
-    }
-    il[half] = ir[half] = (uint32_t)n;   // H rides along as one more base: H^(beta <c,d>)
-    const uint32_t* d_il = idx_list(il);
-    const uint32_t* d_ir = idx_list(ir);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      const S* cL = s.c.data();
-      const S* cR = cL + half;
-      const S* dL = s.d.data();
-      const S* dR = dL + half;
-      s.scal[0].assign(cL, cL + half);
-      s.scal[0].push_back(s.beta_i * host::inner_product(cL, dR, half));   // L_C
-      s.scal[1].assign(dR, dR + half);                                     // L_D over G'_L
-      s.scal[2].assign(cR, cR + half);
-      s.scal[2].push_back(s.beta_i * host::inner_product(cR, dL, half));   // R_C
-      s.scal[3].assign(dL, dL + half);                                     // R_D over G'_R
-    });
-    std::vector<MsmReq> reqs;
-    for (size_t p = 0; p < B; p++) {
-      ProverState& s = st[p];
-      Aff* Gi = d_wGi_.p + p * (n + 1);
-      Aff* Gp = d_wGp_.p + p * (n + 1);
-      reqs.push_back({Gi, d_il, s.scal[0].data(), (uint32_t)half + 1, slot_index(p, sm.LC((int)j))});
-      reqs.push_back({Gp, nullptr, s.scal[1].data(), (uint32_t)half, slot_index(p, sm.LD((int)j))});
-      reqs.push_back({Gi, d_ir, s.scal[2].data(), (uint32_t)half + 1, slot_index(p, sm.RC((int)j))});
-      reqs.push_back({Gp + half, nullptr, s.scal[3].data(), (uint32_t)half, slot_index(p, sm.RD((int)j))});
-    }
-    run_msm_phase(reqs, &comp);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      take(p, sm.LC((int)j), p * 4);
-      take(p, sm.LD((int)j), p * 4 + 1);
-      take(p, sm.RC((int)j), p * 4 + 2);
-      take(p, sm.RD((int)j), p * 4 + 3);
-      const int order[4] = {sm.LC((int)j), sm.LD((int)j), sm.RC((int)j), sm.RD((int)j)};
-      for (int q : order) s.tr.append_point_bytes("ipa_loop", &s.comp[(size_t)q * 48]);
-      const S gamma = s.tr.get_and_append_challenge("ipa_gamma");
-      const S gamma_inv = gamma.inverse();
-      for (size_t i = 0; i < half; i++) {
-        s.c[i] += gamma_inv * s.c[half + i];
-        s.d[i] += gamma * s.d[half + i];
-      }
-      s.gam[0] = gamma;
-      s.gam[1] = gamma_inv;
-    });
-    {
-      // fold the two bases; the reference also folds after the last round (inner_product_argument.rs:174-179)
-      // but nothing reads that output, so it is skipped here
-      if (j + 1 < L) {
-        std::vector<SmulTask> tasks;
-        SVec gs(2 * B);
-        d_scal_.ensure(2 * B);
-        for (size_t p = 0; p < B; p++) {
-          gs[2 * p] = st[p].gam[0];
-          gs[2 * p + 1] = st[p].gam[1];
-          Aff* Gi = d_wGi_.p + p * (n + 1);
-          Aff* Gp = d_wGp_.p + p * (n + 1);
-          tasks.push_back(SmulTask{Gi, Gi + half, Gi, d_scal_.p + 2 * p, 0, 0});
-          tasks.push_back(SmulTask{Gp, Gp + half, Gp, d_scal_.p + 2 * p + 1, 0, 0});
-        }
-        run_smul(tasks, (int)half, gs.data(), gs.size(), 288.0 * half * 2 * B);
-      }
-    }
-  }
-
-  // -- P6 (host only): SameScalar transcript, SameMSM step 1
-  {
-    const std::vector<uint8_t> id_comp = [] {
-      std::vector<uint8_t> v(48, 0);
-      v[0] = 0xc0;
-      return v;
-    }();
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      s.c_final = s.c[0];
-      s.d_final = s.d[0];
-      // same_scalar_argument.rs:63-84
-      const int pts[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
-      for (int q : pts) s.tr.append_point_bytes("sameexp_points", &s.comp[(size_t)q * 48]);
-      const S alpha = s.tr.get_and_append_challenge("same_scalar_alpha");
-      const S kk = S_from_wire(k_in + 32 * p);
-      s.z_k = s.draw(I_RK) + kk * alpha;
-      s.z_t = s.draw(I_RA) + s.draw(I_RT) * alpha;
-      s.z_u = s.draw(I_RB) + s.draw(I_RU) * alpha;
-      // same_multiscalar_argument.rs:84-91
-      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.APRIME() * 48]);
-      s.tr.append_point_bytes("same_msm_step1", &s.comp[SL_CMT2 * 48]);
-      s.tr.append_point_bytes("same_msm_step1", &s.comp[SL_CMU2 * 48]);
-      std::vector<uint8_t> vb(n * 48);
-      const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
-      memcpy(vb.data(), ic + 2 * ell * 48, ell * 48);   // vec_T || O O H O
-      const uint8_t* tailT[4] = {id_comp.data(), id_comp.data(), crs_H_comp_, id_comp.data()};
-      for (int i = 0; i < 4; i++) memcpy(&vb[(ell + i) * 48], tailT[i], 48);
-      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
-      memcpy(vb.data(), ic + 3 * ell * 48, ell * 48);   // vec_U || O O O H
-      const uint8_t* tailU[4] = {id_comp.data(), id_comp.data(), id_comp.data(), crs_H_comp_};
-      for (int i = 0; i < 4; i++) memcpy(&vb[(ell + i) * 48], tailU[i], 48);
-      s.tr.append_point_vec_bytes("same_msm_step1", vb.data(), n);
-      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BA() * 48]);
-      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BT() * 48]);
-      s.tr.append_point_bytes("same_msm_step1", &s.comp[(size_t)sm.BU() * 48]);
-      s.alpha_m = s.tr.get_and_append_challenge("same_msm_alpha");
-      // x = vec_r + alpha * (sigma(a) | a_blinders | r_t | r_u)   (curdleproofs.rs:157-160)
-      s.x.resize(n);
-      for (size_t i = 0; i < ell; i++) s.x[i] = s.draw(I_VR + i) + s.alpha_m * s.a_perm[i];
-      s.x[ell] = s.draw(I_VR + ell) + s.alpha_m * s.draw(I_AB);
-      s.x[ell + 1] = s.draw(I_VR + ell + 1) + s.alpha_m * s.draw(I_AB + 1);
-      s.x[ell + 2] = s.draw(I_VR + ell + 2) + s.alpha_m * s.draw(I_RT);
-      s.x[ell + 3] = s.draw(I_VR + ell + 3) + s.alpha_m * s.draw(I_RU);
-    });
-  }
-
-  // -- P7: SameMSM rounds (same_multiscalar_argument.rs:99-136)
-  for (size_t j = 0; j < L; j++) {
-    const size_t half = n >> (j + 1);
-    std::vector<MsmReq> reqs;
-    for (size_t p = 0; p < B; p++) {
-      ProverState& s = st[p];
-      const S* xL = s.x.data();
-      const S* xR = xL + half;
-      Aff* G = d_wGm_.p + p * (n + 1);
-      Aff* T = d_wT_.p + p * (n + 1);
-      Aff* U = d_wU_.p + p * (n + 1);
-      reqs.push_back({G + half, nullptr, xL, (uint32_t)half, slot_index(p, sm.LA((int)j))});
-      reqs.push_back({T + half, nullptr, xL, (uint32_t)half, slot_index(p, sm.LT((int)j))});
-      reqs.push_back({U + half, nullptr, xL, (uint32_t)half, slot_index(p, sm.LU((int)j))});
-      reqs.push_back({G, nullptr, xR, (uint32_t)half, slot_index(p, sm.RA((int)j))});
-      reqs.push_back({T, nullptr, xR, (uint32_t)half, slot_index(p, sm.RT((int)j))});
-      reqs.push_back({U, nullptr, xR, (uint32_t)half, slot_index(p, sm.RU((int)j))});
-    }
-    run_msm_phase(reqs, &comp);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      const int order[6] = {sm.LA((int)j), sm.LT((int)j), sm.LU((int)j), sm.RA((int)j), sm.RT((int)j), sm.RU((int)j)};
-      for (int i = 0; i < 6; i++) take(p, order[i], p * 6 + i);
-      for (int q : order) s.tr.append_point_bytes("same_msm_loop", &s.comp[(size_t)q * 48]);
-      const S gamma = s.tr.get_and_append_challenge("same_msm_gamma");
-      const S gamma_inv = gamma.inverse();
-      for (size_t i = 0; i < half; i++) s.x[i] += gamma_inv * s.x[half + i];
-      s.gam[0] = gamma;
-    });
-    if (j + 1 < L) {
-      std::vector<SmulTask> tasks;
-      SVec gs(B);
-      d_scal_.ensure(B);
-      for (size_t p = 0; p < B; p++) {
-        gs[p] = st[p].gam[0];
-        for (DevBuf<Aff>* w : {&d_wGm_, &d_wT_, &d_wU_}) {
-          Aff* V = w->p + p * (n + 1);
-          tasks.push_back(SmulTask{V, V + half, V, d_scal_.p + p, 0, 0});
-        }
-      }
-      run_smul(tasks, (int)half, gs.data(), gs.size(), 288.0 * half * 3 * B);
-    }
-  }
-
-  // -- serialise (curdleproofs.rs:300-310 and the nested serialisers)
-  const size_t psz = proof_size();
-  parallel_for(B, [&](size_t p) {
-    ProverState& s = st[p];
-    uint8_t* o = proofs_out + p * psz;
-    auto pt = [&](int slot_id) {
-      memcpy(o, &s.comp[(size_t)slot_id * 48], 48);
-      o += 48;
-    };
-    auto sc = [&](const S& x) {
-      x.to_le_bytes(o);
-      o += 32;
-    };
-    for (int q = SL_A; q <= SL_C; q++) pt(q);   // A, cm_T, cm_U, R, S, B, C
-    sc(s.r_p);
-    pt(SL_BC);
-    pt(SL_BD);
-    for (int q = SL_IPA0; q < SL_IPA0 + 4 * (int)L; q++) pt(q);
-    sc(s.c_final);
-    sc(s.d_final);
-    for (int q = sm.CMA1(); q <= sm.CMB2(); q++) pt(q);
-    sc(s.z_k);
-    sc(s.z_t);
-    sc(s.z_u);
-    for (int q = sm.BA(); q < sm.BA() + 3 + 6 * (int)L; q++) pt(q);
-    sc(s.x[0]);
-  });
-  flush_timers();
-}
-
 
 // ---------------------------------------------------------------- all-MSM prover over shifted-base tables
 // Same protocol, same outputs, different evaluation order of the group arithmetic.  The reference folds the
@@ -1904,6 +1479,10 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
   const SlotMap sm(L);
   const size_t psz = proof_size();
   const int NPP = sm.n_proof_points();
+  // msm_accumulator.rs:44 draws every factor with Fr::rand; the ABI takes them from the caller, so they are validated:
+  // a zero (or non-reduced) factor would silently drop the check it weights
+  for (size_t i = 0; i < B * rand_stride; i++)
+    if (!host::is_valid_factor(rand + 32 * i)) throw ArgError("verifier random factors must be non-zero reduced field elements");
 
   struct VState {
     Transcript tr{"curdleproofs"};
@@ -2259,20 +1838,10 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
         if (!st[p].bad) t += st[p].scal[0][i];
       crs_sum[i] = t;
     });
-    static const bool sorted_big = getenv("CPX_FUSED_BIG") || getenv("CPX_BIG_WINDOW");   // the sort-based wide-window MSM (kept for A/B and its tests)
-    const BigMsmPlan plan = sorted_big ? big_msm_plan(N) : BigMsmPlan{};
     const int fix_wpw = msm_fix_windows_per_wave(1, fix_bits_);
     const int fix_parts = 256 / fix_bits_ / fix_wpw;
     d_scal_.ensure(N + n);
     d_big_idx_.ensure(N);
-    if (sorted_big) {
-      d_conv_.ensure(N);
-      d_big_keys_.ensure(2 * plan.nkeys);
-      d_big_vals_.ensure(2 * plan.nkeys);
-      d_big_temp_.ensure(plan.sort_temp_bytes + 16);
-      d_big_bounds_.ensure(2 * (size_t)plan.nbuckets);
-      d_big_buckets_.ensure(3 * (size_t)plan.nbuckets + 64);
-    }
     d_tpart_.ensure(fix_parts);
     d_ftasks_.ensure(1);
     d_res_.ensure(1);
@@ -2302,12 +1871,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     ensure_raw_sets(fix_parts);
     launch_msm_fix(d_ftasks_.p, 1, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     reduce_sets(fix_parts, 0);
-    if (sorted_big) {
-      tick("big_msm", 128.0 * N, (double)N, true);
-      launch_big_msm(plan, d_pp_.p, d_big_idx_.p, d_scal_.p, N, d_conv_.p, d_big_keys_.p, d_big_vals_.p, d_big_temp_.p, d_big_bounds_.p, d_big_buckets_.p,
-                     d_tpart_.p, fix_parts, d_res_.p, stream_);
-      tock();
-    } else {
+    {
       // The per-proof points of up to 256 groups of proofs through the endomorphism bucket-list kernel (32 additions per
       // point like the per-proof verifier, but one bucket reduction and one Horner tail per GROUP of proofs), then two
       // plain summation levels; the last one adds the fixed-base part and hands the sum over in the standard form.

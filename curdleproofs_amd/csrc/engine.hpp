@@ -28,6 +28,10 @@ struct HipError : std::runtime_error {
   hipError_t code;
   HipError(hipError_t c, const char* what) : std::runtime_error(what), code(c) {}
 };
+// a caller-supplied value is out of range (-> CPX_ERR_ARG)
+struct ArgError : std::runtime_error {
+  explicit ArgError(const char* what) : std::runtime_error(what) {}
+};
 #define CPX_HIP(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t _e = (expr);                                                                             \
@@ -181,12 +185,12 @@ class Engine {
     double bytes, units;
   };
 
+  void set_crs_impl(size_t ell, const uint8_t* points);
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
   void run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out);
   void ensure_raw_sets(size_t nsets);
   void reduce_sets(size_t nplain, size_t nweighted, TJac* part = nullptr);
   void verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid);
-  void batch_prove_fold(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   void batch_prove_tables(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   void run_smul(const std::vector<SmulTask>& tasks, int cnt, const host::S* scalars, size_t nscalars, double alg_bytes);
   const uint32_t* idx_list(const std::vector<uint32_t>& v);
@@ -244,7 +248,6 @@ class Engine {
 
   // shifted-base tables (all-MSM prover)
   static constexpr int copies_ = 32;   // table copies per base: 2^(8c) P and z^2 2^(8c) P, c < 16: one per radix-256 window of the split scalar
-  bool use_tables_ = true;
   // CRS tables are immutable once built and large (15 GB at ell = 252): engines on the same device that are
   // given the same CRS share one copy (process-wide registry in engine.cpp).
   struct CrsTables {
@@ -263,7 +266,8 @@ class Engine {
   DevBuf<Aff> d_psrc_;       // their standard-form sources [B][NP] : M | T_b | U_b
   DevBuf<TblTmp> d_tbltmp_;
   DevBuf<TblTask> d_ttasks_;
-  int fix_bits_ = 16;        // fixed-base CRS table of multiples: radix 2^16 (13 GB at ell = 252), 2^8 (0.1 GB) or 0 = off
+  int fix_bits_cfg_ = 16;    // configured radix of the fixed-base CRS table of multiples: 2^16 (15 GB at ell = 252) or 2^8 (0.1 GB)
+  int fix_bits_ = 16;        // radix of the table in use (set_crs falls back to 2^8 when the 2^16 table does not fit in free HBM)
   DevBuf<FixTask> d_ftasks_;
   DevBuf<uint32_t> d_pfirst_, d_pcount_, d_padd_;
 
@@ -271,7 +275,6 @@ class Engine {
   size_t B_ = 0;
   size_t pp_stride_ = 0;     // 4*ell + NSLOT
   DevBuf<Aff> d_pp_;         // per proof: R|S|T|U | slots
-  DevBuf<Aff> d_wGi_, d_wGp_, d_wGm_, d_wT_, d_wU_;   // folding work vectors, [B][n+1]
   DevBuf<Jac> d_Mjac_;
 
   // phase scratch
@@ -280,9 +283,7 @@ class Engine {
   DevBuf<Fr> d_scal_;
   DevBuf<TJac> d_wsum_, d_part_;   // window sums / Horner partials of the bucket MSM (table representation)
   DevBuf<Jac> d_res_;
-  DevBuf<uint32_t> d_big_idx_, d_big_keys_, d_big_vals_, d_big_bounds_;   // large MSM of the fused verifier
-  DevBuf<uint8_t> d_big_temp_;
-  DevBuf<TJac> d_big_buckets_;
+  DevBuf<uint32_t> d_big_idx_;   // gather list of the fused verifier's per-proof points
   DevBuf<TAff> d_conv_;            // table-form copies of the bases of a bucket-MSM phase
   DevBuf<TJac> d_tpart_;           // partial sums of the table kernels
   DevBuf<uint32_t> d_dst_;

@@ -12,8 +12,8 @@
 // |a| * |b| < 2^11.3 * p^2, which the point formulas keep with a wide margin (worst case 38 p * 38 p, see g1_28).
 // Exact zero is all-limbs-zero; a product is = 0 mod p iff it equals 0 or p (it cannot reach -p).
 #pragma once
-#include "mont32.cuh"
-#include "modinv30.cuh"
+#include "mont32.hpp"
+#include "modinv30.hpp"
 
 namespace cpx {
 
@@ -218,7 +218,7 @@ CPX_HD Fp f28_to_std(const F28& a) {
   f28_canonical_words(f28_mul(a, f28_const(F28Cfg::C_OUT)), r.v);   // x * 2^384, canonical
   return r;
 }
-// Inverse of a lazy value by batched division steps (modinv30.cuh):
+// Inverse of a lazy value by batched division steps (modinv30.hpp):
 // X = a 2^392 -> X^-1 = a^-1 2^-392 as a plain integer -> one product with 2^1176 gives a^-1 2^392.
 CPX_HD F28 f28_inv_euclid(const F28& a) {
   uint32_t w[12], iw[12];

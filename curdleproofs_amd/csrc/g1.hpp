@@ -1,14 +1,14 @@
 // BLS12-381 G1 points in the standard form (32-bit-limb Montgomery Fp) — product code (host + gfx950 device).
-// The group law itself runs on the table form (g1_28.cuh); this header holds the wire types, the affine
+// The group law itself runs on the table form (g1_28.hpp); this header holds the wire types, the affine
 // normalisation step and the compressed encoding.
 //
 // Points cross the C-ABI in arkworks' in-memory limb layout (include/cpx.h):
 //   Aff : x || y                (96 B; the identity is encoded x = y = 0 — (0,0) is not on y^2 = x^3 + 4)
 //   Jac : X || Y || Z Jacobian  (144 B; Z = 0 is the identity)
 #pragma once
-#include "mont32.cuh"
+#include "mont32.hpp"
 
-// Point formulas (g1_28.cuh) are inlined into the kernels so that a kernel's __launch_bounds__ governs their
+// Point formulas (g1_28.hpp) are inlined into the kernels so that a kernel's __launch_bounds__ governs their
 // register budget (a non-kernel function is compiled for the maximum budget, which pins every caller at 2 waves
 // per SIMD).
 #define CPX_PT_FN CPX_HD

@@ -1,7 +1,7 @@
 // Scalar decomposition for the G1 endomorphism phi(x, y) = (beta x, y) — product code, host + device.
 //
 // BLS12-381: r = z^4 - z^2 + 1 with z = -0xd201000000010000, and phi acts on G1 as multiplication by -z^2
-// (fp28.cuh: BETA; the same map the subgroup test of k_decompress uses).  With N = z^2 (128 bits) every scalar
+// (fp28.hpp: BETA; the same map the subgroup test of k_decompress uses).  With N = z^2 (128 bits) every scalar
 // splits by ONE integer division:   k' = q N + t,  |t| <= N / 2,   k' P = t P + q (N P) = t P + q (-phi(P)).
 // Taking k' = min(k, r - k) (and the sign with it) keeps q <= r / (2 N) + 1 < 2^127 and |t| < 2^127, so both halves
 // have 16 signed radix-256 digits with no carry out of the top digit: a 32-copy table row is 16 doubling steps of
@@ -9,7 +9,7 @@
 // kernel still sees 32 windows of weight 1.
 #pragma once
 #include <cstdint>
-#include "mont32.cuh"
+#include "mont32.hpp"
 
 namespace cpx {
 

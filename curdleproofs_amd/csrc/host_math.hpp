@@ -2,15 +2,15 @@
 //
 // The protocol's Fr bookkeeping (challenge algebra, vector folds, inner products) and the Merlin
 // transcript serialise every round of the proof; in this round they run on the host, beside the
-// device kernels, using the same 32-bit-limb Montgomery code the kernels use (mont32.cuh).
+// device kernels, using the same 32-bit-limb Montgomery code the kernels use (mont32.hpp).
 // Mirrors /root/reference/src/transcript.rs:14-60 (CurdleproofsTranscript over merlin 3.0.0) and the
 // Fr helpers of /root/reference/src/util.rs:32-79.
 #pragma once
 #include <cstring>
 #include <string>
 #include <vector>
-#include "mont32.cuh"
-#include "strobe.cuh"
+#include "mont32.hpp"
+#include "strobe.hpp"
 
 namespace cpx {
 namespace host {
@@ -212,6 +212,17 @@ struct S {   // a scalar in Montgomery form
 };
 typedef std::vector<S> SVec;
 
+// A random factor of the accumulated check as the caller hands it over (wire form: Montgomery residue, 4 x u64 LE): it
+// must be a reduced, non-zero element — a zero factor would drop its check from the accumulated sum.
+inline bool is_valid_factor(const uint8_t wire[32]) {
+  uint64_t w[4];
+  memcpy(w, wire, 32);
+  if ((w[0] | w[1] | w[2] | w[3]) == 0) return false;
+  for (int i = 3; i >= 0; i--)
+    if (w[i] != fr64::P[i]) return w[i] < fr64::P[i];
+  return false;   // == r
+}
+
 inline S inner_product(const S* a, const S* b, size_t n) {   // util.rs:66-73
   S c = S::zero();
   for (size_t i = 0; i < n; i++) c += a[i] * b[i];
@@ -235,7 +246,7 @@ inline void batch_inverse(SVec& v) {
   }
 }
 
-// ---- Merlin transcript (STROBE-128 / Keccak core shared with the device: strobe.cuh) ----
+// ---- Merlin transcript (STROBE-128 / Keccak core shared with the device: strobe.hpp) ----
 using cpx::keccak_f1600;
 
 class Transcript {   // merlin::Transcript specialised to the operations the protocol performs

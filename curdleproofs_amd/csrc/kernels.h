@@ -1,8 +1,8 @@
 // Task descriptors and launchers of the gfx950 kernels (kernels.hip) — shared with the host engine.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "g1.cuh"
-#include "tarith.cuh"
+#include "g1.hpp"
+#include "g1_28.hpp"
 
 namespace cpx {
 
@@ -35,10 +35,10 @@ struct SmulTask {
 };
 
 // ---- table-backed MSM (no doubling tails) ----
-// Tables and partial sums are in the table kernels' representation (tarith.cuh: TAff / TJac, 28-bit limbs).
+// Tables and partial sums are in the table kernels' representation (tarith.hpp: TAff / TJac, 28-bit limbs).
 // A table holds, for every base point P_i, 32 affine copies, copy-major (entry (c, i) at base + c*copy_stride + i):
 // 2^(8c) * P_i for c = 0..15 and z^2 * 2^(8(c-16)) * P_i = -phi(2^(8(c-16)) P_i) for c = 16..31.  A scalar is split as
-// k = +-(+-|t| + q z^2) (glv.cuh); every radix-256 window of |t| and of q has its own copy, so all window sums carry
+// k = +-(+-|t| + q z^2) (glv.hpp); every radix-256 window of |t| and of q has its own copy, so all window sums carry
 // weight 1 and no doubling is left in the MSM.
 struct TblSeg {
   const TAff* base;         // copy 0
@@ -78,7 +78,7 @@ void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int n
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
 // endo = false: copy c = 2^(256 c / C) P.   endo = true (the tables k_msm_tblw reads): copies 0..C/2-1 = 2^(8c) P and
-// copies C/2.. = their endomorphism images -phi(2^(8c) P) = z^2 2^(8c) P (glv.cuh) — half the doublings.
+// copies C/2.. = their endomorphism images -phi(2^(8c) P) = z^2 2^(8c) P (glv.hpp) — half the doublings.
 void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
                         TblTmp* d_tmp, hipStream_t s);
 
@@ -121,16 +121,6 @@ void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_o
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s);
-// ---- one large MSM (fused batch verification): wide-window Pippenger over ~10^6 points of d_pp gathered through d_idx ----
-struct BigMsmPlan {
-  int c, W, key_bits;          // window bits, windows, sort key width
-  uint32_t half, nbuckets;     // buckets per window, W * half
-  size_t nkeys;                // n * W (point, window) pairs
-  size_t sort_temp_bytes;
-};
-BigMsmPlan big_msm_plan(size_t n);
-void launch_big_msm(const BigMsmPlan& p, const Aff* d_pp, const uint32_t* d_idx, const Fr* d_scalars, size_t n, TAff* d_conv, uint32_t* d_keys,
-                    uint32_t* d_vals, void* d_sort_temp, uint32_t* d_bounds, TJac* d_buckets, const TJac* d_extra, int nextra, Jac* d_out, hipStream_t s);
 // Fr algebra of the prover's log rounds on device-resident vectors (kernels.hip: "Fr algebra of the log rounds"):
 // IPA vec [nproofs][4][n] = c | d | SG | SGp, out [nproofs][4 (n/2) + 2]; SameMSM vec [nproofs][2][n] = x | SM, out [nproofs][n];
 // gam [nproofs][2] = gamma, gamma^-1

@@ -11,34 +11,33 @@
 //   G' rescale / shuffle scaling    grand_product_argument.rs:90-102, util.rs:94-95 -> k_smul (no add operand)
 //   into_affine / normalize_batch + compressed serialisation                        -> k_finalize, k_finalize_ranges, k_compress
 //   deserialize_compressed (Validate::Yes)                                          -> k_decompress
-//   MsmAccumulator shared by many proofs (BASELINE config 5)                        -> launch_big_msm
+//   MsmAccumulator shared by many proofs (BASELINE config 5)                        -> k_msm_tblw<2, true> over groups of proofs
 //
 // Integer big-number work on the VALU; no MFMA — there is no dense contraction here.  Design notes:
-//  * every group operation runs on the carry-free 28-bit-limb "table form" (fp28.cuh / g1_28.cuh / tarith.cuh);
+//  * every group operation runs on the carry-free 28-bit-limb "table form" (fp28.hpp / g1_28.hpp / tarith.hpp);
 //    points enter a kernel through t_from_std and leave through t_to_std / t_jac_to_std;
 //  * MSM work-groups are single waves (no inter-wave barriers): lanes own buckets in registers and walk per-bucket
 //    lists sorted into LDS (k_msm_tblw) or digit rows staged in LDS (k_msm_fix, k_msm_accw), points are gathered from
 //    HBM/L2 tables; the lane accumulators are added up by separate work-efficient kernels (k_reduce_sets);
-//  * scalars of the table kernels are split by the G1 endomorphism (glv.cuh): half the doublings in the table build;
+//  * scalars of the table kernels are split by the G1 endomorphism (glv.hpp): half the doublings in the table build;
 //  * the long doubling chain that combines the windows of a bucket MSM is split out into k_msm_tail, one *lane* per
 //    partial Horner evaluation, so that lanes stay busy across the many independent MSMs of a proof batch;
 //  * Jacobian results are normalised with one inversion per work-group (LDS product scans + a division-step
-//    inversion, modinv30.cuh) instead of the reference's one inversion per point.
+//    inversion, modinv30.hpp) instead of the reference's one inversion per point.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <hip/hip_ext.h>
-#include <hipcub/device/device_radix_sort.hpp>
-#include "g1.cuh"
-#include "tarith.cuh"
-#include "strobe.cuh"
-#include "recode.cuh"
-#include "glv.cuh"
+#include "g1.hpp"
+#include "g1_28.hpp"
+#include "strobe.hpp"
+#include "recode.hpp"
+#include "glv.hpp"
 #include "kernels.h"
 
 namespace cpx {
 
 // ------------------------------------------------------------------ inversion on device
-// One inversion per work-group by batched division steps (modinv30.cuh): ~0.05 ms of single-wave latency instead of
+// One inversion per work-group by batched division steps (modinv30.hpp): ~0.05 ms of single-wave latency instead of
 // the ~0.25 ms of the binary Euclidean algorithm or the ~0.55 ms of Fermat's a^(p-2) (571 dependent products);
 // callers amortise it over a whole work-group (batch inversion below).
 __device__ __noinline__ Fp fp_inv_device(const Fp& a) { return fe_inv_divsteps(a); }
@@ -79,7 +78,7 @@ __device__ __forceinline__ Fp block_batch_inverse(Fp z, Fp* buf) {
   return fe_mul(fe_mul(tinv, left), right);
 }
 
-// The same on the table form (tarith.cuh): 28-bit-limb lazy values.
+// The same on the table form (tarith.hpp): 28-bit-limb lazy values.
 __device__ __noinline__ TF t_inv_device(const TF& a) { return t_inv(a); }
 __device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
   const int tid = threadIdx.x, n = blockDim.x;
@@ -375,7 +374,7 @@ __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, u
 }
 
 // Signed radix-256 digits of windows [w0, w0 + WPW) of scalar i, biased by 128 and packed four per word.  The scalar
-// is split by the endomorphism first (glv.cuh): k = +-(+-|t| + q z^2), windows 0..15 are the digits of |t| (table copies
+// is split by the endomorphism first (glv.hpp): k = +-(+-|t| + q z^2), windows 0..15 are the digits of |t| (table copies
 // 2^(8c) P), windows 16..31 those of q (table copies -phi(2^(8c) P) = z^2 2^(8c) P); sg_lo / sg_hi are the signs the
 // two halves carry.
 template <int WPW, bool PERWIN> __device__ __forceinline__ void tbw_digits(const TblTask& task, uint32_t i, int w0, uint32_t (&dg)[(WPW + 3) / 4],
@@ -758,7 +757,7 @@ __global__ __launch_bounds__(64) void k_table_build(const Aff* __restrict__ src,
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)rows * npts;
   const bool live = g < total;
-  // endo: the row holds copies / 2 shifted copies 2^(8c) P followed by their images -phi(.) = (beta x, -y) (glv.cuh)
+  // endo: the row holds copies / 2 shifted copies 2^(8c) P followed by their images -phi(.) = (beta x, -y) (glv.hpp)
   const int real = endo ? copies / 2 : copies;
   const int sb = (endo ? 128 : 256) / real;
   const TF beta = t_beta();
@@ -897,7 +896,7 @@ __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restric
 // ark-bls12-381 `deserialize_compressed` (Validate::Yes) for tracker / proof ingestion
 // (/root/reference/src/whisk.rs:265-277, :318-320; curdleproofs.rs:312-323): y = sqrt(x^3 + 4) by
 // a^((p+1)/4), sign chosen by the flag bit, then r * P == O.
-// All field work runs on the table form (fp28.cuh); the subgroup test is the endomorphism test of g1_28.cuh.
+// All field work runs on the table form (fp28.hpp); the subgroup test is the endomorphism test of g1_28.hpp.
 __device__ __noinline__ F28 f28_sqrt_device(const F28& a) { return f28_sqrt_candidate(a); }
 __device__ __noinline__ bool g1_in_subgroup_device(const Aff28& P) { return g1_28_in_subgroup(P); }
 
@@ -945,94 +944,6 @@ __global__ __launch_bounds__(64, 2) void k_decompress(const uint8_t* __restrict_
   status[g] = st;
 }
 
-
-// ------------------------------------------------------------------ one large MSM (fused batch verification, BASELINE config 5)
-// Pippenger with wide windows for N ~ 10^6 points: signed radix-2^c digits (c = 8, 12 or 16), (window, |digit|)
-// keys sorted with the library radix sort, one lane per bucket walking its run of the sorted list, then a tree of
-// "weighted segment sums" per window and a Horner pass.  16 mixed additions per point at c = 16 instead of the 60
-// of the per-proof radix-16 kernels: this is where batching many proofs into one accumulator pays.
-__global__ __launch_bounds__(64) void k_big_gather(const Aff* __restrict__ pp, const uint32_t* __restrict__ idx, uint32_t n, TAff* __restrict__ conv) {
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i < n) conv[i] = t_from_std(pp[idx[i]]);
-}
-// thread per point: all W digits.  keys[w * n + i] = w * 2^(c-1) + |d| - 1 (or `none` for a zero digit),
-// vals[...] = i | sign << 31
-__global__ __launch_bounds__(256) void k_big_keys(const Fr* __restrict__ scalars, uint32_t n, int c, int W, uint32_t* __restrict__ keys,
-                                                  uint32_t* __restrict__ vals) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const Fr k = fe_from_mont(scalars[i]);
-  const uint32_t half = 1u << (c - 1), full = 1u << c, none = (uint32_t)W * half;
-  uint32_t carry = 0;
-  for (int w = 0; w < W; w++) {
-    const int bit = w * c, word = bit >> 5, off = bit & 31;
-    uint32_t chunk = 0;
-    if (word < 8) {
-      uint64_t two = k.v[word];
-      if (word + 1 < 8) two |= (uint64_t)k.v[word + 1] << 32;
-      chunk = (uint32_t)(two >> off) & (full - 1);
-    }
-    const uint32_t v = chunk + carry;           // <= 2^c
-    const bool neg = v >= half;                 // digit v - 2^c in [-2^(c-1), 0]
-    carry = neg ? 1u : 0u;
-    const uint32_t mag = neg ? full - v : v;    // |digit| <= 2^(c-1)
-    keys[(size_t)w * n + i] = mag ? (uint32_t)w * half + (mag - 1) : none;
-    vals[(size_t)w * n + i] = i | (neg ? 0x80000000u : 0u);
-  }
-}
-__global__ __launch_bounds__(256) void k_big_bounds(const uint32_t* __restrict__ keys, size_t total, uint32_t none, uint32_t* __restrict__ start,
-                                                    uint32_t* __restrict__ end) {
-  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= total) return;
-  const uint32_t k = keys[j];
-  if (k >= none) return;
-  if (j == 0 || keys[j - 1] != k) start[k] = (uint32_t)j;
-  if (j + 1 == total || keys[j + 1] != k) end[k] = (uint32_t)(j + 1);
-}
-__global__ __launch_bounds__(64, 2) void k_big_accum(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ start, const uint32_t* __restrict__ end,
-                                                     const TAff* __restrict__ conv, uint32_t nbuckets, TJac* __restrict__ buckets) {
-  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= nbuckets) return;
-  TAcc acc = TAcc::identity();
-  const uint32_t e = end[b];
-  for (uint32_t j = start[b]; j < e; j++) {
-    const uint32_t v = vals[j];
-    const TAff q = conv[v & 0x7fffffffu];
-    acc = t_acc_add_mixed(acc, t_cneg(q, (v >> 31) != 0));
-  }
-  buckets[b] = t_acc_to_jac(acc);
-}
-// One level of the per-window reduction  sum_b b * B_b.  A segment of m = 2^s consecutive buckets is summarised by
-// (T, S) = (sum_j (j+1) x_j, sum_j x_j); K neighbouring segments combine into one of length K m:
-//   S' = sum_i S_i,   T' = sum_i T_i + m * sum_i i S_i     (running sums from the top, then s doublings).
-// Level 0 passes the buckets themselves as both T and S (m = 1).  Thread per output segment.
-__global__ __launch_bounds__(64, 2) void k_big_combine(const TJac* __restrict__ Tin, const TJac* __restrict__ Sin, uint32_t nout, int K, int s,
-                                                       TJac* __restrict__ Tout, TJac* __restrict__ Sout) {
-  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= nout) return;
-  const TJac* Ti = Tin + (size_t)t * K;
-  const TJac* Si = Sin + (size_t)t * K;
-  TJac run = TJac::identity(), acc = TJac::identity(), tsum = Ti[0];
-  for (int i = K - 1; i >= 1; i--) {
-    run = t_add(run, Si[i]);
-    acc = t_add(acc, run);       // ends as sum_{i >= 1} i S_i
-    tsum = t_add(tsum, Ti[i]);
-  }
-  for (int d = 0; d < s; d++) acc = t_dbl(acc);
-  Tout[t] = t_add(tsum, acc);
-  Sout[t] = t_add(run, Si[0]);
-}
-// Horner over the W window sums, plus `nextra` further partial sums (the CRS part from k_msm_fix); standard form out.
-__global__ __launch_bounds__(64) void k_big_final(const TJac* __restrict__ wsum, int W, int c, const TJac* __restrict__ extra, int nextra, Jac* __restrict__ out) {
-  if (threadIdx.x || blockIdx.x) return;
-  TJac acc = wsum[W - 1];
-  for (int w = W - 2; w >= 0; w--) {
-    for (int d = 0; d < c; d++) acc = t_dbl(acc);
-    acc = t_add(acc, wsum[w]);
-  }
-  for (int i = 0; i < nextra; i++) acc = t_add(acc, extra[i]);
-  out[0] = t_jac_to_std(acc);
-}
 
 // sum of n Jacobian points (the partial sums of several engines / GPUs); flag[0] = 1 iff the sum is the identity
 __global__ __launch_bounds__(64) void k_sum_jac(const Jac* __restrict__ in, int n, Jac* __restrict__ out, int* __restrict__ flag) {
@@ -1142,7 +1053,7 @@ __global__ __launch_bounds__(128) void k_smsm_round_fold(Fr* __restrict__ vec, i
 // Lane-parallel STROBE: half a wave (32 lanes) per proof, lane l < 25 holds 64-bit lane l of the Keccak state
 // (x = l % 5, y = l / 5); a round is 9 cross-lane shuffles (theta 6, rho+pi 1, chi 2) instead of ~150 dependent
 // 64-bit operations on one lane (a single GPU lane needs ~17 us per permutation, the 32-lane form ~4 us).  Message bytes
-// are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.cuh (the host's code),
+// are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.hpp (the host's code),
 // pinned by the bit-exact proof tests.
 // bytes written to LDS by some lanes of a wave become visible to the others (no block barrier: the two proofs of a
 // work-group run divergent retry loops)
@@ -1323,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_bench_fpmul(Fp* data, int iters) {
   }
   data[g] = fe_add(x, y);
 }
-// the same chain on the 28-bit-limb field (fp28.cuh)
+// the same chain on the 28-bit-limb field (fp28.hpp)
 __global__ __launch_bounds__(256) void k_bench_f28mul(Fp* data, int iters) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   F28 x = f28_from_std(data[g]), y = f28_from_std(data[g + gridDim.x * blockDim.x]);
@@ -1415,7 +1326,13 @@ size_t raw_set_words() { return RAW_SET_WORDS; }
 void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s) {
   const int nsets = nplain + nweighted;
   if (nsets <= 0) return;
-  if (nsets <= 2048) {   // a few proofs: wave per set, both kinds in one launch
+  // CPX_REDUCE_WAVE_MAX / CPX_FINALIZE_WAVE_MAX move the switch-over between the latency (wave per item) and the
+  // throughput instantiations, so that tests reach the throughput kernels with small batches
+  static const long wave_max = [] {
+    const char* e = getenv("CPX_REDUCE_WAVE_MAX");
+    return e ? atol(e) : 2048L;
+  }();
+  if (nsets <= wave_max) {   // a few proofs: wave per set, both kinds in one launch
     CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), 65 * sizeof(TJac), s, d_raw, d_raw_slot, nplain, d_part);
     return;
   }
@@ -1464,7 +1381,11 @@ void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, T
 void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends) {
   if (n <= 0) return;
-  if (n <= 512) {   // a few proofs: wave per request (tree over the partial sums)
+  static const long wave_max = [] {
+    const char* e = getenv("CPX_FINALIZE_WAVE_MAX");
+    return e ? atol(e) : 512L;
+  }();
+  if (n <= wave_max) {   // a few proofs: wave per request (tree over the partial sums)
     const size_t lds = 2 * 256 * sizeof(TF) + 256 * sizeof(TJac);
     CPX_LAUNCH(k_finalize_ranges_wave, dim3((n + 3) / 4), dim3(256), lds, s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
     return;
@@ -1516,60 +1437,6 @@ void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp
   CPX_LAUNCH(k_transcript_step1, dim3((nproofs + 1) / 2), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
 }
 void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s) { CPX_LAUNCH(k_sum_jac, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_flag); }
-// ---- large MSM ----
-BigMsmPlan big_msm_plan(size_t n) {
-  BigMsmPlan p;
-  p.c = n >= (size_t(1) << 18) ? 16 : (n >= (size_t(1) << 13) ? 12 : 8);
-  if (const char* e = getenv("CPX_BIG_WINDOW")) {   // tests pin the window width to reach every plan with small inputs
-    const int v = atoi(e);
-    if (v == 8 || v == 12 || v == 16) p.c = v;
-  }
-  p.W = (256 + p.c - 1) / p.c;
-  p.half = 1u << (p.c - 1);
-  p.nbuckets = (uint32_t)p.W * p.half;
-  p.nkeys = n * (size_t)p.W;
-  p.sort_temp_bytes = 0;
-  uint32_t* nul = nullptr;
-  int end_bit = 1;
-  while ((1u << end_bit) <= p.nbuckets) end_bit++;
-  p.key_bits = end_bit;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, p.sort_temp_bytes, nul, nul, nul, nul, p.nkeys, 0, end_bit, nullptr);
-  return p;
-}
-// d_keys/d_vals: 2 * nkeys each (ping-pong); d_bounds: 2 * nbuckets; d_buckets: 3 * nbuckets TJac (buckets + two levels of (T, S));
-// result: d_out[0] (standard Jacobian) = sum scalars[i] * pp[idx[i]] + sum extra[j]
-void launch_big_msm(const BigMsmPlan& p, const Aff* d_pp, const uint32_t* d_idx, const Fr* d_scalars, size_t n, TAff* d_conv, uint32_t* d_keys,
-                    uint32_t* d_vals, void* d_sort_temp, uint32_t* d_bounds, TJac* d_buckets, const TJac* d_extra, int nextra, Jac* d_out, hipStream_t s) {
-  const uint32_t n32 = (uint32_t)n;
-  CPX_LAUNCH(k_big_gather, dim3((n32 + 63) / 64), dim3(64), 0, s, d_pp, d_idx, n32, d_conv);
-  CPX_LAUNCH(k_big_keys, dim3((n32 + 255) / 256), dim3(256), 0, s, d_scalars, n32, p.c, p.W, d_keys, d_vals);
-  size_t temp = p.sort_temp_bytes;
-  (void)hipcub::DeviceRadixSort::SortPairs(d_sort_temp, temp, d_keys, d_keys + p.nkeys, d_vals, d_vals + p.nkeys, p.nkeys, 0, p.key_bits, s);
-  uint32_t* start = d_bounds;
-  uint32_t* end = d_bounds + p.nbuckets;
-  (void)hipMemsetAsync(d_bounds, 0, 2 * (size_t)p.nbuckets * sizeof(uint32_t), s);
-  CPX_LAUNCH(k_big_bounds, dim3((unsigned)((p.nkeys + 255) / 256)), dim3(256), 0, s, d_keys + p.nkeys, p.nkeys, p.nbuckets, start, end);
-  CPX_LAUNCH(k_big_accum, dim3((p.nbuckets + 63) / 64), dim3(64), 0, s, d_vals + p.nkeys, start, end, d_conv, p.nbuckets, d_buckets);
-  // per-window reduction tree: segments of 32 (or what is left) per level
-  const TJac* Tin = d_buckets;
-  const TJac* Sin = d_buckets;
-  TJac* lvl = d_buckets + p.nbuckets;
-  uint32_t per_window = p.half;
-  int shift = 0;
-  while (per_window > 1) {
-    const int K = per_window >= 32 ? 32 : (int)per_window;
-    const uint32_t nout = (uint32_t)p.W * (per_window / K);
-    TJac* Tout = lvl;
-    TJac* Sout = lvl + nout;
-    CPX_LAUNCH(k_big_combine, dim3((nout + 63) / 64), dim3(64), 0, s, Tin, Sin, nout, K, shift, Tout, Sout);
-    Tin = Tout;
-    Sin = Sout;
-    lvl = Sout + nout;
-    per_window /= K;
-    while ((1 << shift) < (int)(p.half / per_window)) shift++;
-  }
-  CPX_LAUNCH(k_big_final, dim3(1), dim3(64), 0, s, Tin, p.W, p.c, d_extra, nextra, d_out);
-}
 void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s) {
   CPX_LAUNCH(k_bench_f28mul, dim3(blocks), dim3(256), 0, s, d_data, iters);
 }

@@ -8,8 +8,24 @@
 // subtract / shift iterations of the binary Euclidean algorithm: ~5x fewer instructions on one GPU lane, which is
 // what the latency of the batch-inversion kernels (k_finalize_ranges, k_table_build, ...) consists of.
 // Variable time: only public values (group elements of proofs) are inverted with it.
+//
+// The division-step / matrix-update structure follows libsecp256k1's src/modinv32_impl.h, which is distributed under
+// the MIT license:
+//   Copyright (c) 2020 Peter Dettman, Pieter Wuille
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//   rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//   persons to whom the Software is furnished to do so, subject to the following conditions:
+//   The above copyright notice and this permission notice shall be included in all copies or substantial portions of the
+//   Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+// The code below is a re-derivation for a 381-bit modulus on 13 limbs (different limb count, modulus constants and
+// final normalisation), written for this repository.
 #pragma once
-#include "mont32.cuh"
+#include "mont32.hpp"
 
 namespace cpx {
 

@@ -13,7 +13,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define CPX_HD __host__ __device__ __forceinline__
 // Real (non-inlined) functions for the big bodies: one copy of the ~1.3k-instruction Montgomery

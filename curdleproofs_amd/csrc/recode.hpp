@@ -1,6 +1,6 @@
 // Scalar recodings shared by the gfx950 kernels and the host-side emulation tests.
 #pragma once
-#include "mont32.cuh"
+#include "mont32.hpp"
 
 namespace cpx {
 

@@ -7,7 +7,7 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
-#include "mont32.cuh"
+#include "mont32.hpp"
 
 namespace cpx {
 

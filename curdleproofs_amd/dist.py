@@ -44,7 +44,8 @@ def all_gather_partials(partial_jac, n_invalid, dist=None, device="cpu"):
     Returns (partials of all ranks concatenated in rank order, total invalid count) on every rank.
     One fixed-size uint8 all_gather = ncclAllGather over xGMI on GPUs (backend nccl is RCCL), gloo on CPU; the
     payload is 148 bytes per rank, so the step is latency-bound."""
-    assert len(partial_jac) == JAC_BYTES
+    if len(partial_jac) != JAC_BYTES:
+        raise ValueError("partial sum must be one 144-byte Jacobian point")
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return bytes(partial_jac), int(n_invalid)
     import torch

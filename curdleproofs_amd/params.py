@@ -1,6 +1,6 @@
 """BLS12-381 constants and byte-encoding helpers (pure Python ints) for callers of the C-ABI:
 Montgomery wire forms of scalars / the G1 generator, used to build synthetic inputs."""
-import random
+import secrets
 
 P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
@@ -26,4 +26,9 @@ def g1_generator_wire():
 
 
 def random_fr_wire(rng, n):
+    """n uniform non-zero scalars in wire form.  rng=None draws from the OS CSPRNG (`secrets`): what a caller needs for the
+    verifier's accumulate_check factors (msm_accumulator.rs:44).  A seeded `random.Random` is accepted for reproducible
+    synthetic benchmark inputs only — never for verification factors."""
+    if rng is None:
+        return b"".join(fr_to_wire(1 + secrets.randbelow(R - 1)) for _ in range(n))
     return b"".join(fr_to_wire(rng.randrange(1, R)) for _ in range(n))

@@ -47,8 +47,11 @@ const char* cpx_last_error(const cpx_ctx* ctx); /* message of the last failing c
 int cpx_device_count(void);
 
 /* crs.rs:37-58 `CurdleproofsCrs::from_points(ell, points)`: ell + 7 affine points in the order
- * vec_G[ell] | vec_H[4] | H | G_t | G_u.  Uploads them, computes G_sum / H_sum on the device. */
-int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points);
+ * vec_G[ell] | vec_H[4] | H | G_t | G_u.  Uploads them, computes G_sum / H_sum on the device and builds the fixed-base
+ * tables (radix 2^16: 15 GB at ell = 252; falls back to radix 2^8 when free HBM is short).  `n_points` is the number of
+ * points behind `points`: fewer than ell + 7 is the reference's "not enough points" error (crs.rs:40-42) ->
+ * CPX_ERR_ARG; surplus points are ignored, as the reference's slicing does.  On failure the context holds no CRS. */
+int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points, size_t n_points);
 int cpx_crs_sums(const cpx_ctx* ctx, uint8_t g_sum[96], uint8_t h_sum[96]);
 size_t cpx_proof_size(const cpx_ctx* ctx); /* 48*(18+10*log2(ell+4)) + 32*7, e.g. 4928 at ell = 252 */
 
@@ -72,7 +75,8 @@ int cpx_g1_decompress(cpx_ctx* ctx, const uint8_t* compressed /* n*48 */, size_t
 typedef struct cpx_accum cpx_accum;
 int cpx_accum_new(cpx_ctx* ctx, cpx_accum** out);
 void cpx_accum_free(cpx_accum* acc);
-/* `accumulate_check(&mut self, C, vec_x, vec_V, rng)`; the caller passes the `Fr::rand(rng)` value it drew */
+/* `accumulate_check(&mut self, C, vec_x, vec_V, rng)`; the caller passes the `Fr::rand(rng)` value it drew: a uniform,
+ * reduced, NON-ZERO field element (zero or >= r -> CPX_ERR_ARG: a zero factor would drop the check) */
 int cpx_accum_check(cpx_accum* acc, const uint8_t C[144], const uint8_t* vec_x /* n*32 */, const uint8_t* vec_V /* n*96 */, size_t n,
                     const uint8_t random_factor[32]);
 /* `verify(self)`: CPX_OK or CPX_ERR_VERIFY */
@@ -93,8 +97,21 @@ int cpx_batch_load(cpx_ctx* ctx, size_t batch, const uint8_t* vec_R, const uint8
 int cpx_batch_prove(cpx_ctx* ctx, const uint32_t* permutation, const uint8_t* k, const uint8_t* vec_m_blinders, const uint8_t* rand,
                     uint8_t* proofs_out);
 /* curdleproofs.rs:197 `verify` (after `deserialize`, :312-323) for every loaded instance.
- *   rand     batch*8*32: the eight `accumulate_check` factors (msm_accumulator.rs:44) in call order
- *   verdict  batch ints: CPX_OK, CPX_ERR_VERIFY or CPX_ERR_DESERIALIZE */
+ *   rand     batch*8*32: the eight `accumulate_check` factors (msm_accumulator.rs:44) in call order.  They must be
+ *            independent uniform non-zero reduced field elements (what `Fr::rand` returns but for the zero it may
+ *            return with probability 1/r); zero or >= r -> CPX_ERR_ARG.
+ *   verdict  batch ints: CPX_OK, CPX_ERR_VERIFY or CPX_ERR_DESERIALIZE
+ * One deliberate difference in HOW (not in what) is checked: the reference tests the four SameScalar relations
+ * (same_scalar_argument.rs:127-137) as direct equalities; here they join the accumulated MSM with the weights
+ * a1*a2, a3*a4, a5*a6, a7*a8 built from the caller's factors.  The accumulated sum is then a polynomial of total degree 2
+ * in independent uniform factors whose coefficients are the individual check values, so a false relation survives with
+ * probability <= 2/r (Schwartz-Zippel) — the same bound every other check of `MsmAccumulator` already rests on.  The
+ * verdict therefore equals the reference's except with probability < 2^-253 over the caller's factors
+ * (tests/test_gpu_parity.py::test_same_scalar_relations_are_checked isolates these relations).
+ * Point encodings are validated strictly, as the zcash serialisation spec words it: an encoding with the infinity flag set
+ * must be exactly 0xc0 || 0^47, anything else (sort flag set, non-zero x bits) is CPX_ERR_DESERIALIZE.  ark-bls12-381 ^0.4 is
+ * not available in the build image, so its treatment of such NON-CANONICAL infinity encodings could not be checked; if it
+ * accepts them as the identity, this library is stricter on those (never produced by an honest serialiser) inputs. */
 int cpx_batch_verify(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, int* verdict);
 /* BASELINE config 5: the batched verifier.  Every `accumulate_check` of every loaded proof goes into
  * ONE accumulated MSM — the reference's `MsmAccumulator` (msm_accumulator.rs:22-68; `new` is pub(crate), :28, and
@@ -113,8 +130,10 @@ int cpx_g1_sum_jac(cpx_ctx* ctx, const uint8_t* points_jac, size_t n, uint8_t* o
 /* ---- measurement --------------------------------------------------------------------------- */
 int cpx_set_profiling(cpx_ctx* ctx, int on); /* time every kernel group with HIP events on the ctx stream */
 int cpx_reset_stats(cpx_ctx* ctx);
-/* name = kernel name as rocprofv3 reports it: "k_msm_accum", "k_msm_tail", "k_smul", "k_finalize",
- * "k_compress", "k_decompress"; units = MSM points / scalar-mul elements / points; out pointers may be NULL */
+/* name = kernel name as rocprofv3 reports it, template arguments included: "k_msm_fix<16, 16>", "k_msm_tblw<32, false>",
+ * "k_msm_tblw<2, true>", "k_msm_accw", "k_reduce_sets", "k_finalize_ranges", "k_table_build", "k_msm_tail", "k_smul",
+ * "k_finalize", "k_compress", "k_decompress" (+ the host spans "host_prove_wall", "host_verify_wall", ...);
+ * units = MSM points / scalar-mul elements / points; out pointers may be NULL */
 int cpx_get_stat(const cpx_ctx* ctx, const char* name, uint64_t* launches, double* total_ms, double* algorithmic_bytes, double* units);
 int cpx_set_host_threads(cpx_ctx* ctx, int threads);
 /* dependent Fp multiply chains: returns achieved Fp products per second */

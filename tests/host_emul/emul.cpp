@@ -1,15 +1,15 @@
-// TEST-ONLY: compiles the product's host/device-portable math (curdleproofs_amd/csrc/*.cuh,
+// TEST-ONLY: compiles the product's host/device-portable math (curdleproofs_amd/csrc/*.hpp,
 // host_math.hpp) for the CPU so that `pytest -m "not gpu"` can check the exact limb arithmetic,
 // point formulas, scalar recodings and the engine's transcript against the oracle without a GPU.
 // This is NOT a product path: nothing in curdleproofs_amd/ links or loads it.
 #include <algorithm>
 #include <cstring>
 #include <vector>
-#include "../../curdleproofs_amd/csrc/g1.cuh"
-#include "../../curdleproofs_amd/csrc/tarith.cuh"
-#include "../../curdleproofs_amd/csrc/modinv30.cuh"
-#include "../../curdleproofs_amd/csrc/glv.cuh"
-#include "../../curdleproofs_amd/csrc/recode.cuh"
+#include "../../curdleproofs_amd/csrc/g1.hpp"
+#include "../../curdleproofs_amd/csrc/g1_28.hpp"
+#include "../../curdleproofs_amd/csrc/modinv30.hpp"
+#include "../../curdleproofs_amd/csrc/glv.hpp"
+#include "../../curdleproofs_amd/csrc/recode.hpp"
 #include "../../curdleproofs_amd/csrc/host_math.hpp"
 
 using namespace cpx;
@@ -174,7 +174,7 @@ void emul_challenges(const uint8_t* msg, size_t len, uint8_t out[64]) {
 }
 void emul_keccak(uint64_t* st) { host::keccak_f1600(st); }
 
-// ---- 28-bit-limb lazy field (fp28.cuh / g1_28.cuh) ----
+// ---- 28-bit-limb lazy field (fp28.hpp / g1_28.hpp) ----
 static double f28_mag(const F28& a) {   // |value| / p, approximately
   long double v = 0, pp = 0;
   for (int i = 13; i >= 0; i--) {
@@ -302,7 +302,7 @@ int emul_inv_euclid(const uint8_t* a, uint8_t* out /*2*48: std form, table form 
   return (memcmp(e.v, f.v, 48) == 0 && memcmp(e28.v, f28v.v, 48) == 0 && memcmp(e.v, e28.v, 48) == 0) ? 1 : 0;
 }
 
-// division-step inversion (modinv30.cuh) against the binary Euclidean one, canonical integers; returns mismatches
+// division-step inversion (modinv30.hpp) against the binary Euclidean one, canonical integers; returns mismatches
 int emul_modinv30_check(const uint8_t* a, size_t n, uint8_t* first_out) {
   int bad = 0;
   for (size_t i = 0; i < n; i++) {
@@ -316,7 +316,7 @@ int emul_modinv30_check(const uint8_t* a, size_t n, uint8_t* first_out) {
   return bad;
 }
 
-// endomorphism split of canonical scalars (glv.cuh): per scalar |t| (16 B), q (16 B), neg_k, neg_t (1 B each) and the
+// endomorphism split of canonical scalars (glv.hpp): per scalar |t| (16 B), q (16 B), neg_k, neg_t (1 B each) and the
 // 32 biased digit bytes the table kernel derives from them
 void emul_glv_split(const uint8_t* k, size_t n, uint8_t* out) {
   for (size_t i = 0; i < n; i++) {

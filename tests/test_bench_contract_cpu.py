@@ -35,3 +35,25 @@ def test_bench_cli_accepts_driver_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks (--gpus was parsed and ignored).
+    Rehearsed without GPUs: CPX_BENCH_DRYRUN skips the proofs, CPX_BENCH_BACKEND=gloo replaces RCCL; rank 0 reports the world size
+    the process group saw and the max over ranks of the per-rank dummy time (1 + rank)."""
+    env = dict(os.environ, CPX_BENCH_DRYRUN="1", CPX_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # exactly one line, from rank 0
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["max_over_ranks_dt"] == 2.0 and d["steps"] == 2 and d["warmup"] == 1
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    env = dict(os.environ, CPX_BENCH_DRYRUN="1", CPX_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

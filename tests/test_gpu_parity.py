@@ -217,6 +217,61 @@ def test_accumulator_matches_reference_semantics(ctx, orc):
         acc.verify()
 
 
+def test_accumulator_shared_bases_identity_and_projective_lhs(ctx, orc):
+    """msm_accumulator.rs:38-68 beyond the reference's own n = 4 test: checks of different lengths over the SAME bases (their
+    scalars merge under one key, :47-51), the identity as a base (the G1Affine::zero() padding of curdleproofs.rs:141-155),
+    n = ell + 4 = 32, left-hand sides handed over as non-normalised Jacobian points (Z != 1) and as the point at infinity.
+    Expected verdict = every individual relation C_i == msm(V_i, x_i) holds (checked with the oracle's MSM)."""
+    import curdleproofs_amd as cpx
+    rng = orc.rng(4711)
+    n = 32
+    V = bytearray(rng.g1_affine(n))
+    V[3 * AFF:4 * AFF] = bytes(AFF)                        # identity base (also a map key)
+    V[9 * AFF:10 * AFF] = V[8 * AFF:9 * AFF]               # the same base twice inside one check
+    V = bytes(V)
+    checks = []
+    for m in (n, 10, 1, n):                                # different lengths over prefixes of the same base vector
+        x = rng.fr(m)
+        C = orc.g1_msm(V[:m * AFF], x)                     # Jacobian, Z != 1
+        checks.append((C, x, V[:m * AFF]))
+    zero_x = bytes(FR * 5)
+    checks.append((bytes(JAC), zero_x, V[:5 * AFF]))       # O == msm(V, 0): Z = 0 left-hand side
+    for C, x, Vs in checks:
+        assert _same_point(orc, C, orc.g1_msm(Vs, x))
+
+    def run(cs):
+        acc = cpx.MsmAccumulator(ctx)
+        for C, x, Vs in cs:
+            acc.accumulate_check(C, x, Vs, rng.fr(1))
+        acc.verify()
+
+    run(checks)
+    # one wrong left-hand side (C_1 + C_2 instead of C_1) anywhere rejects
+    bad = list(checks)
+    bad[1] = (orc.g1_add_jac(checks[1][0], checks[2][0]), checks[1][1], checks[1][2])
+    with pytest.raises(cpx.ProofError):
+        run(bad)
+    # a wrong scalar on the identity base is invisible (x * O = O): still accepted, as in the reference
+    x0 = bytearray(checks[0][1])
+    x0[3 * FR:4 * FR] = rng.fr(1)
+    run([(checks[0][0], bytes(x0), checks[0][2])] + checks[1:])
+    # a zero random factor is refused (it would drop the check)
+    acc = cpx.MsmAccumulator(ctx)
+    with pytest.raises(cpx.CpxError) as e:
+        acc.accumulate_check(checks[0][0], checks[0][1], checks[0][2], bytes(FR))
+    assert e.value.code == cpx.CPX_ERR_ARG
+
+
+def test_crs_not_enough_points(ctx, orc):
+    import curdleproofs_amd as cpx
+    crs = orc.generate_crs_points(28)
+    with pytest.raises(cpx.CpxError) as e:                 # crs.rs:40-42 "not enough points"
+        ctx.set_crs(28, crs[:-AFF])
+    assert e.value.code == cpx.CPX_ERR_ARG
+    ctx.set_crs(28, crs + crs[:AFF])                       # surplus points are ignored (the reference slices)
+    assert ctx.crs_sums() == orc.crs_sums(28, crs)
+
+
 def _prove_and_check(ctx, orc, ell, seeds):
     import curdleproofs_amd as cpx
     crs = orc.generate_crs_points(ell)
@@ -440,8 +495,8 @@ def test_fused_batch_verifier_config5(ctx, orc):
 
 
 @pytest.mark.parametrize("ell,nproofs", [(124, 3)])
-def test_fused_batch_verifier_wider_windows(ctx, orc, ell, nproofs):
-    # enough points (> 2^13) for the 12-bit window plan of the large MSM
+def test_fused_batch_verifier_many_points(ctx, orc, ell, nproofs):
+    # 18 proofs x 631 points in one task of the endomorphism bucket-list kernel (several list rounds per wave)
     crs, insts, proofs = _prove_and_check(ctx, orc, ell, list(range(nproofs)) * 6)
     rand = orc.rng(7).fr(12 * len(proofs))
     assert ctx.verify_batch_fused(proofs, rand)
@@ -450,25 +505,171 @@ def test_fused_batch_verifier_wider_windows(ctx, orc, ell, nproofs):
     assert not ctx.verify_batch_fused(wrong, rand)
 
 
-@pytest.mark.parametrize("window", [16])
-def test_fused_batch_verifier_window_plans(window):
-    # the 16-bit plan is chosen from 2^18 points on (bench scale); pin it on the small batches (fresh process: read once per call site)
-    import subprocess
-    import sys
-    env = dict(os.environ, CPX_BIG_WINDOW=str(window))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "test_fused_batch_verifier_config5"],
-                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+# The bench runs 2048 proofs per engine context: its launchers then pick k_msm_fix<16, 16>, k_msm_tblw<32, false>, the
+# thread-per-group reductions (k_reduce_sets / k_reduce_groups) and the thread-per-request k_finalize_ranges, none of which
+# a batch of a few proofs reaches.  THROUGHPUT_ENV moves every switch-over so that small batches run exactly those
+# instantiations (kernels.hip: msm_fix_windows_per_wave, msm_tblw_windows_per_wave, launch_reduce_sets,
+# launch_finalize_ranges).
+THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAVE_MAX": "0", "CPX_FINALIZE_WAVE_MAX": "0"}
 
 
-@pytest.mark.parametrize("env", [{"CPX_PROVER": "fold"}, {"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_TRANSCRIPT_MIN_BATCH": "1"}])
+@pytest.mark.parametrize("env", [{"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_TRANSCRIPT_MIN_BATCH": "1"}, THROUGHPUT_ENV,
+                                 dict(THROUGHPUT_ENV, CPX_DEVICE_TRANSCRIPT_MIN_BATCH="1")],
+                         ids=["fix8", "device_transcript", "throughput_kernels", "throughput_kernels_device_transcript"])
 def test_engine_variants_stay_bit_exact(env):
-    # the reference-shaped fold prover (basis folds + shrinking MSMs), the 8-bit fixed-base table and the device-side
-    # transcript prefix (k_transcript_step1, normally used from 32 proofs per batch on) are alternative engine
-    # configurations; all must reproduce the reference KAT and the oracle's verdicts
+    # the 8-bit fixed-base table, the device-side transcript (normally used from 32 proofs per batch on) and the
+    # throughput instantiations of the MSM / reduction / finalisation kernels are alternative engine configurations;
+    # all must reproduce the reference KAT (whisk.rs:416-456), the oracle's bytes at ell = 252 and the oracle's verdicts
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_prove_matches_reference_kat_ell124 or test_verify_rejects_mutated_instances or test_fused_batch_verifier_config5"],
+                        "test_prove_matches_reference_kat_ell124 or test_verify_rejects_mutated_instances or test_fused_batch_verifier_config5 "
+                        "or test_prove_verify_ell252_batch or test_same_scalar_relations_are_checked"],
                        env=dict(os.environ, **env), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _proof_offsets(ell):
+    """byte offsets inside CurdleproofsProof::serialize (curdleproofs.rs:300-310 and the sub-proofs' serialisers)"""
+    L = (ell + 4).bit_length() - 1
+    o = 9 * 48                   # A cm_T(2) cm_U(2) R S | B | C
+    off = {"r_p": o}
+    o += 32 + (2 + 4 * L) * 48   # B_c B_d L_C R_C L_D R_D
+    off["c"], off["d"] = o, o + 32
+    o += 64
+    off["cm_A_T1"], off["cm_A_T2"], off["cm_B_T1"], off["cm_B_T2"] = o, o + 48, o + 96, o + 144
+    o += 4 * 48
+    off["z_k"], off["z_t"], off["z_u"] = o, o + 32, o + 64
+    o += 96 + (3 + 6 * L) * 48
+    off["x"] = o
+    assert o + 32 == 48 * (18 + 10 * L) + 32 * 7
+    return off
+
+
+def test_same_scalar_relations_are_checked(ctx, orc):
+    """same_scalar_argument.rs:96-137.  z_k, z_t, z_u are never absorbed into the transcript, so re-encoding a proof with
+    one of them replaced by another canonical scalar breaks ONLY the SameScalar equalities (every challenge and every other
+    check stays as it was): the verdict must be VerificationError, as the oracle's.  Same for cm_A.T_1 / cm_B.T_2 replaced
+    by another valid point.  Both verifier forms (per proof, fused) and a fused batch with exactly one such proof."""
+    import curdleproofs_amd as cpx
+    ell = 28
+    seeds = [11, 12, 13, 14]
+    crs = orc.generate_crs_points(ell)
+    ctx.set_crs(ell, crs)
+    insts = [orc.make_instance(ell, s, crs) for s in seeds]
+    cat = lambda key: b"".join(i[key] for i in insts)
+    ctx.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+    proofs = [i["proof"] for i in insts]
+    vrand = cat("verifier_rand")
+    frand = orc.rng(515).fr(12 * len(seeds))
+    assert ctx.verify_batch(proofs, vrand) == [cpx.CPX_OK] * 4
+    assert ctx.verify_batch_fused(proofs, frand)
+    off = _proof_offsets(ell)
+    rng = orc.rng(616)
+    other_scalar = orc.fr_to_canonical_bytes(rng.fr(1))
+    other_point = orc.g1_compress(rng.g1_affine(1))
+
+    def oracle_verdict(i, proof):
+        x = insts[i]
+        return orc.verify(ell, crs, x["vec_R"], x["vec_S"], x["vec_T"], x["vec_U"], x["M"], proof, x["verifier_rand"])
+
+    for field, repl in [("z_k", other_scalar), ("z_t", other_scalar), ("z_u", other_scalar), ("cm_A_T1", other_point), ("cm_B_T2", other_point)]:
+        for victim in (0, 2):
+            bad = bytearray(proofs[victim])
+            bad[off[field]:off[field] + len(repl)] = repl
+            bad = bytes(bad)
+            assert oracle_verdict(victim, bad) == 0, field
+            mixed = list(proofs)
+            mixed[victim] = bad
+            want = [cpx.CPX_OK] * 4
+            want[victim] = cpx.CPX_ERR_VERIFY
+            assert ctx.verify_batch(mixed, vrand) == want, field
+            assert not ctx.verify_batch_fused(mixed, frand), field
+            part, nbad = ctx.verify_batch_fused_partial(mixed, frand)
+            assert nbad == 0 and orc.g1_compress_jac(part)[0] != 0xC0, field
+    # z_k + 1 (a "nearby" scalar, still canonical)
+    zk = int.from_bytes(proofs[1][off["z_k"]:off["z_k"] + 32], "little")
+    bad = bytearray(proofs[1])
+    bad[off["z_k"]:off["z_k"] + 32] = ((zk + 1) % 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001).to_bytes(32, "little")
+    assert oracle_verdict(1, bytes(bad)) == 0
+    assert ctx.verify_batch([proofs[0], bytes(bad), proofs[2], proofs[3]], vrand) == [cpx.CPX_OK, cpx.CPX_ERR_VERIFY, cpx.CPX_OK, cpx.CPX_OK]
+
+
+def test_verifier_rejects_degenerate_random_factors(ctx, orc):
+    """include/cpx.h: the accumulate_check factors must be uniform non-zero field elements (msm_accumulator.rs:44 draws
+    Fr::rand); a zero or non-reduced factor would silently drop a check, so it is an argument error."""
+    import curdleproofs_amd as cpx
+    ell = 28
+    crs = orc.generate_crs_points(ell)
+    ctx.set_crs(ell, crs)
+    inst = orc.make_instance(ell, 21, crs)
+    ctx.load_batch(inst["vec_R"], inst["vec_S"], inst["vec_T"], inst["vec_U"], inst["M"])
+    vr = bytearray(inst["verifier_rand"])
+    for repl in (bytes(32), b"\xff" * 32):
+        for slot in (0, 5):
+            bad = bytearray(vr)
+            bad[32 * slot:32 * slot + 32] = repl
+            with pytest.raises(cpx.CpxError) as e:
+                ctx.verify_batch([inst["proof"]], bytes(bad))
+            assert e.value.code == cpx.CPX_ERR_ARG
+    fr = bytearray(orc.rng(1).fr(12))
+    fr[32 * 9:32 * 10] = bytes(32)
+    with pytest.raises(cpx.CpxError) as e:
+        ctx.verify_batch_fused_partial([inst["proof"]], bytes(fr))
+    assert e.value.code == cpx.CPX_ERR_ARG
+    assert ctx.verify_batch([inst["proof"]], bytes(vr)) == [cpx.CPX_OK]
+
+
+def test_large_batch_four_contexts_every_proof_matches_oracle(orc):
+    """BASELINE config 4 recipe at oracle-friendly size: >= 1024 independent instances (instance i from StdRng(i)) split over
+    FOUR engine contexts driven by four host threads at once (the bench's mode of operation: shared CRS tables, concurrent
+    streams, worker pools side by side).  EVERY proof must equal the oracle's bytes and every verdict the oracle's,
+    including a few deliberately wrong proofs per context."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import curdleproofs_amd as cpx
+    ell, K = 28, 4
+    ncpu = os.cpu_count() or 8
+    N = 2048 if ncpu >= 32 else 1024     # 512 proofs per context: P1 alone has 4608 fixed-base tasks -> k_msm_fix<16, 16>
+    crs = orc.generate_crs_points(ell)
+    with ThreadPoolExecutor(min(ncpu, 64)) as ex:   # the oracle is a C library behind ctypes: the threads run in parallel
+        insts = list(ex.map(lambda s: orc.make_instance(ell, 5000 + s, crs), range(N)))
+    per = N // K
+    errors = []
+
+    def run(k):
+        try:
+            c = cpx.Context(0)
+            c.set_crs(ell, crs)
+            mine = insts[k * per:(k + 1) * per]
+            cat = lambda key: b"".join(i[key] for i in mine)
+            c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+            proofs = c.prove_batch([x for i in mine for x in i["permutation"]], cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+            wrong = [j for j, (i, p) in enumerate(zip(mine, proofs)) if p != i["proof"]]
+            if wrong:
+                errors.append("context %d: %d proofs differ from the oracle's, first at index %d" % (k, len(wrong), wrong[0]))
+            # verdicts: three wrong proofs per context (a neighbour's proof; swapped points; a flipped scalar)
+            proofs = list(proofs)
+            proofs[3] = proofs[4]
+            proofs[per // 2] = proofs[per // 2][48:96] + proofs[per // 2][:48] + proofs[per // 2][96:]
+            last = bytearray(proofs[per - 1])
+            last[-1] ^= 0x01
+            proofs[per - 1] = bytes(last)
+            got = c.verify_batch(proofs, cat("verifier_rand"))
+            want = [cpx.CPX_OK] * per
+            for j in (3, per // 2, per - 1):
+                x = mine[j]
+                o = orc.verify(ell, crs, x["vec_R"], x["vec_S"], x["vec_T"], x["vec_U"], x["M"], proofs[j], x["verifier_rand"])
+                want[j] = {1: cpx.CPX_OK, 0: cpx.CPX_ERR_VERIFY, -1: cpx.CPX_ERR_DESERIALIZE}[o]
+            if got != want:
+                errors.append("context %d: verdicts differ at %s" % (k, [j for j in range(per) if got[j] != want[j]][:8]))
+            c.close()
+        except Exception as e:   # surfaced below (an exception in a thread would otherwise be lost)
+            errors.append("context %d: %r" % (k, e))
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors

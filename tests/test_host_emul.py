@@ -1,4 +1,4 @@
-"""CPU checks of the PRODUCT's portable math (curdleproofs_amd/csrc/*.cuh + host_math.hpp), compiled
+"""CPU checks of the PRODUCT's portable math (curdleproofs_amd/csrc/*.hpp + host_math.hpp), compiled
 for the host by tests/host_emul/emul.cpp, against the oracle.  The emulation library is test-only: it
 mirrors what each kernel computes per lane so that arithmetic / recoding bugs surface without a GPU."""
 import ctypes
@@ -18,7 +18,7 @@ FR, AFF, JAC = 32, 96, 144
 
 @pytest.fixture(scope="module")
 def emul():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.cuh", "g1.cuh", "recode.cuh", "host_math.hpp", "fp28.cuh", "g1_28.cuh", "tarith.cuh", "modinv30.cuh", "strobe.cuh")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.hpp", "g1.hpp", "recode.hpp", "host_math.hpp", "fp28.hpp", "g1_28.hpp", "modinv30.hpp", "strobe.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC])
     L = ctypes.CDLL(LIB)
@@ -163,7 +163,7 @@ def test_f28_field_matches_oracle(emul, orc):
 
 
 def test_f28_point_formulas(emul, orc):
-    """Point arithmetic on the lazy field against the oracle, with the magnitude bounds of g1_28.cuh checked."""
+    """Point arithmetic on the lazy field against the oracle, with the magnitude bounds of g1_28.hpp checked."""
     n = 6
     rng = orc.rng(77)
     bases = bytearray(rng.g1_affine(n))
@@ -261,7 +261,7 @@ def test_f28_xyzz_accumulation(emul, orc):
 
 
 def test_divstep_inversion_matches_euclid(emul):
-    """modinv30.cuh (batched division steps, the inversion of the batch-inversion kernels) vs the binary Euclidean one."""
+    """modinv30.hpp (batched division steps, the inversion of the batch-inversion kernels) vs the binary Euclidean one."""
     import random
     rnd = random.Random(11)
     vals = [1, 2, 3, 4, 5, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 30, (1 << 30) - 1, (1 << 60) + 1, 1 << 380, (1 << 381) - 1,
@@ -277,7 +277,7 @@ def test_divstep_inversion_matches_euclid(emul):
 
 
 def test_glv_split(emul):
-    """glv.cuh: k = +-(+-|t| + q z^2) mod r with |t|, q < 2^127, and the signed radix-256 digits of both halves."""
+    """glv.hpp: k = +-(+-|t| + q z^2) mod r with |t|, q < 2^127, and the signed radix-256 digits of both halves."""
     import random
     rnd = random.Random(5)
     z2 = 0xd201000000010000 ** 2

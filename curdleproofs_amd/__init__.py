@@ -54,6 +54,7 @@ EXPORTS = [
     "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress",
     "cpx_accum_new", "cpx_accum_free", "cpx_accum_check", "cpx_accum_verify",
     "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify", "cpx_batch_verify_fused", "cpx_g1_sum_jac",
+    "cpx_whisk_generate_shuffle_proof", "cpx_whisk_is_valid_shuffle_proof", "cpx_whisk_generate_tracker_proof", "cpx_whisk_is_valid_tracker_proof",
     "cpx_set_profiling", "cpx_reset_stats", "cpx_get_stat", "cpx_set_host_threads", "cpx_bench_fpmul",
 ]
 
@@ -100,6 +101,10 @@ def load_library():
     L.cpx_batch_verify_fused.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ci)]
     L.cpx_g1_sum_jac.argtypes = [vp, vp, sz, vp, ctypes.POINTER(ci)]
     L.cpx_set_host_threads.argtypes = [vp, ci]
+    L.cpx_whisk_generate_shuffle_proof.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cpx_whisk_is_valid_shuffle_proof.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(ci)]
+    L.cpx_whisk_generate_tracker_proof.argtypes = [vp, vp, vp, vp, vp]
+    L.cpx_whisk_is_valid_tracker_proof.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ci)]
     L.cpx_bench_fpmul.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
     _lib = L
     return L

@@ -240,6 +240,33 @@ int cpx_g1_sum_jac(cpx_ctx* ctx, const uint8_t* points_jac, size_t n, uint8_t* o
   });
 }
 
+// ---- Whisk byte-level API (whisk.rs) ----
+int cpx_whisk_generate_shuffle_proof(cpx_ctx* ctx, const uint8_t* pre_trackers, const uint32_t* permutation, const uint8_t k[32], const uint8_t* vec_m_blinders,
+                                     const uint8_t* rand, uint8_t* post_trackers_out, uint8_t* proof_out) {
+  if (!pre_trackers || !permutation || !k || !vec_m_blinders || !rand || !post_trackers_out || !proof_out) return CPX_ERR_ARG;
+  return guarded(ctx, [&] {
+    const size_t ell = ctx->eng->ell();
+    std::vector<uint8_t> seen(ell, 0);
+    for (size_t i = 0; i < ell; i++) {   // must be a permutation of 0..ell (the reference shuffles (0..ELL))
+      if (permutation[i] >= ell || seen[permutation[i]]) return (int)CPX_ERR_ARG;
+      seen[permutation[i]] = 1;
+    }
+    return ctx->eng->whisk_generate_shuffle_proof(pre_trackers, permutation, k, vec_m_blinders, rand, post_trackers_out, proof_out);
+  });
+}
+int cpx_whisk_is_valid_shuffle_proof(cpx_ctx* ctx, const uint8_t* pre_trackers, const uint8_t* post_trackers, const uint8_t* proof, const uint8_t* rand, int* valid) {
+  if (!pre_trackers || !post_trackers || !proof || !rand || !valid) return CPX_ERR_ARG;
+  return guarded(ctx, [&] { return ctx->eng->whisk_is_valid_shuffle_proof(pre_trackers, post_trackers, proof, rand, valid); });
+}
+int cpx_whisk_generate_tracker_proof(cpx_ctx* ctx, const uint8_t tracker[96], const uint8_t k[32], const uint8_t blinder[32], uint8_t proof_out[128]) {
+  if (!tracker || !k || !blinder || !proof_out) return CPX_ERR_ARG;
+  return guarded(ctx, [&] { return ctx->eng->whisk_generate_tracker_proof(tracker, k, blinder, proof_out); });
+}
+int cpx_whisk_is_valid_tracker_proof(cpx_ctx* ctx, const uint8_t tracker[96], const uint8_t k_commitment[48], const uint8_t proof[128], int* valid) {
+  if (!tracker || !k_commitment || !proof || !valid) return CPX_ERR_ARG;
+  return guarded(ctx, [&] { return ctx->eng->whisk_is_valid_tracker_proof(tracker, k_commitment, proof, valid); });
+}
+
 int cpx_set_profiling(cpx_ctx* ctx, int on) {
   if (!ctx || !ctx->eng) return CPX_ERR_ARG;
   ctx->eng->set_profiling(on != 0);

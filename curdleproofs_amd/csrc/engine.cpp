@@ -582,6 +582,7 @@ void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
   L_ = 0;
   while ((size_t(1) << L_) < n) L_++;
   const Aff* pts = reinterpret_cast<const Aff*>(points);
+  crs_host_.assign(pts, pts + ell + 7);
   std::vector<Aff> crs(n + 1), gb(n);
   for (size_t i = 0; i < n; i++) crs[i] = pts[i];   // G | Hvec
   crs[n] = pts[n];                                  // H

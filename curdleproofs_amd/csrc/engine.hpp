@@ -132,6 +132,13 @@ class Engine {
   void batch_verify_fused(const uint8_t* proofs, const uint8_t* rand, uint8_t* partial_jac, int* n_invalid);
   size_t batch() const { return B_; }
 
+  // ---- Whisk byte-level API (whisk.rs; whisk.cpp) ----
+  int whisk_generate_shuffle_proof(const uint8_t* pre_trackers, const uint32_t* permutation, const uint8_t* k, const uint8_t* vec_m_blinders, const uint8_t* rand,
+                                   uint8_t* post_trackers_out, uint8_t* proof_out);
+  int whisk_is_valid_shuffle_proof(const uint8_t* pre_trackers, const uint8_t* post_trackers, const uint8_t* proof, const uint8_t* rand, int* valid);
+  int whisk_generate_tracker_proof(const uint8_t tracker[96], const uint8_t k[32], const uint8_t blinder[32], uint8_t proof_out[128]);
+  int whisk_is_valid_tracker_proof(const uint8_t tracker[96], const uint8_t k_commitment[48], const uint8_t proof[128], int* valid);
+
   // ---- measurement ----
   void set_profiling(bool on) { profiling_ = on; }
   void reset_stats() { stats_.clear(); }
@@ -186,6 +193,12 @@ class Engine {
   };
 
   void set_crs_impl(size_t ell, const uint8_t* points);
+  const Aff& generator();
+  void compress_affine(const Aff* pts, size_t n, uint8_t* out);
+  bool unzip_trackers(const uint8_t* trackers, size_t n, std::vector<Aff>& vec_r, std::vector<Aff>& vec_s);
+  Aff gen_;
+  bool have_gen_ = false;
+  std::vector<Aff> crs_host_;   // the ell + 7 CRS points (host copy: M of the Whisk shuffle is an MSM over vec_G | vec_H)
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
   void run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out);
   void ensure_raw_sets(size_t nsets);

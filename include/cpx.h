@@ -127,6 +127,29 @@ int cpx_batch_verify_fused(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* r
 /* sum of n Jacobian points (n*144 B) -> out (144 B); *is_identity = 1 iff the sum is the point at infinity */
 int cpx_g1_sum_jac(cpx_ctx* ctx, const uint8_t* points_jac, size_t n, uint8_t* out_jac, int* is_identity);
 
+/* ---- Whisk byte-level API: whisk.rs (the reference's `pub fn`s, source-compatible at the byte level) ------------------
+ * A tracker is 96 bytes: r_G (48, compressed) || k_r_G (48)  (`WhiskTracker`, whisk.rs:36-42).  ell is the CRS's ell
+ * (the reference hard-codes N = 128, ell = 124, whisk.rs:27-28; any power-of-two ell + 4 works here).  A bad point or
+ * scalar encoding anywhere is the reference's `Err(SerializationError)` -> CPX_ERR_DESERIALIZE.  The RNG stays with the
+ * caller: every draw the reference makes from `rng` is an argument, in the reference's order. */
+/* whisk.rs:144-179 `generate_whisk_shuffle_proof(rng, crs, pre_trackers)`.
+ *   permutation     ell u32: `(0..ELL).collect().shuffle(rng)` (:152-155)      k  `Fr::rand(rng)` (:156)
+ *   vec_m_blinders  4*32: `generate_blinders(rng, N_BLINDERS)` inside shuffle_permute_and_commit_input (util.rs:91)
+ *   rand            (3n+9)*32: the draws of `CurdleproofsProof::new` (see cpx_batch_prove)
+ *   post_trackers_out  ell*96       proof_out  48 + cpx_proof_size() = M || CurdleproofsProof::serialize (4496 B at ell = 124)
+ * Replaces the batch loaded into ctx (it loads the one instance it proves). */
+int cpx_whisk_generate_shuffle_proof(cpx_ctx* ctx, const uint8_t* pre_trackers /* ell*96 */, const uint32_t* permutation, const uint8_t k[32],
+                                     const uint8_t* vec_m_blinders, const uint8_t* rand, uint8_t* post_trackers_out, uint8_t* proof_out);
+/* whisk.rs:106-130 `is_valid_whisk_shuffle_proof(rng, crs, pre_trackers, post_trackers, proof_bytes)`;
+ *   rand 8*32: the verifier's `accumulate_check` factors (see cpx_batch_verify).  *valid = 1 / 0 = Ok(true) / Ok(false). */
+int cpx_whisk_is_valid_shuffle_proof(cpx_ctx* ctx, const uint8_t* pre_trackers, const uint8_t* post_trackers, const uint8_t* proof, const uint8_t* rand,
+                                     int* valid);
+/* whisk.rs:228-263 `generate_whisk_tracker_proof(rng, tracker, k)`; blinder = its one `Fr::rand(rng)` (:238).
+ *   proof_out 128 B = A (48) || B (48) || s (32 LE)  (`TrackerProof`, whisk.rs:69-73) */
+int cpx_whisk_generate_tracker_proof(cpx_ctx* ctx, const uint8_t tracker[96], const uint8_t k[32], const uint8_t blinder[32], uint8_t proof_out[128]);
+/* whisk.rs:183-226 `is_valid_whisk_tracker_proof(tracker, k_commitment, tracker_proof)` */
+int cpx_whisk_is_valid_tracker_proof(cpx_ctx* ctx, const uint8_t tracker[96], const uint8_t k_commitment[48], const uint8_t proof[128], int* valid);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 int cpx_set_profiling(cpx_ctx* ctx, int on); /* time every kernel group with HIP events on the ctx stream */
 int cpx_reset_stats(cpx_ctx* ctx);

@@ -367,6 +367,37 @@ int orc_verify(size_t ell, const uint8_t* crs_points, const uint8_t* vec_R, cons
   return ok ? 1 : 0;
 }
 
+// whisk.rs:228-263 / :183-226 with the caller's draws (tracker = r_G || k_r_G, 96 bytes); returns 1 / 0 / -1 (deserialisation)
+int orc_whisk_tracker_proof(const uint8_t tracker[96], const uint8_t* k, const uint8_t* blinder, uint8_t out[128]) {
+  WhiskTracker t;
+  memcpy(t.r_G, tracker, 48);
+  memcpy(t.k_r_G, tracker + 48, 48);
+  Fr b = fr_from_wire(blinder);
+  FrDraw draw = [&b]() { return b; };
+  return generate_whisk_tracker_proof(draw, t, fr_from_wire(k), out) ? 1 : -1;
+}
+int orc_whisk_tracker_verify(const uint8_t tracker[96], const uint8_t k_commitment[48], const uint8_t proof[128]) {
+  WhiskTracker t;
+  memcpy(t.r_G, tracker, 48);
+  memcpy(t.k_r_G, tracker + 48, 48);
+  return is_valid_whisk_tracker_proof(t, k_commitment, proof);
+}
+// whisk.rs:106-130 with the verifier's draws replayed from `rand`
+int orc_whisk_shuffle_verify(size_t ell, const uint8_t* crs_points, const uint8_t* pre, const uint8_t* post, const uint8_t* proof, size_t proof_len,
+                             const uint8_t* rand, size_t n_rand) {
+  Crs crs;
+  if (!crs_from_wire(ell, crs_points, &crs)) return -1;
+  std::vector<WhiskTracker> a(ell), b(ell);
+  for (size_t i = 0; i < ell; i++) {
+    memcpy(a[i].r_G, pre + 96 * i, 48);
+    memcpy(a[i].k_r_G, pre + 96 * i + 48, 48);
+    memcpy(b[i].r_G, post + 96 * i, 48);
+    memcpy(b[i].k_r_G, post + 96 * i + 48, 48);
+  }
+  Replayer rp{rand, n_rand};
+  return is_valid_whisk_shuffle_proof(std::ref(rp), crs, a, b, proof, proof_len);
+}
+
 // Timing helper for bench.py's cpu_baseline leg: `reps` x (prove + verify) on one instance,
 // single thread; returns seconds for prove and verify separately.
 int orc_time_prove_verify(size_t ell, const uint8_t* crs_points, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T,

@@ -54,6 +54,9 @@ class Oracle:
         vp = ctypes.c_void_p
         L.orc_challenges.argtypes = [vp, sz, vp]
         L.orc_kat_shuffle_proof.argtypes = [sz, vp, vp, vp, sz, ctypes.POINTER(sz)]
+        L.orc_whisk_tracker_proof.argtypes = [vp, vp, vp, vp]
+        L.orc_whisk_tracker_verify.argtypes = [vp, vp, vp]
+        L.orc_whisk_shuffle_verify.argtypes = [sz, vp, vp, vp, vp, sz, vp, sz]
         L.orc_fp_mul.argtypes = [vp, vp, vp, sz]
         L.orc_fp_inv.argtypes = [vp, vp, sz]
         L.orc_fr_mul.argtypes = [vp, vp, vp, sz]
@@ -102,6 +105,19 @@ class Oracle:
         o = _buf(128)
         v = self.lib.orc_kat_tracker_proof(o)
         return v, bytes(o)
+
+    def generate_whisk_tracker_proof(self, tracker96, k, blinder):
+        o = _buf(128)
+        if self.lib.orc_whisk_tracker_proof(_cb(tracker96), _cb(k), _cb(blinder), o) != 1:
+            raise ValueError("undecodable tracker")
+        return bytes(o)
+
+    def is_valid_whisk_tracker_proof(self, tracker96, k_commitment, proof):
+        """1 valid, 0 invalid, -1 deserialisation error"""
+        return self.lib.orc_whisk_tracker_verify(_cb(tracker96), _cb(k_commitment), _cb(proof))
+
+    def is_valid_whisk_shuffle_proof(self, ell, crs_points, pre, post, proof, rand):
+        return self.lib.orc_whisk_shuffle_verify(ell, _cb(crs_points), _cb(pre), _cb(post), _cb(proof), len(proof), _cb(rand), len(rand) // FR)
 
     def kat_shuffle_proof(self, ell=124):
         pre, post, proof = _buf(96 * ell), _buf(96 * ell), _buf(8192)

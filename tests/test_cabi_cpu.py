@@ -35,7 +35,8 @@ def test_header_and_library_agree(lib):
 def test_every_entry_point_cites_the_reference():
     hdr = open(os.path.join(ROOT, "include", "cpx.h")).read()
     for needle in ("util.rs:19-22", "util.rs:25-29", "inner_product_argument.rs:177-178", "grand_product_argument.rs:90-102",
-                   "msm_accumulator.rs:22-68", "curdleproofs.rs:59", "curdleproofs.rs:197", "crs.rs:37-58"):
+                   "msm_accumulator.rs:22-68", "curdleproofs.rs:59", "curdleproofs.rs:197", "crs.rs:37-58",
+                   "whisk.rs:144-179", "whisk.rs:106-130", "whisk.rs:228-263", "whisk.rs:183-226"):
         assert needle in hdr
 
 
@@ -55,6 +56,8 @@ def test_null_arguments_are_rejected_not_dereferenced(lib):
     assert lib.cpx_ctx_create(0, None) == cpx.CPX_ERR_ARG
     assert lib.cpx_g1_msm(None, None, None, 0, None) == cpx.CPX_ERR_ARG
     assert lib.cpx_batch_prove(None, None, None, None, None, None) == cpx.CPX_ERR_ARG
+    assert lib.cpx_whisk_generate_shuffle_proof(None, None, None, None, None, None, None, None) == cpx.CPX_ERR_ARG
+    assert lib.cpx_whisk_is_valid_tracker_proof(None, None, None, None, None) == cpx.CPX_ERR_ARG
     assert lib.cpx_proof_size(None) == 0
     lib.cpx_ctx_destroy(None)
 

@@ -1,0 +1,118 @@
+"""GPU parity of the Whisk byte-level API (curdleproofs_amd.whisk -> cpx_whisk_* C-ABI) against the reference's own
+known-answer tests (whisk.rs:381-402 tracker proof, whisk.rs:416-456 shuffle proof) end to end from 48-byte tracker inputs,
+and against the oracle's verdicts on mutated inputs.  Inputs are regenerated with the oracle's StdRng model exactly as the
+reference tests draw them."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R_ = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import curdleproofs_amd as cpx
+    return cpx.Context(0)
+
+
+def test_whisk_tracker_proof_reference_kat(ctx, orc, whisk_kat):
+    from curdleproofs_amd import whisk
+    kat = bytes.fromhex(whisk_kat["tracker_proof"])
+    rng = orc.rng(0)                                   # StdRng::seed_from_u64(0)
+    k = rng.fr(1)                                      # let k = Fr::rand(&mut rng)
+    tracker = whisk.WhiskTracker.from_k_r(ctx, k, rng.fr(1))            # WhiskTracker::from_k: r = Fr::rand
+    k_commitment = whisk.to_bytes_g1affine(ctx, whisk.bls_g1_scalar_multiply(ctx, whisk.g1_generator(ctx), k))
+    proof = whisk.generate_whisk_tracker_proof(ctx, tracker, k, blinder=rng.fr(1))
+    assert proof == kat                                # whisk.rs:401
+    assert len(proof) == whisk.TRACKER_PROOF_SIZE
+    assert whisk.is_valid_whisk_tracker_proof(ctx, tracker, k_commitment, proof)
+    # wrong commitment / wrong tracker / tampered response: Ok(false)
+    other = whisk.to_bytes_g1affine(ctx, whisk.bls_g1_scalar_multiply(ctx, whisk.g1_generator(ctx), rng.fr(1)))
+    assert not whisk.is_valid_whisk_tracker_proof(ctx, tracker, other, proof)
+    assert orc.is_valid_whisk_tracker_proof(tracker.to_bytes(), other, proof) == 0 and orc.is_valid_whisk_tracker_proof(tracker.to_bytes(), k_commitment, proof) == 1
+    assert not whisk.is_valid_whisk_tracker_proof(ctx, whisk.WhiskTracker(tracker.k_r_G, tracker.r_G), k_commitment, proof)
+    s = int.from_bytes(proof[96:], "little")
+    assert not whisk.is_valid_whisk_tracker_proof(ctx, tracker, k_commitment, proof[:96] + ((s + 1) % R_).to_bytes(32, "little"))
+    assert not whisk.is_valid_whisk_tracker_proof(ctx, tracker, k_commitment, proof[48:96] + proof[:48] + proof[96:])
+    # undecodable inputs: Err(SerializationError)
+    with pytest.raises(whisk.SerializationError):
+        whisk.is_valid_whisk_tracker_proof(ctx, tracker, k_commitment, proof[:96] + b"\xff" * 32)          # s >= r
+    with pytest.raises(whisk.SerializationError):
+        whisk.is_valid_whisk_tracker_proof(ctx, tracker, bytes(48), proof)                                # compression flag missing
+    with pytest.raises(whisk.SerializationError):
+        whisk.generate_whisk_tracker_proof(ctx, whisk.WhiskTracker(bytes([0x80]) + bytes(46) + b"\x05", tracker.k_r_G), k, rng.fr(1))
+    # the oracle agrees on a second, unrelated instance (fresh k, r, blinder)
+    k2, r2, b2 = rng.fr(1), rng.fr(1), rng.fr(1)
+    t2 = whisk.WhiskTracker.from_k_r(ctx, k2, r2)
+    assert whisk.generate_whisk_tracker_proof(ctx, t2, k2, b2) == orc.generate_whisk_tracker_proof(t2.to_bytes(), k2, b2)
+
+
+def _kat_inputs(ctx, orc):
+    """whisk.rs:416-424: generate_shuffle_trackers(rng) — per tracker k = Fr::rand, r = Fr::rand"""
+    from curdleproofs_amd import whisk
+    rng = orc.rng(0)
+    gen = orc.g1_generator()
+    trackers = []
+    for _ in range(124):
+        k, r = rng.fr(1), rng.fr(1)
+        rG = orc.g1_scale(gen, r)
+        trackers.append(whisk.WhiskTracker(orc.g1_compress(rG), orc.g1_compress(orc.g1_scale(rG, k))))
+    return rng, trackers
+
+
+def test_whisk_shuffle_proof_reference_kat(ctx, orc, whisk_kat):
+    from curdleproofs_amd import whisk
+    ell = 124
+    kat = bytes.fromhex(whisk_kat["whisk_shuffle_proof_ell124"])
+    crs = orc.generate_crs_points(ell)                 # CurdleproofsCrs::generate_crs(ELL)
+    ctx.set_crs(ell, crs)
+    rng, pre = _kat_inputs(ctx, orc)
+    # the draws of generate_whisk_shuffle_proof, in its order: shuffle, k, 4 blinders, the prover's 3n+9
+    perm = rng.shuffle(ell)
+    k = rng.fr(1)
+    mb = rng.fr(4)
+    rand = rng.fr(3 * (ell + 4) + 9)
+    post, proof = whisk.generate_whisk_shuffle_proof(ctx, pre, permutation=perm, k=k, vec_m_blinders=mb, rand=rand)
+    assert len(proof) == 4496 == whisk.whisk_shuffle_proof_size(ctx)   # WHISK_SHUFFLE_PROOF_SIZE
+    assert proof == kat                                # whisk.rs:455
+    vrand = rng.fr(8)
+    assert whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, proof, rand=vrand)
+    # post trackers = (k * r_G, k * k_r_G) permuted
+    for i in (0, 17, 123):
+        j = perm[i]
+        assert post[i].r_G == orc.g1_compress(orc.g1_scale(orc.g1_decompress(pre[j].r_G), k))
+        assert post[i].k_r_G == orc.g1_compress(orc.g1_scale(orc.g1_decompress(pre[j].k_r_G), k))
+    # Ok(false): trackers swapped, pre / post exchanged, a proof for other trackers
+    swapped = [post[1], post[0]] + post[2:]
+    assert not whisk.is_valid_whisk_shuffle_proof(ctx, pre, swapped, proof, rand=vrand)
+    cat = lambda ts: b"".join(t.to_bytes() for t in ts)
+    assert orc.is_valid_whisk_shuffle_proof(ell, crs, cat(pre), cat(post), proof, vrand) == 1
+    assert orc.is_valid_whisk_shuffle_proof(ell, crs, cat(pre), cat(swapped), proof, vrand) == 0
+    assert not whisk.is_valid_whisk_shuffle_proof(ctx, post, pre, proof, rand=vrand)
+    tampered = bytearray(proof)
+    tampered[0:48], tampered[48:96] = proof[48:96], proof[0:48]     # M <-> A
+    assert not whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, bytes(tampered), rand=vrand)
+    # Err(SerializationError): an undecodable tracker, an undecodable M, a non-canonical scalar inside the proof
+    bad_tr = [whisk.WhiskTracker(bytes([0x80]) + bytes(46) + b"\x05", post[0].k_r_G)] + post[1:]
+    with pytest.raises(whisk.SerializationError):
+        whisk.is_valid_whisk_shuffle_proof(ctx, pre, bad_tr, proof, rand=vrand)
+    with pytest.raises(whisk.SerializationError):
+        whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, bytes(48) + proof[48:], rand=vrand)
+    with pytest.raises(whisk.SerializationError):
+        whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, proof[:-32] + b"\xff" * 32, rand=vrand)
+    with pytest.raises(whisk.SerializationError):
+        whisk.generate_whisk_shuffle_proof(ctx, bad_tr, permutation=perm, k=k, vec_m_blinders=mb, rand=rand)
+    # CSPRNG-drawn witnesses: a fresh proof verifies, and differs from the KAT
+    post2, proof2 = whisk.generate_whisk_shuffle_proof(ctx, pre)
+    assert proof2 != kat and whisk.is_valid_whisk_shuffle_proof(ctx, pre, post2, proof2)
+    assert not whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, proof2)
+
+
+def test_whisk_scalar_and_point_helpers(ctx, orc, whisk_kat):
+    from curdleproofs_amd import whisk
+    kb = bytes.fromhex(whisk_kat["fr_le_bytes"])
+    assert whisk.to_bytes_fr(whisk.from_bytes_fr(kb)) == kb                        # whisk.rs:355-361
+    gb = bytes.fromhex(whisk_kat["g1_generator_compressed"])
+    assert whisk.to_bytes_g1affine(ctx, whisk.from_bytes_g1affine(ctx, gb)) == gb  # whisk.rs:363-368
+    assert whisk.from_bytes_g1affine(ctx, gb) == whisk.g1_generator(ctx) == orc.g1_generator()
+    assert whisk.to_bytes_g1affine(ctx, bytes(96)) == bytes([0xc0]) + bytes(47)

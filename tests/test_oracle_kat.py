@@ -99,3 +99,24 @@ def test_whisk_shuffle_proof_kat(orc, whisk_kat):
     assert valid == 1
     assert len(proof) == 4496
     assert proof.hex() == whisk_kat["whisk_shuffle_proof_ell124"]
+
+
+def test_oracle_whisk_entry_points_with_explicit_draws(orc, whisk_kat):
+    """The explicit-draw forms the GPU whisk tests compare against reproduce the reference KATs too (whisk.rs:381-456)."""
+    rng = orc.rng(0)
+    k, r = rng.fr(1), rng.fr(1)
+    gen = orc.g1_generator()
+    rG = orc.g1_scale(gen, r)
+    tracker = orc.g1_compress(rG) + orc.g1_compress(orc.g1_scale(rG, k))
+    proof = orc.generate_whisk_tracker_proof(tracker, k, rng.fr(1))
+    assert proof.hex() == whisk_kat["tracker_proof"]
+    kc = orc.g1_compress(orc.g1_scale(gen, k))
+    assert orc.is_valid_whisk_tracker_proof(tracker, kc, proof) == 1
+    assert orc.is_valid_whisk_tracker_proof(tracker, orc.g1_compress(gen), proof) == 0
+    assert orc.is_valid_whisk_tracker_proof(tracker, kc, proof[:96] + b"\xff" * 32) == -1
+    v, sproof, pre, post = orc.kat_shuffle_proof(124)
+    crs = orc.generate_crs_points(124)
+    vr = orc.rng(5).fr(8)
+    assert v == 1 and orc.is_valid_whisk_shuffle_proof(124, crs, pre, post, sproof, vr) == 1
+    assert orc.is_valid_whisk_shuffle_proof(124, crs, post, pre, sproof, vr) == 0
+    assert orc.is_valid_whisk_shuffle_proof(124, crs, pre, post, bytes(48) + sproof[48:], vr) == -1

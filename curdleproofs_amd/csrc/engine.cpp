@@ -16,37 +16,6 @@ using host::Transcript;
 
 static const size_t N_BLINDERS = 4;   // /root/reference/src/lib.rs:35
 
-// ---- per-proof point registry ("slots") that follows the 4*ell instance points in d_pp_ ----
-// CRS singles, M, then every proof point in serialisation order (curdleproofs.rs:300-310), then scratch.
-enum { SL_H = 0, SL_GT, SL_GU, SL_GSUM, SL_HSUM, SL_M, SL_A, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, SL_R, SL_S, SL_B, SL_C, SL_BC, SL_BD, SL_IPA0 };
-struct SlotMap {
-  int L;
-  explicit SlotMap(size_t l) : L((int)l) {}
-  int LC(int j) const { return SL_IPA0 + j; }
-  int RC(int j) const { return SL_IPA0 + L + j; }
-  int LD(int j) const { return SL_IPA0 + 2 * L + j; }
-  int RD(int j) const { return SL_IPA0 + 3 * L + j; }
-  int CMA1() const { return SL_IPA0 + 4 * L; }
-  int CMA2() const { return CMA1() + 1; }
-  int CMB1() const { return CMA1() + 2; }
-  int CMB2() const { return CMA1() + 3; }
-  int BA() const { return CMA1() + 4; }
-  int BT() const { return CMA1() + 5; }
-  int BU() const { return CMA1() + 6; }
-  int LA(int j) const { return CMA1() + 7 + j; }
-  int LT(int j) const { return CMA1() + 7 + L + j; }
-  int LU(int j) const { return CMA1() + 7 + 2 * L + j; }
-  int RA(int j) const { return CMA1() + 7 + 3 * L + j; }
-  int RT(int j) const { return CMA1() + 7 + 4 * L + j; }
-  int RU(int j) const { return CMA1() + 7 + 5 * L + j; }
-  int D() const { return CMA1() + 7 + 6 * L; }
-  int APRIME() const { return D() + 1; }
-  int TMP(int i) const { return D() + 2 + i; }   // 8 scratch results
-  int count() const { return D() + 2 + 8; }
-  int first_proof_point() const { return SL_A; }
-  int n_proof_points() const { return 18 + 10 * L; }   // SL_A .. RU(L-1), contiguous
-};
-
 static inline S S_from_wire(const uint8_t* b) {
   S s;
   memcpy(s.f.v, b, 32);
@@ -394,21 +363,6 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
   launch_smul(d_stasks_.p, (int)tasks.size(), cnt, stream_);
   tock();
   wait_stream();   // staging buffer reuse safety
-}
-
-// kernel names as rocprofv3 reports the template instantiations (statistics keys)
-static const char* fix_kernel_name(int bits, int wpw) {
-  if (bits == 16) return wpw == 16 ? "k_msm_fix<16, 16>" : wpw == 8 ? "k_msm_fix<16, 8>" : wpw == 4 ? "k_msm_fix<16, 4>" : "k_msm_fix<16, 2>";
-  return wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>";
-}
-static const char* tblw_kernel_name(int wpw) {
-  switch (wpw) {
-    case 32: return "k_msm_tblw<32, false>";
-    case 16: return "k_msm_tblw<16, false>";
-    case 8: return "k_msm_tblw<8, false>";
-    case 4: return "k_msm_tblw<4, false>";
-    default: return "k_msm_tblw<2, false>";
-  }
 }
 
 // raw lane accumulators of the MSM waves (kernels.h) and their reduction to partial sums in d_tpart_
@@ -926,7 +880,8 @@ struct ProverState {
 
 void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   if (!B_) throw std::logic_error("batch_load first");
-  batch_prove_tables(permutation, k_in, m_blinders, rand, proofs_out);
+  if (device_prefix(B_)) batch_prove_device(permutation, k_in, m_blinders, rand, proofs_out);   // the whole protocol on the GPU (engine_device.cpp)
+  else batch_prove_tables(permutation, k_in, m_blinders, rand, proofs_out);                  // a few proofs: host-driven Fiat-Shamir
 }
 
 // ---------------------------------------------------------------- all-MSM prover over shifted-base tables
@@ -1427,7 +1382,27 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     }
   }
 
-  // -- serialise (identical to the fold prover)
+  if (getenv("CPX_TRACE")) {
+    const ProverState& s = st[0];
+    trace_scalar("beta_sp", s.beta_sp.f);
+    trace_scalar("alpha_sp", s.alpha_sp.f);
+    trace_scalar("-beta_g_inv", (-s.beta_g_inv).f);
+    trace_scalar("alpha_g", s.alpha_g.f);
+    trace_scalar("gprod", s.gprod.f);
+    trace_scalar("beta_g", s.beta_g.f);
+    trace_scalar("beta_g_inv", s.beta_g_inv.f);
+    trace_scalar("r_p", s.r_p.f);
+    trace_scalar("z_ip", s.z_ip.f);
+    trace_scalar("alpha_i", s.alpha_i.f);
+    trace_scalar("beta_i", s.beta_i.f);
+    trace_scalar("alpha_m", s.alpha_m.f);
+    trace_scalar("z_k", s.z_k.f);
+    trace_scalar("z_t", s.z_t.f);
+    trace_scalar("z_u", s.z_u.f);
+    trace_scalar("c_final", s.c_final.f);
+    trace_scalar("d_final", s.d_final.f);
+  }
+  // -- serialise
   const size_t psz = proof_size();
   parallel_for(B, [&](size_t p) {
     ProverState& s = st[p];

@@ -21,6 +21,7 @@
 #include "../../include/cpx.h"   // public error codes
 #include "host_math.hpp"
 #include "kernels.h"
+#include "protocol.h"
 
 namespace cpx {
 
@@ -98,6 +99,24 @@ class WorkerPool {
   bool stop_ = false;
   std::exception_ptr err_;
 };
+
+// kernel names as rocprofv3 reports the template instantiations (statistics keys)
+inline const char* fix_kernel_name(int bits, int wpw) {
+  if (bits == 16) return wpw == 16 ? "k_msm_fix<16, 16>" : wpw == 8 ? "k_msm_fix<16, 8>" : wpw == 4 ? "k_msm_fix<16, 4>" : "k_msm_fix<16, 2>";
+  return wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>";
+}
+inline const char* tblw_kernel_name(int wpw) {
+  switch (wpw) {
+    case 32: return "k_msm_tblw<32, false>";
+    case 16: return "k_msm_tblw<16, false>";
+    case 8: return "k_msm_tblw<8, false>";
+    case 4: return "k_msm_tblw<4, false>";
+    default: return "k_msm_tblw<2, false>";
+  }
+}
+
+
+void trace_scalar(const char* name, const Fr& x);   // CPX_TRACE=1 debugging aid (engine_device.cpp)
 
 class Engine {
  public:
@@ -199,6 +218,33 @@ class Engine {
   Aff gen_;
   bool have_gen_ = false;
   std::vector<Aff> crs_host_;   // the ell + 7 CRS points (host copy: M of the Whisk shuffle is an MSM over vec_G | vec_H)
+  // ---- device-resident batch prover / verifier (engine_device.cpp) ----
+  struct TblPlan {   // task descriptors of one table-backed MSM phase whose scalars live in device memory, built once
+    size_t nt = 0, ntt = 0, nft = 0, nparts = 0, fix_sets = 0, tbl_sets = 0;
+    int fix_wpw = 16, tbl_wpw = 32;
+    double pts_fix = 0, pts_tbl = 0;
+    bool any_add = false;
+    DevBuf<TblTask> ttasks;
+    DevBuf<FixTask> ftasks;
+    DevBuf<uint32_t> meta;   // first partial | partial count | affine destination | compressed-bytes slot | addends[3], per request
+  };
+  struct DevProver {
+    std::vector<const void*> signature;   // buffer addresses + shape the plans were built for
+    ProveDev dev;
+    DevBuf<uint32_t> perm, mdst;
+    DevBuf<Fr> k, mbl, rnd, vec, sc, rvec2;
+    DevBuf<uint8_t> slotcomp, proofs;
+    TblPlan p1, p2, p3;
+    std::vector<std::unique_ptr<TblPlan>> ipa, smsm;
+    const uint32_t* side_cols = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  };
+  DevProver dprove_;
+  void build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std::vector<uint32_t>& comp_index);
+  void exec_plan(const TblPlan& pl, uint8_t* d_comp_registry);
+  void prepare_device_prover();
+  void batch_prove_device(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
+
   void run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>* comp_out);
   void run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>* comp_out);
   void ensure_raw_sets(size_t nsets);

@@ -1,0 +1,450 @@
+// Device-resident batch prover / verifier of the engine — product code (see engine.hpp, protocol.h).
+//
+// For batches of >= 32 proofs (CPX_DEVICE_TRANSCRIPT_MIN_BATCH) the whole protocol runs on the GPU: the MSM phases read their
+// scalars from device memory through task descriptors that are built ONCE per loaded batch shape ("plans"), the
+// finalisation kernels leave the compressed results in a per-proof slot registry, and one-wave-per-proof step kernels
+// (protocol.hip) hash them into the transcripts and derive the next phase's scalars.  The host only enqueues: no
+// synchronisation between cpx_batch_prove's input upload and the download of the proofs.  (Small batches keep the
+// host-driven path of engine.cpp: a lone transcript is latency-bound on a GPU wave.)
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "engine.hpp"
+
+namespace cpx {
+
+static const size_t N_BLINDERS = 4;
+
+// ---------------------------------------------------------------- plans
+// Layout of a table-backed MSM phase whose requests all read device-resident scalars (TblReq::dev): the CRS segments go to
+// k_msm_fix, the per-proof segments to k_msm_tblw; k_reduce_sets turns the raw lane accumulators into partial sums,
+// k_finalize_ranges adds them per request, normalises, scatters the affine point (TblReq::dst) and writes the compressed
+// bytes to slot `comp_index[i]` of the registry.
+void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std::vector<uint32_t>& comp_index) {
+  const size_t nt = reqs.size();
+  const bool fix = fix_bits_ && fixtab();
+  if (!fix) throw std::logic_error("set_crs first");
+  const TAff* c_lo = ctab();
+  const TAff* c_hi = ctab() + (size_t)copies_ * nc();
+  auto is_crs = [&](const TblSeg& sg) { return sg.n && sg.base >= c_lo && sg.base < c_hi; };
+  auto needs_tbl = [&](const TblReq& r) { return (r.seg0.n && !is_crs(r.seg0)) || (r.seg1.n && !is_crs(r.seg1)); };
+  size_t ntt = 0, nft = 0;
+  for (const TblReq& r : reqs) {
+    if (!r.dev && (r.seg0.n || r.seg1.n)) throw std::logic_error("device plan: request without device scalars");
+    ntt += needs_tbl(r) ? 1 : 0;
+    nft += (is_crs(r.seg0) ? 1 : 0) + (is_crs(r.seg1) ? 1 : 0);
+  }
+  pl.nt = nt;
+  pl.ntt = ntt;
+  pl.nft = nft;
+  pl.fix_wpw = msm_fix_windows_per_wave((int)nft, fix_bits_);
+  pl.tbl_wpw = msm_tblw_windows_per_wave((int)ntt);
+  const uint32_t fix_parts = (uint32_t)(256 / fix_bits_ / pl.fix_wpw), tbl_parts = (uint32_t)msm_tblw_parts(pl.tbl_wpw);
+  std::vector<TblTask> ht(ntt);
+  std::vector<FixTask> hf(nft);
+  std::vector<uint32_t> meta(7 * nt);   // pfirst | pcount | dst | comp_index | addends[3]
+  const uint32_t dummy_dst = slot_index(0, SlotMap(L_).TMP(7));
+  const TblSeg none{nullptr, nullptr, 0, 0};
+  size_t it = 0, jf = 0, nparts = 0;
+  pl.pts_fix = pl.pts_tbl = 0;
+  pl.any_add = false;
+  for (size_t i = 0; i < nt; i++) {
+    const TblReq& r = reqs[i];
+    const bool f0 = is_crs(r.seg0), f1 = is_crs(r.seg1);
+    const uint32_t first = (uint32_t)nparts;
+    if (needs_tbl(r)) {
+      TblTask t;
+      t.seg[0] = r.seg0;
+      t.seg[1] = f1 ? none : r.seg1;
+      t.scalars = r.dev;
+      if (f0) {   // seg0 goes to the fixed-base kernel: its scalars are skipped, seg1 becomes the only segment
+        t.seg[0] = f1 ? none : r.seg1;
+        t.seg[1] = none;
+        t.scalars = r.dev + r.seg0.n;
+      }
+      t.flags = 0;
+      t.pad = (uint32_t)nparts;
+      t.digits = nullptr;
+      ht[it++] = t;
+      nparts += tbl_parts;
+    }
+    if (f0) {
+      hf[jf++] = FixTask{r.seg0.idx, r.dev, (uint32_t)(r.seg0.base - c_lo), r.seg0.n, 0, (uint32_t)nparts};
+      nparts += fix_parts;
+    }
+    if (f1) {
+      hf[jf++] = FixTask{r.seg1.idx, r.dev + r.seg0.n, (uint32_t)(r.seg1.base - c_lo), r.seg1.n, 0, (uint32_t)nparts};
+      nparts += fix_parts;
+    }
+    meta[i] = first;
+    meta[nt + i] = (uint32_t)nparts - first;
+    meta[2 * nt + i] = r.dst != ~0u ? r.dst : dummy_dst;
+    meta[3 * nt + i] = comp_index[i];
+    for (int j = 0; j < 3; j++) meta[4 * nt + 3 * i + j] = r.add[j];
+    pl.any_add |= r.add[0] != ~0u;
+    pl.pts_fix += (f0 ? r.seg0.n : 0) + (f1 ? r.seg1.n : 0);
+    pl.pts_tbl += (f0 ? 0 : r.seg0.n) + (f1 ? 0 : r.seg1.n);
+  }
+  pl.nparts = nparts;
+  pl.fix_sets = nft * fix_parts;
+  pl.tbl_sets = ntt * tbl_parts;
+  pl.ttasks.ensure(std::max<size_t>(ntt, 1));
+  pl.ftasks.ensure(std::max<size_t>(nft, 1));
+  pl.meta.ensure(std::max<size_t>(meta.size(), 1));
+  if (ntt) CPX_HIP(hipMemcpy(pl.ttasks.p, ht.data(), ntt * sizeof(TblTask), hipMemcpyHostToDevice));
+  if (nft) CPX_HIP(hipMemcpy(pl.ftasks.p, hf.data(), nft * sizeof(FixTask), hipMemcpyHostToDevice));
+  if (nt) CPX_HIP(hipMemcpy(pl.meta.p, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+}
+
+void Engine::exec_plan(const TblPlan& pl, uint8_t* d_comp_registry) {
+  if (!pl.nt) return;
+  d_tpart_.ensure(std::max<size_t>(pl.nparts, 1));
+  ensure_raw_sets(pl.fix_sets + pl.tbl_sets);
+  if (pl.nft) {
+    tick(fix_kernel_name(fix_bits_, pl.fix_wpw), 128.0 * pl.pts_fix, pl.pts_fix);
+    launch_msm_fix(pl.ftasks.p, (int)pl.nft, fixtab(), fix_bits_, pl.fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
+    tock();
+  }
+  if (pl.ntt) {
+    tick(tblw_kernel_name(pl.tbl_wpw), 128.0 * pl.pts_tbl, pl.pts_tbl);
+    launch_msm_tblw(pl.ttasks.p, (int)pl.ntt, pl.tbl_wpw, d_raw_.p + pl.fix_sets * raw_set_words(), d_rawslot_.p + pl.fix_sets, stream_);
+    tock();
+  }
+  reduce_sets(pl.fix_sets, pl.tbl_sets);
+  const uint32_t* m = pl.meta.p;
+  tick("k_finalize_ranges", 0, (double)pl.nt);
+  launch_finalize_ranges(d_tpart_.p, m, m + pl.nt, (int)pl.nt, d_pp_.p, m + 2 * pl.nt, d_comp_registry, stream_, pl.any_add ? m + 4 * pl.nt : nullptr, m + 3 * pl.nt);
+  tock();
+}
+
+// ---------------------------------------------------------------- prover
+// (Re)builds everything that depends only on the shape of the loaded batch: device buffers, the ProveDev view, the task
+// descriptors of every phase and of the side stream.
+void Engine::prepare_device_prover() {
+  const size_t B = B_, ell = ell_, n = n_, L = L_;
+  const SlotMap sm(L);
+  const RandIdx ri((int)n);
+  const size_t NS = sm.count(), NP = np(), nrand = ri.count();
+  DevProver& dp = dprove_;
+  // buffers (sizes only grow; a reallocation changes a pointer and invalidates the plans)
+  d_bytes_.ensure(B * 4 * ell * 48);
+  d_mcomp_.ensure(B * 48);
+  d_tstate_.ensure(B * 27);
+  d_veca_.ensure(B * ell);
+  d_rvec_.ensure(B * 4 * n);
+  dp.rvec2.ensure(B * 2 * n);
+  d_rgam_.ensure(B * 2);
+  d_rbeta_.ensure(B);
+  d_rout_.ensure(B * (2 * n + 2));
+  dp.perm.ensure(B * ell);
+  dp.k.ensure(B);
+  dp.mbl.ensure(B * 4);
+  dp.rnd.ensure(B * nrand);
+  dp.vec.ensure(B * (size_t)V_COUNT * n);
+  dp.sc.ensure(B * (size_t)SC_COUNT);
+  dp.slotcomp.ensure(B * NS * 48);
+  dp.proofs.ensure(B * proof_size());
+  dp.mdst.ensure(B);
+  side_.tasks.ensure(2 * B);
+  side_.stasks.ensure(4 * B);
+  side_.res.ensure(2 * B);
+  side_.dst.ensure(2 * B);
+  side_.conv.ensure(4 * B * ell);
+  side_.ttasks.ensure(2 * B);
+  side_.digits.ensure(9 * 2 * B * ell);
+  side_.raw.ensure(2 * B * 32 * raw_set_words());
+  side_.rawslot.ensure(2 * B * 32);
+  side_.mid.ensure(2 * B * 32 * 16);
+  side_.part.ensure(2 * B * 32);
+  const std::vector<const void*> sig = {d_pp_.p,     d_ptab_.p,    d_psrc_.p,  d_bytes_.p,  d_mcomp_.p,   d_tstate_.p,   d_veca_.p,      d_rvec_.p,
+                                        dp.rvec2.p,  d_rgam_.p,    d_rbeta_.p, d_rout_.p,   dp.perm.p,    dp.k.p,        dp.mbl.p,       dp.rnd.p,
+                                        dp.vec.p,    dp.sc.p,      dp.slotcomp.p, dp.proofs.p, side_.tasks.p, side_.stasks.p, side_.dst.p, side_.conv.p,
+                                        ctab(),      fixtab(),     (const void*)(uintptr_t)B, (const void*)(uintptr_t)ell, (const void*)(uintptr_t)fix_bits_};
+  if (sig == dp.signature) return;
+  dp.signature.clear();
+
+  ProveDev& d = dp.dev;
+  d.ell = (int)ell;
+  d.n = (int)n;
+  d.L = (int)L;
+  d.NS = (int)NS;
+  d.psz = proof_size();
+  d.perm = dp.perm.p;
+  d.k = dp.k.p;
+  d.mbl = dp.mbl.p;
+  d.rnd = dp.rnd.p;
+  d.tstate = d_tstate_.p;
+  d.veca = d_veca_.p;
+  d.vec = dp.vec.p;
+  d.sc = dp.sc.p;
+  d.slotcomp = dp.slotcomp.p;
+  d.inst_comp = d_bytes_.p;
+  d.mcomp = d_mcomp_.p;
+  d.rvec = d_rvec_.p;
+  d.rvec2 = dp.rvec2.p;
+  d.rgam = d_rgam_.p;
+  d.rbeta = d_rbeta_.p;
+  d.proofs = dp.proofs.p;
+  memcpy(d.crs_h_comp, crs_H_comp_, 48);
+
+  auto rnd = [&](size_t p, int i) { return dp.rnd.p + p * nrand + i; };
+  auto vec = [&](size_t p, int v) { return dp.vec.p + (p * V_COUNT + v) * n; };
+  auto sc = [&](size_t p, int i) { return dp.sc.p + p * SC_COUNT + i; };
+  auto cidx = [&](size_t p, int slot) { return (uint32_t)(p * NS + slot); };
+  const size_t O_M = 0, O_T = 1, O_U = 1 + n;
+  const uint32_t* iH = idx_list({(uint32_t)n});
+  const uint32_t* iGt = idx_list({(uint32_t)(n + 1)});
+  const uint32_t* iGu = idx_list({(uint32_t)(n + 2)});
+  std::vector<uint32_t> gb(n);   // SameMSM basis G | Hvec[0..2) | G_t | G_u as CRS-table indices
+  for (size_t i = 0; i < ell + 2; i++) gb[i] = (uint32_t)i;
+  gb[ell + 2] = (uint32_t)(n + 1);
+  gb[ell + 3] = (uint32_t)(n + 2);
+  const uint32_t* iGb = idx_list(gb);
+  const TblSeg none{nullptr, nullptr, 0, 0};
+  auto req = [&](TblSeg s0, TblSeg s1, const Fr* dev, uint32_t dst = ~0u) {
+    TblReq r{s0, nullptr, s1, nullptr, dst};
+    r.dev = dev;
+    return r;
+  };
+  std::vector<TblReq> reqs;
+  std::vector<uint32_t> ci;
+
+  // mdst: where the affine M of proof p goes (table source slot 0)
+  {
+    std::vector<uint32_t> md(B);
+    for (size_t p = 0; p < B; p++) md[p] = (uint32_t)(p * NP + O_M);
+    CPX_HIP(hipMemcpy(dp.mdst.p, md.data(), B * 4, hipMemcpyHostToDevice));
+  }
+  // -- phase 1: everything that depends only on vec_a and the prover's randomness (curdleproofs.rs:93,110-116,
+  //    same_multiscalar_argument.rs:80-82, inner_product_argument.rs:126, same_scalar_argument.rs:60-61)
+  for (size_t p = 0; p < B; p++) {
+    const int TMPX = sm.TMP(6);   // compressed bytes nobody reads
+    reqs.push_back(req(cseg(0, (uint32_t)n), none, vec(p, V_APERM), slot_index(p, SL_A)));            // A
+    ci.push_back(cidx(p, SL_A));
+    reqs.push_back(req(cseg(0, (uint32_t)n, iGb), none, rnd(p, ri.VR())));                            // B_a
+    ci.push_back(cidx(p, sm.BA()));
+    reqs.push_back(req(pseg(p, O_T, (uint32_t)n), none, rnd(p, ri.VR())));                            // B_t
+    ci.push_back(cidx(p, sm.BT()));
+    reqs.push_back(req(pseg(p, O_U, (uint32_t)n), none, rnd(p, ri.VR())));                            // B_u
+    ci.push_back(cidx(p, sm.BU()));
+    reqs.push_back(req(cseg(0, (uint32_t)n), none, rnd(p, ri.IR())));                                 // B_c = msm(G | Hvec, r_c)
+    ci.push_back(cidx(p, SL_BC));
+    reqs.push_back(req(cseg(0, 1, iGt), none, rnd(p, ri.RT()), slot_index(p, SL_CMT1)));              // cm_T.T_1 = r_t G_t
+    ci.push_back(cidx(p, SL_CMT1));
+    reqs.push_back(req(cseg(0, 1, iGu), none, rnd(p, ri.RU()), slot_index(p, SL_CMU1)));              // cm_U.T_1
+    ci.push_back(cidx(p, SL_CMU1));
+    reqs.push_back(req(cseg(0, 1, iGt), none, rnd(p, ri.RA())));                                      // cm_A.T_1
+    ci.push_back(cidx(p, sm.CMA1()));
+    reqs.push_back(req(cseg(0, 1, iGu), none, rnd(p, ri.RB())));                                      // cm_B.T_1
+    ci.push_back(cidx(p, sm.CMB1()));
+    const int rs[4] = {ri.RT(), ri.RU(), ri.RA(), ri.RB()};                                           // r * H halves of the four T_2 commitments
+    for (int q = 0; q < 4; q++) {
+      reqs.push_back(req(cseg(0, 1, iH), none, rnd(p, rs[q]), slot_index(p, sm.TMP(q))));
+      ci.push_back(cidx(p, TMPX));
+    }
+  }
+  build_plan(dp.p1, reqs, ci);
+  // -- phase 2: B = A + alpha M + beta sum(G) (same_permutation_argument.rs:75-76), A' = A + cm_T.T_1 + cm_U.T_1
+  //    (curdleproofs.rs:134), C = msm(G | Hvec, c) (grand_product_argument.rs:76)
+  reqs.clear();
+  ci.clear();
+  for (size_t p = 0; p < B; p++) {
+    TblReq rb = req(cseg(n + 3, 1), pseg(p, O_M, 1), sc(p, SC_BETA_SP), slot_index(p, SL_B));
+    rb.add[0] = slot_index(p, SL_A);
+    reqs.push_back(rb);
+    ci.push_back(cidx(p, SL_B));
+    TblReq ra = req(none, none, nullptr);
+    ra.add[0] = slot_index(p, SL_A);
+    ra.add[1] = slot_index(p, SL_CMT1);
+    ra.add[2] = slot_index(p, SL_CMU1);
+    reqs.push_back(ra);
+    ci.push_back(cidx(p, sm.APRIME()));
+    reqs.push_back(req(cseg(0, (uint32_t)n), none, vec(p, V_C)));
+    ci.push_back(cidx(p, SL_C));
+  }
+  build_plan(dp.p2, reqs, ci);
+  // -- phase 3: D = B - beta^-1 sum(G) + alpha sum(H) (grand_product_argument.rs:132), B_d = msm(G', r_d) = msm(G, r_d o u)
+  reqs.clear();
+  ci.clear();
+  for (size_t p = 0; p < B; p++) {
+    TblReq rd = req(cseg(n + 3, 2), none, sc(p, SC_NEG_BETA_G_INV));
+    rd.add[0] = slot_index(p, SL_B);
+    reqs.push_back(rd);
+    ci.push_back(cidx(p, sm.D()));
+    reqs.push_back(req(cseg(0, (uint32_t)n), none, vec(p, V_ZZU)));
+    ci.push_back(cidx(p, SL_BD));
+  }
+  build_plan(dp.p3, reqs, ci);
+  // -- IPA rounds as MSMs over the original bases; scalars from k_ipa_round_scalars
+  dp.ipa.clear();
+  dp.smsm.clear();
+  const size_t hn = n / 2, per = 4 * hn + 2;
+  for (size_t j = 0; j < L; j++) {
+    const size_t half = n >> (j + 1);
+    std::vector<uint32_t> hi, lo, ghi, glo;
+    for (size_t k = 0; k < n; k++) {
+      ((k & half) ? hi : lo).push_back((uint32_t)k);
+      ((k & half) ? ghi : glo).push_back(gb[k]);
+    }
+    const uint32_t *d_hi = idx_list(hi), *d_lo = idx_list(lo), *d_ghi = idx_list(ghi), *d_glo = idx_list(glo);
+    reqs.clear();
+    ci.clear();
+    for (size_t p = 0; p < B; p++) {
+      const Fr* o = d_rout_.p + p * per;   // [L_C (hn), beta<c_L,d_R> | L_D (hn) | R_C (hn), beta<c_R,d_L> | R_D (hn)]
+      reqs.push_back(req(cseg(0, (uint32_t)hn, d_hi), cseg(0, 1, iH), o));
+      ci.push_back(cidx(p, sm.LC((int)j)));
+      reqs.push_back(req(cseg(0, (uint32_t)hn, d_lo), none, o + hn + 1));
+      ci.push_back(cidx(p, sm.LD((int)j)));
+      reqs.push_back(req(cseg(0, (uint32_t)hn, d_lo), cseg(0, 1, iH), o + 2 * hn + 1));
+      ci.push_back(cidx(p, sm.RC((int)j)));
+      reqs.push_back(req(cseg(0, (uint32_t)hn, d_hi), none, o + 3 * hn + 2));
+      ci.push_back(cidx(p, sm.RD((int)j)));
+    }
+    dp.ipa.emplace_back(new TblPlan());
+    build_plan(*dp.ipa.back(), reqs, ci);
+    reqs.clear();
+    ci.clear();
+    for (size_t p = 0; p < B; p++) {
+      const Fr* oL = d_rout_.p + p * 2 * hn;   // [L_* scalars (hn) | R_* scalars (hn)]
+      const Fr* oR = oL + hn;
+      reqs.push_back(req(cseg(0, (uint32_t)hn, d_ghi), none, oL));
+      ci.push_back(cidx(p, sm.LA((int)j)));
+      reqs.push_back(req(pseg(p, O_T, (uint32_t)hn, d_hi), none, oL));
+      ci.push_back(cidx(p, sm.LT((int)j)));
+      reqs.push_back(req(pseg(p, O_U, (uint32_t)hn, d_hi), none, oL));
+      ci.push_back(cidx(p, sm.LU((int)j)));
+      reqs.push_back(req(cseg(0, (uint32_t)hn, d_glo), none, oR));
+      ci.push_back(cidx(p, sm.RA((int)j)));
+      reqs.push_back(req(pseg(p, O_T, (uint32_t)hn, d_lo), none, oR));
+      ci.push_back(cidx(p, sm.RT((int)j)));
+      reqs.push_back(req(pseg(p, O_U, (uint32_t)hn, d_lo), none, oR));
+      ci.push_back(cidx(p, sm.RU((int)j)));
+    }
+    dp.smsm.emplace_back(new TblPlan());
+    build_plan(*dp.smsm.back(), reqs, ci);
+  }
+  // -- side stream: R = a x vec_R, S = a x vec_S (curdleproofs.rs:112-113) and the four T_2 = s * {R, S} + r * H
+  //    scalar multiplications (curdleproofs.rs:115-116, same_scalar_argument.rs:60-61)
+  {
+    std::vector<MsmTask> mt(2 * B);
+    std::vector<uint32_t> md(2 * B);
+    std::vector<SmulTask> st(4 * B);
+    for (size_t p = 0; p < B; p++) {
+      mt[2 * p] = MsmTask{pp(p), nullptr, d_veca_.p + p * ell, (uint32_t)ell, 0, (uint32_t)(2 * p * ell)};
+      mt[2 * p + 1] = MsmTask{pp(p) + ell, nullptr, d_veca_.p + p * ell, (uint32_t)ell, 0, (uint32_t)((2 * p + 1) * ell)};
+      md[2 * p] = slot_index(p, SL_R);
+      md[2 * p + 1] = slot_index(p, SL_S);
+      const Fr* kk = dp.k.p + p;
+      const Fr* rk = rnd(p, ri.RK());
+      st[4 * p + 0] = SmulTask{slot(p, sm.TMP(0)), slot(p, SL_R), slot(p, SL_CMT2), kk, 0, 0};
+      st[4 * p + 1] = SmulTask{slot(p, sm.TMP(1)), slot(p, SL_S), slot(p, SL_CMU2), kk, 0, 0};
+      st[4 * p + 2] = SmulTask{slot(p, sm.TMP(2)), slot(p, SL_R), slot(p, sm.CMA2()), rk, 0, 0};
+      st[4 * p + 3] = SmulTask{slot(p, sm.TMP(3)), slot(p, SL_S), slot(p, sm.CMB2()), rk, 0, 0};
+    }
+    CPX_HIP(hipMemcpy(side_.tasks.p, mt.data(), mt.size() * sizeof(MsmTask), hipMemcpyHostToDevice));
+    CPX_HIP(hipMemcpy(side_.dst.p, md.data(), md.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CPX_HIP(hipMemcpy(side_.stasks.p, st.data(), st.size() * sizeof(SmulTask), hipMemcpyHostToDevice));
+    dp.side_cols = idx_list({(uint32_t)SL_R, (uint32_t)SL_S, (uint32_t)SL_CMT2, (uint32_t)SL_CMU2, (uint32_t)sm.CMA2(), (uint32_t)sm.CMB2()});
+  }
+  if (!dp.ev_a) {
+    CPX_HIP(hipEventCreateWithFlags(&dp.ev_a, hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&dp.ev_b, hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&dp.ev_c, hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&dp.ev_d, hipEventDisableTiming));
+  }
+  dp.signature = sig;
+}
+
+void Engine::batch_prove_device(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
+  HostSpan wall(this, "host_prove_wall");
+  CPX_HIP(hipSetDevice(device_));
+  const size_t B = B_, ell = ell_, n = n_, L = L_;
+  const SlotMap sm(L);
+  const size_t NP = np(), NS = sm.count(), nrand = 3 * n + 9;
+  prepare_device_prover();
+  DevProver& dp = dprove_;
+  const ProveDev& d = dp.dev;
+  const int Bi = (int)B;
+
+  // witnesses and the prover's random draws: the only host -> device traffic of a prove
+  CPX_HIP(hipMemcpyAsync(dp.perm.p, permutation, B * ell * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dp.k.p, k_in, B * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dp.mbl.p, m_blinders, B * 4 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dp.rnd.p, rand, B * nrand * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+
+  // -- P0: compressed instance vectors, M -> affine (table source slot 0); side stream: transcript prefix (instance + M
+  //    absorbed, vec_a drawn), then R and S; main stream: the per-proof tables
+  tick("k_compress", 0, (double)(4 * ell * B));
+  launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, Bi, d_bytes_.p, stream_);
+  tock();
+  launch_finalize(d_Mjac_.p, Bi, d_psrc_.p, dp.mdst.p, d_mcomp_.p, stream_);
+  CPX_HIP(hipEventRecord(dp.ev_a, stream_));
+  CPX_HIP(hipStreamWaitEvent(side_.stream, dp.ev_a, 0));
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side_.stream);
+  CPX_HIP(hipEventRecord(dp.ev_b, side_.stream));
+  {
+    const int nt = 2 * Bi;
+    launch_msm_endo(side_.tasks.p, nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
+    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, nt * 32, side_.mid.p, side_.part.p, side_.stream);
+    launch_msm_tail(side_.part.p, nullptr, side_.res.p, nt, 16, 8, side_.stream, nullptr, 0, 2);
+    launch_finalize(side_.res.p, nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
+  }
+  tick("k_table_build", 0, (double)(B * NP));
+  launch_table_build(d_psrc_.p, NP, d_ptab_.p, Bi, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
+  tock();
+  CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_b, 0));   // vec_a and the transcript states
+
+  // -- P1
+  launch_ps_aperm(d, Bi, stream_);
+  exec_plan(dp.p1, dp.slotcomp.p);
+  CPX_HIP(hipEventRecord(dp.ev_c, stream_));           // the r * H points of the T_2 commitments are in TMP0..3
+  CPX_HIP(hipStreamWaitEvent(side_.stream, dp.ev_c, 0));
+  launch_smul(side_.stasks.p, 4 * Bi, 1, side_.stream);
+  launch_compress_cols(d_pp_.p + 4 * ell, dp.side_cols, 6, (int)pp_stride_, Bi, dp.slotcomp.p, (int)NS, side_.stream);
+  CPX_HIP(hipEventRecord(dp.ev_d, side_.stream));
+  launch_ps_sameperm(d, Bi, stream_);
+  // -- P2, P3
+  exec_plan(dp.p2, dp.slotcomp.p);
+  launch_ps_gprod(d, Bi, stream_);
+  exec_plan(dp.p3, dp.slotcomp.p);
+  launch_ps_ipa_setup(d, Bi, stream_);
+  // -- IPA rounds (inner_product_argument.rs:150-186 in all-MSM form)
+  for (size_t j = 0; j < L; j++) {
+    const int half = (int)(n >> (j + 1));
+    launch_ipa_round_scalars(d_rvec_.p, Bi, (int)n, half, d_rbeta_.p, d_rout_.p, stream_);
+    exec_plan(*dp.ipa[j], dp.slotcomp.p);
+    launch_ps_ipa_round(d, Bi, (int)j, stream_);
+    launch_ipa_round_fold(d_rvec_.p, Bi, (int)n, half, d_rgam_.p, stream_);
+  }
+  // -- SameScalar, SameMSM step 1 (needs R, S and the T_2 commitments of the side stream)
+  CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_d, 0));
+  launch_ps_smsm_setup(d, Bi, stream_);
+  for (size_t j = 0; j < L; j++) {
+    const int half = (int)(n >> (j + 1));
+    launch_smsm_round_scalars(dp.rvec2.p, Bi, (int)n, half, d_rout_.p, stream_);
+    exec_plan(*dp.smsm[j], dp.slotcomp.p);
+    launch_ps_smsm_round(d, Bi, (int)j, stream_);
+    launch_smsm_round_fold(dp.rvec2.p, Bi, (int)n, half, d_rgam_.p, stream_);
+  }
+  launch_ps_serialize(d, Bi, stream_);
+  CPX_HIP(hipMemcpyAsync(proofs_out, dp.proofs.p, B * proof_size(), hipMemcpyDeviceToHost, stream_));
+  wait_stream();
+  flush_timers();
+  if (getenv("CPX_TRACE")) {   // debugging aid: the challenges and responses of proof 0, same format as the host-driven prover prints
+    std::vector<Fr> sc(SC_COUNT);
+    CPX_HIP(hipMemcpy(sc.data(), dp.sc.p, SC_COUNT * sizeof(Fr), hipMemcpyDeviceToHost));
+    const char* names[SC_COUNT] = {"beta_sp", "alpha_sp", "-beta_g_inv", "alpha_g", "gprod", "beta_g", "beta_g_inv", "r_p", "z_ip", "alpha_i", "beta_i",
+                                   "alpha_s", "alpha_m", "z_k", "z_t", "z_u", "c_final", "d_final", "x_final"};
+    for (int i = 0; i < SC_COUNT; i++)
+      if (names[i]) trace_scalar(names[i], sc[i]);
+  }
+}
+
+void trace_scalar(const char* name, const Fr& x) {
+  fprintf(stderr, "[cpx trace] %-12s ", name);
+  for (int i = 7; i >= 0; i--) fprintf(stderr, "%08x", x.v[i]);
+  fprintf(stderr, "\n");
+}
+
+}  // namespace cpx

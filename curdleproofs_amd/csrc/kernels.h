@@ -101,8 +101,9 @@ void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, i
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
 // output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)
 // d_addends (optional): [n][3] indices into d_aff of affine points (results of earlier phases) to add to output o; ~0u = none
+// d_comp_index (optional): output o's compressed bytes go to d_comp + 48 * d_comp_index[o] instead of d_comp + 48 * o
 void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
-                            uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends = nullptr);
+                            uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends = nullptr, const uint32_t* d_comp_index = nullptr);
 
 // ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian, table representation) ...
 // d_conv: scratch for the table-form copies of all bases (sum of n over the tasks, addressed by task.conv_off);
@@ -117,7 +118,9 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
 // Jacobian -> affine (+ optional scatter through dst_index) and optional 48-byte compressed form.
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
 // `batch` rows of n points, row r starting at d_in + r*stride; output dense [batch][n][48]
-void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s);
+void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s, int out_stride = 0);   // out_stride (points per output row), 0 = dense
+// `batch` strided rows; only the columns d_cols[0..ncols) are compressed, each to the same column of the output row
+void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, int stride, int batch, uint8_t* d_out, int out_stride, hipStream_t s);
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s);

@@ -30,6 +30,7 @@
 #include "g1.hpp"
 #include "g1_28.hpp"
 #include "strobe.hpp"
+#include "wave_strobe.hpp"
 #include "recode.hpp"
 #include "glv.hpp"
 #include "kernels.h"
@@ -651,7 +652,7 @@ template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* 
 // convert to the standard form, scatter the affine point and emit the 48-byte compressed encoding.
 __global__ __launch_bounds__(64) void k_finalize_ranges(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
                                                          int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
-                                                         const uint32_t* __restrict__ addends) {
+                                                         const uint32_t* __restrict__ addends, const uint32_t* __restrict__ comp_index) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(64) void k_finalize_ranges(const TJac* __restrict__
   if (g >= n) return;
   const Aff a = inf ? Aff::identity() : t_to_std(t_to_affine(p, zinv));
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
-  if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
+  if (out_comp) aff_compress(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
 }
 
 // Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per request.  The lanes add the
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(64) void k_finalize_ranges(const TJac* __restrict__
 // the inversion is shared by the 4 requests of a work-group.
 __global__ __launch_bounds__(256) void k_finalize_ranges_wave(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
                                                               int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
-                                                              const uint32_t* __restrict__ addends) {
+                                                              const uint32_t* __restrict__ addends, const uint32_t* __restrict__ comp_index) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);                                     // 2 * 256 field elements (batch inversion)
   TJac* red = reinterpret_cast<TJac*>(smem + 2 * 256 * sizeof(TF));          // [256]
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256) void k_finalize_ranges_wave(const TJac* __rest
   if (!owner) return;
   const Aff a = inf ? Aff::identity() : t_to_std(t_to_affine(p, zinv));
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
-  if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
+  if (out_comp) aff_compress(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
 }
 
 // ------------------------------------------------------------------ table construction
@@ -837,11 +838,18 @@ __global__ __launch_bounds__(64) void k_finalize(const Jac* __restrict__ in, int
 }
 
 // affine -> compressed bytes only; `batch` strided input rows of n points each, dense output
-__global__ __launch_bounds__(256) void k_compress(const Aff* __restrict__ in, int n, int stride, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_compress(const Aff* __restrict__ in, int n, int stride, uint8_t* __restrict__ out, int out_stride) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const size_t row = blockIdx.y;
-  aff_compress(in[row * stride + g], out + (row * n + g) * 48);
+  aff_compress(in[row * stride + g], out + (row * out_stride + g) * 48);
+}
+
+// selected columns of strided rows: out[(row * out_stride + cols[t]) * 48] = compress(in[row * stride + cols[t]]), t < ncols
+__global__ __launch_bounds__(64) void k_compress_cols(const Aff* __restrict__ in, const uint32_t* __restrict__ cols, int ncols, int stride, uint8_t* __restrict__ out,
+                                                      int out_stride) {
+  const size_t row = blockIdx.x;
+  for (int t = threadIdx.x; t < ncols; t += 64) aff_compress(in[row * stride + cols[t]], out + (row * out_stride + cols[t]) * 48);
 }
 
 // ------------------------------------------------------------------ per-element scalar-mul (+ add)
@@ -1055,110 +1063,6 @@ __global__ __launch_bounds__(128) void k_smsm_round_fold(Fr* __restrict__ vec, i
 // 64-bit operations on one lane (a single GPU lane needs ~17 us per permutation, the 32-lane form ~4 us).  Message bytes
 // are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.hpp (the host's code),
 // pinned by the bit-exact proof tests.
-// bytes written to LDS by some lanes of a wave become visible to the others (no block barrier: the two proofs of a
-// work-group run divergent retry loops)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-struct WaveStrobe {
-  uint64_t a;                 // this lane's 64-bit lane of the state (lanes >= 25 keep 0)
-  uint32_t pos, pos_begin;    // uniform over the 32 lanes of a proof
-  int l;                      // lane within the 32-lane group
-
-  __device__ __forceinline__ uint64_t shfl(uint64_t v, int src) const {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 32), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 32);
-    return ((uint64_t)hi << 32) | lo;
-  }
-  __device__ void keccak() {
-    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
-                             0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
-                             0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
-                             0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-                             0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-    // rotation offsets r[x + 5y] of rho
-    const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    const int lc = l < 25 ? l : 0;   // idle lanes mirror lane 0 (their value is never used)
-    const int x = lc % 5, y = lc / 5;
-    // rho + pi as a gather: destination (X, Y) = (y, (2x + 3y) % 5)  <=>  source x = (X + 3Y) % 5, y = X
-    const int sx = (x + 3 * y) % 5, sy = x, src = sx + 5 * sy, rot = RHO[src];
-    const int xm1 = (x + 4) % 5 + 5 * y, xp1 = (x + 1) % 5 + 5 * y, xp2 = (x + 2) % 5 + 5 * y;
-    for (int r = 0; r < 24; r++) {
-      uint64_t c = a;
-      CPX_UNROLL for (int k = 1; k < 5; k++) c ^= shfl(a, (lc + 5 * k) % 25);     // column parity (same for every y)
-      const uint64_t d = shfl(c, xm1) ^ rol64(shfl(c, xp1), 1);
-      a ^= d;
-      uint64_t b = shfl(a, src);
-      b = rot ? ((b << rot) | (b >> (64 - rot))) : b;
-      a = b ^ (~shfl(b, xp1) & shfl(b, xp2));
-      if (l == 0) a ^= RC[r];
-    }
-    if (l >= 25) a = 0;
-  }
-  __device__ __forceinline__ void xor_byte(uint32_t i, uint8_t b) {
-    if ((int)(i >> 3) == l) a ^= (uint64_t)b << (8 * (i & 7));
-  }
-  __device__ void run_f() {
-    xor_byte(pos, (uint8_t)pos_begin);
-    xor_byte(pos + 1, 0x04);
-    xor_byte(Strobe::RATE + 1, 0x80);
-    keccak();
-    pos = pos_begin = 0;
-  }
-  // absorb n bytes readable by every lane (global, constant or LDS memory)
-  __device__ void absorb(const uint8_t* d, size_t n) {
-    while (n) {
-      const uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), n);
-      uint64_t v = 0;
-      CPX_UNROLL for (int j = 0; j < 8; j++) {
-        const uint32_t sidx = 8u * (uint32_t)l + j;   // state byte owned by this lane
-        if (sidx >= pos && sidx < pos + k) v |= (uint64_t)d[sidx - pos] << (8 * j);
-      }
-      a ^= v;
-      pos += k;
-      d += k;
-      n -= k;
-      if (pos == Strobe::RATE) run_f();
-    }
-  }
-  __device__ void begin_op(uint32_t flags, bool more) {
-    if (more) return;
-    const uint8_t h0 = (uint8_t)pos_begin, h1 = (uint8_t)flags;
-    pos_begin = pos + 1;
-    xor_byte(pos, h0);                 // the two header bytes, one at a time (the rate boundary may fall between them)
-    if (++pos == Strobe::RATE) run_f();
-    xor_byte(pos, h1);
-    if (++pos == Strobe::RATE) run_f();
-    if ((flags & (Strobe::FLAG_C | Strobe::FLAG_K)) && pos != 0) run_f();
-  }
-  __device__ void meta_ad(const void* d, size_t n, bool more) {
-    begin_op(Strobe::FLAG_M | Strobe::FLAG_A, more);
-    absorb(static_cast<const uint8_t*>(d), n);
-  }
-  __device__ void len4(size_t len, uint8_t* scratch4) {   // LE32(len) through the group's scratch bytes
-    if (l < 4) scratch4[l] = (uint8_t)(len >> (8 * l));
-    wave_lds_sync();
-    meta_ad(scratch4, 4, true);
-  }
-  __device__ void append_begin(const char* label, size_t label_len, size_t len, uint8_t* scratch) {
-    meta_ad(label, label_len, false);
-    len4(len, scratch);
-    begin_op(Strobe::FLAG_A, false);
-  }
-  __device__ void init(const char* label, size_t label_len, uint8_t* scratch) {
-    const uint8_t ini[18] = {1, 168, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
-    a = 0;
-    CPX_UNROLL for (int i = 0; i < 18; i++) xor_byte(i, ini[i]);
-    keccak();
-    pos = pos_begin = 0;
-    meta_ad("Merlin v1.0", 11, false);
-    append_begin("dom-sep", 7, label_len, scratch);
-    absorb(reinterpret_cast<const uint8_t*>(label), label_len);
-  }
-};
-
 // out_state: [nproofs][27] u64, out_vec_a: [nproofs][ell] Fr (Montgomery wire form)
 __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restrict__ inst_comp, const uint8_t* __restrict__ m_comp, int nproofs, int ell,
                                                          uint64_t* __restrict__ out_state, Fr* __restrict__ out_vec_a) {
@@ -1379,7 +1283,7 @@ void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, T
   else CPX_LAUNCH(k_fix_build<8>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
 }
 void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
-                            uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends) {
+                            uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends, const uint32_t* d_comp_index) {
   if (n <= 0) return;
   static const long wave_max = [] {
     const char* e = getenv("CPX_FINALIZE_WAVE_MAX");
@@ -1387,10 +1291,10 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
   }();
   if (n <= wave_max) {   // a few proofs: wave per request (tree over the partial sums)
     const size_t lds = 2 * 256 * sizeof(TF) + 256 * sizeof(TJac);
-    CPX_LAUNCH(k_finalize_ranges_wave, dim3((n + 3) / 4), dim3(256), lds, s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
+    CPX_LAUNCH(k_finalize_ranges_wave, dim3((n + 3) / 4), dim3(256), lds, s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
     return;
   }
-  CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends);
+  CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
 }
 void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
                         TblTmp* d_tmp, hipStream_t s) {
@@ -1406,9 +1310,13 @@ void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_i
   if (n <= 0) return;
   CPX_LAUNCH(k_finalize, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(Fp), s, d_in, n, d_aff, d_dst_index, d_comp);
 }
-void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s) {
+void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s, int out_stride) {
   if (n <= 0 || batch <= 0) return;
-  CPX_LAUNCH(k_compress, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_in, n, stride, d_out);
+  CPX_LAUNCH(k_compress, dim3((n + 255) / 256, batch), dim3(256), 0, s, d_in, n, stride, d_out, out_stride > 0 ? out_stride : n);
+}
+void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, int stride, int batch, uint8_t* d_out, int out_stride, hipStream_t s) {
+  if (ncols <= 0 || batch <= 0) return;
+  CPX_LAUNCH(k_compress_cols, dim3(batch), dim3(64), 0, s, d_in, d_cols, ncols, stride, d_out, out_stride);
 }
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
   const long total = (long)ntasks * cnt;

@@ -29,18 +29,27 @@
 
 namespace cpx {
 
-struct Signed30 {   // 13 signed limbs of 30 bits, value = sum v[i] 2^(30 i); limbs 0..11 in [0, 2^30), v[12] carries the sign
-  int32_t v[13];
+template <int NL> struct Signed30T {   // NL signed limbs of 30 bits, value = sum v[i] 2^(30 i); limbs 0..NL-2 in [0, 2^30), the last one carries the sign
+  int32_t v[NL];
 };
+typedef Signed30T<13> Signed30;
 struct Trans2x2 {
   int32_t u, v, q, r;
 };
 
-struct ModInv30Cfg {
+struct ModInv30Cfg {   // BLS12-381 base field: 381 bits = 12 x u32 words = 13 limbs
+  static constexpr int NL = 13, NW = 12, MAX_BATCHES = 40;
   static constexpr int32_t M30 = (1 << 30) - 1;
   static constexpr int32_t P30[13] = {0x3fffaaab, 0x27fbffff, 0x153ffffb, 0x2affffac, 0x30f6241e, 0x034a83da, 0x112bf673,
                                       0x12e13ce1, 0x2cd76477, 0x1ed90d2e, 0x29a4b1ba, 0x3a8e5ff9, 0x001a0111};
   static constexpr uint32_t PINV30 = 0x00030003;   // p^-1 mod 2^30
+};
+
+struct ModInv30FrCfg {   // BLS12-381 scalar field: 255 bits = 8 x u32 words = 9 limbs (the Fr inversions of the device-side protocol steps)
+  static constexpr int NL = 9, NW = 8, MAX_BATCHES = 28;   // <= 735 division steps for 255-bit inputs (the paper's bound), 30 per batch
+  static constexpr int32_t M30 = (1 << 30) - 1;
+  static constexpr int32_t P30[9] = {0x00000001, 0x3ffffffc, 0x3fe5bfef, 0x2f6900bf, 0x21d80553, 0x27602026, 0x17d48333, 0x29d4ca67, 0x000073ed};
+  static constexpr uint32_t PINV30 = 0x00000001;   // r^-1 mod 2^30
 };
 
 // 30 division steps on the low bits; returns the new eta (= -delta) and the transition matrix t with
@@ -88,45 +97,47 @@ CPX_HD int32_t modinv30_divsteps(int32_t eta, uint32_t f0, uint32_t g0, Trans2x2
 }
 
 // [d, e] <- t * [d, e] / 2^30 mod p, both kept in (-2p, p)
-CPX_HD void modinv30_update_de(Signed30& d, Signed30& e, const Trans2x2& t) {
-  constexpr int32_t M30 = ModInv30Cfg::M30;
+template <class C> CPX_HD void modinv30_update_de(Signed30T<C::NL>& d, Signed30T<C::NL>& e, const Trans2x2& t) {
+  constexpr int32_t M30 = C::M30;
+  constexpr int NL = C::NL;
   const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
-  const int32_t sd = d.v[12] >> 31, se = e.v[12] >> 31;   // all-ones if negative
+  const int32_t sd = d.v[NL - 1] >> 31, se = e.v[NL - 1] >> 31;   // all-ones if negative
   int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
   int32_t di = d.v[0], ei = e.v[0];
   int64_t cd = (int64_t)u * di + (int64_t)v * ei, ce = (int64_t)q * di + (int64_t)r * ei;
   // choose the multiples of p that clear the low 30 bits of the two sums
-  md -= (int32_t)((ModInv30Cfg::PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
-  me -= (int32_t)((ModInv30Cfg::PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
-  cd += (int64_t)ModInv30Cfg::P30[0] * md;
-  ce += (int64_t)ModInv30Cfg::P30[0] * me;
+  md -= (int32_t)((C::PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+  me -= (int32_t)((C::PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+  cd += (int64_t)C::P30[0] * md;
+  ce += (int64_t)C::P30[0] * me;
   cd >>= 30;
   ce >>= 30;
-  CPX_UNROLL for (int i = 1; i < 13; i++) {
+  CPX_UNROLL for (int i = 1; i < NL; i++) {
     di = d.v[i];
     ei = e.v[i];
     cd += (int64_t)u * di + (int64_t)v * ei;
     ce += (int64_t)q * di + (int64_t)r * ei;
-    cd += (int64_t)ModInv30Cfg::P30[i] * md;
-    ce += (int64_t)ModInv30Cfg::P30[i] * me;
+    cd += (int64_t)C::P30[i] * md;
+    ce += (int64_t)C::P30[i] * me;
     d.v[i - 1] = (int32_t)cd & M30;
     cd >>= 30;
     e.v[i - 1] = (int32_t)ce & M30;
     ce >>= 30;
   }
-  d.v[12] = (int32_t)cd;
-  e.v[12] = (int32_t)ce;
+  d.v[NL - 1] = (int32_t)cd;
+  e.v[NL - 1] = (int32_t)ce;
 }
 
 // [f, g] <- t * [f, g] / 2^30 (exact)
-CPX_HD void modinv30_update_fg(Signed30& f, Signed30& g, const Trans2x2& t) {
-  constexpr int32_t M30 = ModInv30Cfg::M30;
+template <class C> CPX_HD void modinv30_update_fg(Signed30T<C::NL>& f, Signed30T<C::NL>& g, const Trans2x2& t) {
+  constexpr int32_t M30 = C::M30;
+  constexpr int NL = C::NL;
   const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
   int32_t fi = f.v[0], gi = g.v[0];
   int64_t cf = (int64_t)u * fi + (int64_t)v * gi, cg = (int64_t)q * fi + (int64_t)r * gi;
   cf >>= 30;
   cg >>= 30;
-  CPX_UNROLL for (int i = 1; i < 13; i++) {
+  CPX_UNROLL for (int i = 1; i < NL; i++) {
     fi = f.v[i];
     gi = g.v[i];
     cf += (int64_t)u * fi + (int64_t)v * gi;
@@ -136,72 +147,75 @@ CPX_HD void modinv30_update_fg(Signed30& f, Signed30& g, const Trans2x2& t) {
     g.v[i - 1] = (int32_t)cg & M30;
     cg >>= 30;
   }
-  f.v[12] = (int32_t)cf;
-  g.v[12] = (int32_t)cg;
+  f.v[NL - 1] = (int32_t)cf;
+  g.v[NL - 1] = (int32_t)cg;
 }
 
-// a^-1 mod p for a canonical integer 0 < a < p given as 12 x u32 words; out likewise.  a = 0 gives 0.
-CPX_HD void words_inv_mod_p_divsteps(const uint32_t* a, uint32_t* out) {
-  constexpr int32_t M30 = ModInv30Cfg::M30;
-  Signed30 d, e, f, g;
-  CPX_UNROLL for (int i = 0; i < 13; i++) {
+// a^-1 mod p for a canonical integer 0 < a < p given as C::NW x u32 words; out likewise.  a = 0 gives 0.
+template <class C> CPX_HD void words_inv_divsteps(const uint32_t* a, uint32_t* out) {
+  constexpr int32_t M30 = C::M30;
+  constexpr int NL = C::NL, NW = C::NW;
+  Signed30T<NL> d, e, f, g;
+  CPX_UNROLL for (int i = 0; i < NL; i++) {
     d.v[i] = 0;
     e.v[i] = 0;
-    f.v[i] = ModInv30Cfg::P30[i];
+    f.v[i] = C::P30[i];
     const int bit = 30 * i, w = bit >> 5, o = bit & 31;
-    uint64_t x = w < 12 ? a[w] : 0;
-    if (w + 1 < 12) x |= (uint64_t)a[w + 1] << 32;
+    uint64_t x = w < NW ? a[w] : 0;
+    if (w + 1 < NW) x |= (uint64_t)a[w + 1] << 32;
     g.v[i] = (int32_t)((x >> o) & (uint32_t)M30);
   }
   e.v[0] = 1;
   int32_t eta = -1;
   // every batch performs 30 division steps; at most ~1100 are ever needed for 381-bit inputs (the bound of the paper),
   // the loop stops as soon as g = 0
-  for (int batch = 0; batch < 40; batch++) {
+  for (int batch = 0; batch < C::MAX_BATCHES; batch++) {
     Trans2x2 t;
     eta = modinv30_divsteps(eta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
-    modinv30_update_de(d, e, t);
-    modinv30_update_fg(f, g, t);
+    modinv30_update_de<C>(d, e, t);
+    modinv30_update_fg<C>(f, g, t);
     int32_t nz = 0;
-    CPX_UNROLL for (int i = 0; i < 13; i++) nz |= g.v[i];
+    CPX_UNROLL for (int i = 0; i < NL; i++) nz |= g.v[i];
     if (nz == 0) break;
   }
   // f = +-1 now (gcd); d = +-a^-1 in (-2p, p): fix the sign, then bring into [0, p)
-  const int32_t fneg = f.v[12] >> 31;   // all-ones if f = -1
+  const int32_t fneg = f.v[NL - 1] >> 31;   // all-ones if f = -1
   int32_t carry = 0;
-  CPX_UNROLL for (int i = 0; i < 13; i++) {   // d <- (f < 0 ? -d : d), limbs renormalised
+  CPX_UNROLL for (int i = 0; i < NL; i++) {   // d <- (f < 0 ? -d : d), limbs renormalised
     int32_t x = (d.v[i] ^ fneg) - fneg + carry;
     carry = x >> 30;
-    d.v[i] = i < 12 ? (x & M30) : x;
+    d.v[i] = i < NL - 1 ? (x & M30) : x;
   }
   for (int round = 0; round < 2; round++) {   // d in (-2p, 2p): add p while negative
-    const int32_t neg = d.v[12] >> 31;
+    const int32_t neg = d.v[NL - 1] >> 31;
     carry = 0;
-    CPX_UNROLL for (int i = 0; i < 13; i++) {
-      int32_t x = d.v[i] + (ModInv30Cfg::P30[i] & neg) + carry;
+    CPX_UNROLL for (int i = 0; i < NL; i++) {
+      int32_t x = d.v[i] + (C::P30[i] & neg) + carry;
       carry = x >> 30;
-      d.v[i] = i < 12 ? (x & M30) : x;
+      d.v[i] = i < NL - 1 ? (x & M30) : x;
     }
   }
   {   // subtract p if d >= p
-    Signed30 s;
+    Signed30T<NL> s;
     carry = 0;
-    CPX_UNROLL for (int i = 0; i < 13; i++) {
-      int32_t x = d.v[i] - ModInv30Cfg::P30[i] + carry;
+    CPX_UNROLL for (int i = 0; i < NL; i++) {
+      int32_t x = d.v[i] - C::P30[i] + carry;
       carry = x >> 30;
-      s.v[i] = i < 12 ? (x & M30) : x;
+      s.v[i] = i < NL - 1 ? (x & M30) : x;
     }
-    const int32_t keep = s.v[12] >> 31;   // negative: d < p, keep d
-    CPX_UNROLL for (int i = 0; i < 13; i++) d.v[i] = (d.v[i] & keep) | (s.v[i] & ~keep);
+    const int32_t keep = s.v[NL - 1] >> 31;   // negative: d < p, keep d
+    CPX_UNROLL for (int i = 0; i < NL; i++) d.v[i] = (d.v[i] & keep) | (s.v[i] & ~keep);
   }
-  CPX_UNROLL for (int k = 0; k < 12; k++) {   // 30-bit limbs -> 32-bit words
+  CPX_UNROLL for (int k = 0; k < NW; k++) {   // 30-bit limbs -> 32-bit words
     const int bit = 32 * k, i = bit / 30, o = bit % 30;
     uint64_t x = (uint64_t)(uint32_t)d.v[i] >> o;
-    if (i + 1 < 13) x |= (uint64_t)(uint32_t)d.v[i + 1] << (30 - o);
-    if (i + 2 < 13 && 60 - o < 32) x |= (uint64_t)(uint32_t)d.v[i + 2] << (60 - o);
+    if (i + 1 < NL) x |= (uint64_t)(uint32_t)d.v[i + 1] << (30 - o);
+    if (i + 2 < NL && 60 - o < 32) x |= (uint64_t)(uint32_t)d.v[i + 2] << (60 - o);
     out[k] = (uint32_t)x;
   }
 }
+
+CPX_HD void words_inv_mod_p_divsteps(const uint32_t* a, uint32_t* out) { words_inv_divsteps<ModInv30Cfg>(a, out); }
 
 // Montgomery-form inverse through it: X = a R  ->  X^-1 = a^-1 R^-1  ->  times R^3 (one Montgomery product) = a^-1 R
 CPX_HD Fp fe_inv_divsteps(const Fp& a) {
@@ -210,6 +224,15 @@ CPX_HD Fp fe_inv_divsteps(const Fp& a) {
   Fp t, r3;
   words_inv_mod_p_divsteps(a.v, t.v);
   CPX_UNROLL for (int i = 0; i < 12; i++) r3.v[i] = R3[i];
+  return fe_mul(t, r3);
+}
+
+// The same for the scalar field (Montgomery radix 2^256): the device-side protocol steps invert challenges with it.  0 -> 0.
+CPX_HD Fr fr_inv_divsteps(const Fr& a) {
+  const uint32_t R3[8] = {0x439b73afu, 0xc62c1807u, 0x8cf06990u, 0x1b3e0d18u, 0xc7b5f418u, 0x73d13c71u, 0xc8db33e9u, 0x6e2a5bb9u};   // R^3 mod r
+  Fr t, r3;
+  words_inv_divsteps<ModInv30FrCfg>(a.v, t.v);
+  CPX_UNROLL for (int i = 0; i < 8; i++) r3.v[i] = R3[i];
   return fe_mul(t, r3);
 }
 

@@ -1,0 +1,188 @@
+// Lane-parallel STROBE-128 / Keccak-f[1600] for the device side of the transcripts — product code (device only).
+//
+// Half a wave (32 lanes) per transcript: lane l < 25 holds 64-bit lane l of the Keccak state (x = l % 5, y = l / 5); a round
+// is 9 cross-lane shuffles (theta 6, rho+pi 1, chi 2) instead of ~150 dependent 64-bit operations on one lane (a single
+// GPU lane needs ~17 us per permutation, the 32-lane form ~4 us).  Message bytes are absorbed by the lane that owns their
+// position in the rate.  Same semantics as strobe.hpp (the host's code, merlin 3.0.0 as used by transcript.rs:28-60 of
+// the reference), pinned by the bit-exact proof tests.  When a whole 64-lane wave drives ONE transcript, both halves run
+// the same operations on the same inputs and hold identical copies of the state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mont32.hpp"
+#include "strobe.hpp"
+
+namespace cpx {
+
+// bytes written to LDS by some lanes of a wave become visible to the others (no block barrier: the two proofs of a
+// work-group run divergent retry loops)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveStrobe {
+  uint64_t a;                 // this lane's 64-bit lane of the state (lanes >= 25 keep 0)
+  uint32_t pos, pos_begin;    // uniform over the 32 lanes of a proof
+  int l;                      // lane within the 32-lane group
+
+  __device__ __forceinline__ uint64_t shfl(uint64_t v, int src) const {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 32), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 32);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  __device__ void keccak() {
+    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                             0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                             0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                             0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                             0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    // rotation offsets r[x + 5y] of rho
+    const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    const int lc = l < 25 ? l : 0;   // idle lanes mirror lane 0 (their value is never used)
+    const int x = lc % 5, y = lc / 5;
+    // rho + pi as a gather: destination (X, Y) = (y, (2x + 3y) % 5)  <=>  source x = (X + 3Y) % 5, y = X
+    const int sx = (x + 3 * y) % 5, sy = x, src = sx + 5 * sy, rot = RHO[src];
+    const int xm1 = (x + 4) % 5 + 5 * y, xp1 = (x + 1) % 5 + 5 * y, xp2 = (x + 2) % 5 + 5 * y;
+    for (int r = 0; r < 24; r++) {
+      uint64_t c = a;
+      CPX_UNROLL for (int k = 1; k < 5; k++) c ^= shfl(a, (lc + 5 * k) % 25);     // column parity (same for every y)
+      const uint64_t d = shfl(c, xm1) ^ rol64(shfl(c, xp1), 1);
+      a ^= d;
+      uint64_t b = shfl(a, src);
+      b = rot ? ((b << rot) | (b >> (64 - rot))) : b;
+      a = b ^ (~shfl(b, xp1) & shfl(b, xp2));
+      if (l == 0) a ^= RC[r];
+    }
+    if (l >= 25) a = 0;
+  }
+  __device__ __forceinline__ void xor_byte(uint32_t i, uint8_t b) {
+    if ((int)(i >> 3) == l) a ^= (uint64_t)b << (8 * (i & 7));
+  }
+  __device__ void run_f() {
+    xor_byte(pos, (uint8_t)pos_begin);
+    xor_byte(pos + 1, 0x04);
+    xor_byte(Strobe::RATE + 1, 0x80);
+    keccak();
+    pos = pos_begin = 0;
+  }
+  // absorb n bytes readable by every lane (global, constant or LDS memory)
+  __device__ void absorb(const uint8_t* d, size_t n) {
+    while (n) {
+      const uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), n);
+      uint64_t v = 0;
+      CPX_UNROLL for (int j = 0; j < 8; j++) {
+        const uint32_t sidx = 8u * (uint32_t)l + j;   // state byte owned by this lane
+        if (sidx >= pos && sidx < pos + k) v |= (uint64_t)d[sidx - pos] << (8 * j);
+      }
+      a ^= v;
+      pos += k;
+      d += k;
+      n -= k;
+      if (pos == Strobe::RATE) run_f();
+    }
+  }
+  __device__ void begin_op(uint32_t flags, bool more) {
+    if (more) return;
+    const uint8_t h0 = (uint8_t)pos_begin, h1 = (uint8_t)flags;
+    pos_begin = pos + 1;
+    xor_byte(pos, h0);                 // the two header bytes, one at a time (the rate boundary may fall between them)
+    if (++pos == Strobe::RATE) run_f();
+    xor_byte(pos, h1);
+    if (++pos == Strobe::RATE) run_f();
+    if ((flags & (Strobe::FLAG_C | Strobe::FLAG_K)) && pos != 0) run_f();
+  }
+  __device__ void meta_ad(const void* d, size_t n, bool more) {
+    begin_op(Strobe::FLAG_M | Strobe::FLAG_A, more);
+    absorb(static_cast<const uint8_t*>(d), n);
+  }
+  __device__ void len4(size_t len, uint8_t* scratch4) {   // LE32(len) through the group's scratch bytes
+    if (l < 4) scratch4[l] = (uint8_t)(len >> (8 * l));
+    wave_lds_sync();
+    meta_ad(scratch4, 4, true);
+  }
+  __device__ void append_begin(const char* label, size_t label_len, size_t len, uint8_t* scratch) {
+    meta_ad(label, label_len, false);
+    len4(len, scratch);
+    begin_op(Strobe::FLAG_A, false);
+  }
+  __device__ void init(const char* label, size_t label_len, uint8_t* scratch) {
+    const uint8_t ini[18] = {1, 168, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
+    a = 0;
+    CPX_UNROLL for (int i = 0; i < 18; i++) xor_byte(i, ini[i]);
+    keccak();
+    pos = pos_begin = 0;
+    meta_ad("Merlin v1.0", 11, false);
+    append_begin("dom-sep", 7, label_len, scratch);
+    absorb(reinterpret_cast<const uint8_t*>(label), label_len);
+  }
+  // ---- state import / export ([27] u64: 25 lanes, pos, pos_begin — the layout host::Transcript::load_state reads) ----
+  __device__ __forceinline__ void load(const uint64_t* st27, int lane_in_group) {
+    l = lane_in_group;
+    a = l < 25 ? st27[l] : 0;
+    pos = (uint32_t)st27[25];
+    pos_begin = (uint32_t)st27[26];
+  }
+  __device__ __forceinline__ void store(uint64_t* st27) const {
+    if (l < 25) st27[l] = a;
+    if (l == 25) st27[25] = pos;
+    if (l == 26) st27[26] = pos_begin;
+  }
+  // append_message(label, data): data readable by every lane (global / LDS / constant)
+  __device__ void append_message(const char* label, size_t label_len, const uint8_t* data, size_t len, uint8_t* scratch) {
+    append_begin(label, label_len, len, scratch);
+    absorb(data, len);
+  }
+  // CurdleproofsTranscript::append(label, &Fr) (transcript.rs:29-33): the canonical 32 little-endian bytes of a scalar every
+  // lane holds (Montgomery form)
+  __device__ void append_scalar(const char* label, size_t label_len, const Fr& x_mont, uint8_t* scratch) {
+    const Fr c = fe_from_mont(x_mont);
+    if (l < 8) {
+      CPX_UNROLL for (int j = 0; j < 4; j++) scratch[16 + 4 * l + j] = (uint8_t)(c.v[l] >> (8 * j));
+    }
+    wave_lds_sync();
+    append_begin(label, label_len, 32, scratch);
+    absorb(scratch + 16, 32);
+    wave_lds_sync();   // scratch may be rewritten right away by the next operation
+  }
+  // get_and_append_challenge (transcript.rs:40-60): 64 PRF bytes, Fr::from_random_bytes on the first 32 with the top bit
+  // cleared, retried until canonical and non-zero, then appended back under the same label.  Returns the Montgomery form
+  // (uniform over the lanes of the group).
+  __device__ Fr challenge_scalar(const char* label, size_t label_len, uint8_t* scratch) {
+    for (;;) {
+      meta_ad(label, label_len, false);
+      len4(64, scratch);
+      begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
+      // squeeze 64 bytes = lanes 0..7 of the state, which the PRF operation overwrites with zero (pos is 0 here)
+      uint64_t w[4];
+      CPX_UNROLL for (int j = 0; j < 4; j++) w[j] = shfl(a, j);
+      if (l < 8) a = 0;
+      pos = 64;
+      w[3] &= 0x7fffffffffffffffULL;
+      Fr c;
+      CPX_UNROLL for (int j = 0; j < 4; j++) {
+        c.v[2 * j] = (uint32_t)w[j];
+        c.v[2 * j + 1] = (uint32_t)(w[j] >> 32);
+      }
+      bool nz = false, lt = false;
+      for (int j = 0; j < 8; j++) nz |= c.v[j] != 0;
+      for (int j = 7; j >= 0; j--) {
+        if (c.v[j] != FrCfg::P[j]) {
+          lt = c.v[j] < FrCfg::P[j];
+          break;
+        }
+      }
+      if (lt && nz) {
+        if (l < 4) {
+          CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * l + j] = (uint8_t)(w[l] >> (8 * j));
+        }
+        wave_lds_sync();
+        append_begin(label, label_len, 32, scratch);
+        absorb(scratch + 16, 32);
+        wave_lds_sync();
+        return fe_to_mont(c);
+      }
+    }
+  }
+};
+
+}  // namespace cpx

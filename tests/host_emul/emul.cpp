@@ -316,6 +316,16 @@ int emul_modinv30_check(const uint8_t* a, size_t n, uint8_t* first_out) {
   return bad;
 }
 
+// the scalar-field instance (fr_inv_divsteps: Montgomery in, Montgomery out): out[i] = a[i]^-1 (wire form)
+void emul_fr_inv_divsteps(const uint8_t* a, size_t n, uint8_t* out) {
+  for (size_t i = 0; i < n; i++) {
+    Fr x, y;
+    memcpy(x.v, a + 32 * i, 32);
+    y = fr_inv_divsteps(x);
+    memcpy(out + 32 * i, y.v, 32);
+  }
+}
+
 // endomorphism split of canonical scalars (glv.hpp): per scalar |t| (16 B), q (16 B), neg_k, neg_t (1 B each) and the
 // 32 biased digit bytes the table kernel derives from them
 void emul_glv_split(const uint8_t* k, size_t n, uint8_t* out) {

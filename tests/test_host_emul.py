@@ -29,6 +29,8 @@ def emul():
     L.emul_host_fr_inv_check.argtypes = [vp, sz]
     L.emul_modinv30_check.argtypes = [vp, sz, vp]
     L.emul_glv_split.argtypes = [vp, sz, vp]
+    L.emul_fr_inv_divsteps.argtypes = [vp, sz, vp]
+    L.emul_fr_inv_divsteps.restype = None
     L.emul_msm_endo.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.emul_msm_endo.restype = None
     L.emul_glv_split.restype = None
@@ -274,6 +276,25 @@ def test_divstep_inversion_matches_euclid(emul):
         o = _o(48)
         emul.emul_modinv30_check(_b(v.to_bytes(48, "little")), 1, o)
         assert int.from_bytes(bytes(o), "little") == pow(v, -1, P)
+
+
+def test_fr_inversion_by_division_steps(emul):
+    """fr_inv_divsteps (modinv30.hpp on 9 limbs): the inversion of the device-side protocol steps (challenge inverses) vs pow(x, -1, r)"""
+    import random
+    rnd = random.Random(12)
+    RR = 1 << 256
+    vals = [1, 2, 3, R - 1, R - 2, (R - 1) // 2, (R + 1) // 2, 1 << 30, (1 << 30) - 1, 1 << 254, (1 << 240) - 1, 0x3fffffff << 30, R >> 1, R >> 30]
+    vals += [rnd.randrange(1, R) for _ in range(3000)] + [rnd.randrange(1, 1 << b) for b in range(1, 255, 2)]
+    blob = b"".join((v * RR % R).to_bytes(32, "little") for v in vals)       # Montgomery wire form
+    out = _o(32 * len(vals))
+    emul.emul_fr_inv_divsteps(_b(blob), len(vals), out)
+    out = bytes(out)
+    for i, v in enumerate(vals):
+        got = int.from_bytes(out[32 * i:32 * i + 32], "little")
+        assert got == pow(v, -1, R) * RR % R, v
+    z = _o(32)
+    emul.emul_fr_inv_divsteps(_b(bytes(32)), 1, z)
+    assert bytes(z) == bytes(32)                                             # 0 -> 0 (ark_ff batch_inversion convention)
 
 
 def test_glv_split(emul):

@@ -1459,6 +1459,10 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
   // a zero (or non-reduced) factor would silently drop the check it weights
   for (size_t i = 0; i < B * rand_stride; i++)
     if (!host::is_valid_factor(rand + 32 * i)) throw ArgError("verifier random factors must be non-zero reduced field elements");
+  if (device_prefix(B)) {   // the whole verifier on the GPU (engine_device.cpp); a few proofs: host-driven Fiat-Shamir below
+    verify_core_device(proofs, rand, rand_stride, verdict, fused_partial, fused_invalid);
+    return;
+  }
 
   struct VState {
     Transcript tr{"curdleproofs"};

@@ -240,6 +240,22 @@ class Engine {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   };
   DevProver dprove_;
+  struct DevVerifier {
+    std::vector<const void*> signature;
+    VerifyDev dev;
+    DevBuf<uint8_t> proofs, slotcomp, status;
+    DevBuf<Fr> rnd, vsc, scal, scal_crs;
+    DevBuf<uint32_t> flags, src_off, dst, mdst, gidx;
+    DevBuf<MsmTask> mtasks, gtasks;
+    DevBuf<FixTask> ftasks;
+    TblPlan pd;                                  // D and A'
+    int fix_wpw = 16, fix_parts = 1, fix_wpw1 = 2, fix_parts1 = 8;
+    size_t G = 1, NT = 1;                        // fused batch: proofs per group, groups
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  };
+  DevVerifier dverify_;
+  void prepare_device_verifier(size_t rand_stride);
+  void verify_core_device(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid);
   void build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std::vector<uint32_t>& comp_index);
   void exec_plan(const TblPlan& pl, uint8_t* d_comp_registry);
   void prepare_device_prover();

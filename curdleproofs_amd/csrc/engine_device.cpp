@@ -441,6 +441,226 @@ void Engine::batch_prove_device(const uint32_t* permutation, const uint8_t* k_in
   }
 }
 
+// ---------------------------------------------------------------- verifier
+void Engine::prepare_device_verifier(size_t rand_stride) {
+  const size_t B = B_, ell = ell_, n = n_, L = L_;
+  const SlotMap sm(L);
+  const size_t NS = sm.count(), NPP = sm.n_proof_points(), NM = 6 + NPP, NI = 4 * ell, NPT = NI + NM, psz = proof_size();
+  DevVerifier& dv = dverify_;
+  d_bytes_.ensure(B * 4 * ell * 48);
+  d_mcomp_.ensure(B * 48);
+  d_tstate_.ensure(B * 27);
+  d_veca_.ensure(B * ell);
+  dv.proofs.ensure(B * psz);
+  dv.rnd.ensure(B * 12);
+  dv.vsc.ensure(B * (size_t)VSC_COUNT);
+  dv.slotcomp.ensure(B * NS * 48);
+  dv.status.ensure(B * NPP);
+  dv.scal.ensure(B * NPT + n);   // + the summed CRS scalars of a fused batch
+  dv.scal_crs.ensure(B * n);
+  dv.flags.ensure(B);
+  dv.src_off.ensure(B * NPP);
+  dv.dst.ensure(B * NPP);
+  dv.mdst.ensure(B);
+  dv.mtasks.ensure(B);
+  dv.ftasks.ensure(B + 1);
+  dv.gidx.ensure(B * NPT);
+  d_conv_.ensure(2 * B * NPT);
+  d_digits_.ensure(9 * B * NPT);
+  d_ttasks_.ensure(B);
+  d_part_.ensure(B * 32);
+  d_res_.ensure(B);
+  d_comp_.ensure(B * 48);
+  const std::vector<const void*> sig = {d_pp_.p,       d_bytes_.p,  d_mcomp_.p,     d_tstate_.p, d_veca_.p,  dv.proofs.p, dv.rnd.p,    dv.vsc.p, dv.slotcomp.p,
+                                        dv.status.p,   dv.scal.p,   dv.scal_crs.p,  dv.flags.p,  dv.mtasks.p, dv.ftasks.p, dv.gidx.p,  ctab(),   fixtab(),
+                                        (const void*)(uintptr_t)B, (const void*)(uintptr_t)ell, (const void*)(uintptr_t)fix_bits_};
+  dv.dev.rand_stride = (int)rand_stride;
+  if (sig == dv.signature) return;
+  dv.signature.clear();
+  VerifyDev& d = dv.dev;
+  d.ell = (int)ell;
+  d.n = (int)n;
+  d.L = (int)L;
+  d.NS = (int)NS;
+  d.NM = (int)NM;
+  d.psz = psz;
+  d.proofs = dv.proofs.p;
+  d.rnd = dv.rnd.p;
+  d.tstate = d_tstate_.p;
+  d.veca = d_veca_.p;
+  d.vsc = dv.vsc.p;
+  d.slotcomp = dv.slotcomp.p;
+  d.inst_comp = d_bytes_.p;
+  d.mcomp = d_mcomp_.p;
+  d.status = dv.status.p;
+  d.scal = dv.scal.p;
+  d.scal_crs = dv.scal_crs.p;
+  d.flags = dv.flags.p;
+  memcpy(d.crs_h_comp, crs_H_comp_, 48);
+
+  // where the proof points sit inside a serialized proof (slot order == serialisation order, the seven scalars interleaved)
+  std::vector<uint32_t> pt_off(NPP);
+  for (size_t q = 0; q < NPP; q++) pt_off[q] = (uint32_t)(48 * q + (q >= 9 ? 32 : 0) + (q >= 11 + 4 * L ? 64 : 0) + (q >= 15 + 4 * L ? 96 : 0));
+  std::vector<uint32_t> so(B * NPP), ds(B * NPP), md(B);
+  for (size_t p = 0; p < B; p++) {
+    for (size_t q = 0; q < NPP; q++) {
+      so[p * NPP + q] = (uint32_t)(p * psz + pt_off[q]);
+      ds[p * NPP + q] = slot_index(p, SL_A + (int)q);
+    }
+    md[p] = slot_index(p, SL_M);
+  }
+  CPX_HIP(hipMemcpy(dv.src_off.p, so.data(), so.size() * 4, hipMemcpyHostToDevice));
+  CPX_HIP(hipMemcpy(dv.dst.p, ds.data(), ds.size() * 4, hipMemcpyHostToDevice));
+  CPX_HIP(hipMemcpy(dv.mdst.p, md.data(), md.size() * 4, hipMemcpyHostToDevice));
+  // D = B - beta^-1 sum(G) + alpha sum(H) (grand_product_argument.rs:223) and A' = A + cm_T.T_1 + cm_U.T_1 (curdleproofs.rs:258)
+  // are hashed into the transcript, so they are needed as bytes
+  {
+    const TblSeg none{nullptr, nullptr, 0, 0};
+    std::vector<TblReq> reqs;
+    std::vector<uint32_t> ci;
+    for (size_t p = 0; p < B; p++) {
+      TblReq rd{cseg(n + 3, 2), nullptr, none, nullptr, slot_index(p, sm.D())};
+      rd.dev = dv.vsc.p + p * VSC_COUNT + VSC_NEG_BETA_G_INV;
+      rd.add[0] = slot_index(p, SL_B);
+      TblReq ra{none, nullptr, none, nullptr, slot_index(p, sm.APRIME())};
+      ra.add[0] = slot_index(p, SL_A);
+      ra.add[1] = slot_index(p, SL_CMT1);
+      ra.add[2] = slot_index(p, SL_CMU1);
+      reqs.push_back(rd);
+      ci.push_back((uint32_t)(p * NS + sm.D()));
+      reqs.push_back(ra);
+      ci.push_back((uint32_t)(p * NS + sm.APRIME()));
+    }
+    build_plan(dv.pd, reqs, ci);
+  }
+  // the accumulated check: per proof one fixed-base task over G | Hvec and one bucket MSM over R | S | T | U and the misc slots
+  std::vector<uint32_t> all_idx(NPT);   // row-relative gather list
+  for (size_t i = 0; i < NI; i++) all_idx[i] = (uint32_t)i;
+  for (size_t j = 0; j < NM; j++) all_idx[NI + j] = (uint32_t)(NI + j);   // misc index j == slot j (SL_H .. SL_M, then the proof points)
+  const uint32_t* d_all = idx_list(all_idx);
+  dv.fix_wpw = msm_fix_windows_per_wave((int)B, fix_bits_);
+  dv.fix_parts = 256 / fix_bits_ / dv.fix_wpw;
+  dv.fix_wpw1 = msm_fix_windows_per_wave(1, fix_bits_);
+  dv.fix_parts1 = 256 / fix_bits_ / dv.fix_wpw1;
+  std::vector<MsmTask> mt(B);
+  std::vector<FixTask> ft(B + 1);
+  std::vector<uint32_t> gi(B * NPT);
+  for (size_t p = 0; p < B; p++) {
+    mt[p] = MsmTask{pp(p), d_all, dv.scal.p + p * NPT, (uint32_t)NPT, 0, (uint32_t)(p * NPT)};
+    ft[p] = FixTask{nullptr, dv.scal_crs.p + p * n, 0, (uint32_t)n, 0, (uint32_t)(p * dv.fix_parts)};
+    for (size_t i = 0; i < NPT; i++) gi[p * NPT + i] = (uint32_t)(p * pp_stride_ + i);
+  }
+  ft[B] = FixTask{nullptr, dv.scal.p + B * NPT, 0, (uint32_t)n, 0, 0};   // fused batch: the CRS scalars summed over the proofs
+  CPX_HIP(hipMemcpy(dv.mtasks.p, mt.data(), B * sizeof(MsmTask), hipMemcpyHostToDevice));
+  CPX_HIP(hipMemcpy(dv.ftasks.p, ft.data(), (B + 1) * sizeof(FixTask), hipMemcpyHostToDevice));
+  CPX_HIP(hipMemcpy(dv.gidx.p, gi.data(), gi.size() * 4, hipMemcpyHostToDevice));
+  // fused batch: the proofs in up to 256 groups, every group one task of the endomorphism bucket-list kernel
+  dv.G = (B + 255) / 256;
+  dv.NT = (B + dv.G - 1) / dv.G;
+  dv.gtasks.ensure(dv.NT);
+  std::vector<MsmTask> gt(dv.NT);
+  for (size_t g = 0; g < dv.NT; g++) {
+    const size_t off = g * dv.G * NPT, np_ = std::min(dv.G, B - g * dv.G) * NPT;
+    gt[g] = MsmTask{d_pp_.p, dv.gidx.p + off, dv.scal.p + off, (uint32_t)np_, 0, (uint32_t)off};
+  }
+  CPX_HIP(hipMemcpy(dv.gtasks.p, gt.data(), dv.NT * sizeof(MsmTask), hipMemcpyHostToDevice));
+  if (!dv.ev_a) {
+    CPX_HIP(hipEventCreateWithFlags(&dv.ev_a, hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&dv.ev_b, hipEventDisableTiming));
+  }
+  dv.signature = sig;
+}
+
+// curdleproofs.rs:197 for every loaded instance (verdict != nullptr) or BASELINE config 5 (fused_partial != nullptr), all on the
+// device: the host uploads proofs and random factors, enqueues, and reads back 48 bytes + a flag word per proof (or one point).
+void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid) {
+  CPX_HIP(hipSetDevice(device_));
+  const size_t B = B_, ell = ell_, n = n_, L = L_;
+  const SlotMap sm(L);
+  const size_t NPP = sm.n_proof_points(), NM = 6 + NPP, NPT = 4 * ell + NM, psz = proof_size();
+  prepare_device_verifier(rand_stride);
+  DevVerifier& dv = dverify_;
+  const VerifyDev& d = dv.dev;
+  const int Bi = (int)B;
+  CPX_HIP(hipMemcpyAsync(dv.proofs.p, proofs, B * psz, hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dv.rnd.p, rand, B * rand_stride * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  // -- V0: compressed instance vectors, M -> affine; side stream: transcript prefix; main: proof points -> slots
+  tick("k_compress", 0, (double)(4 * ell * B));
+  launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, Bi, d_bytes_.p, stream_);
+  tock();
+  launch_finalize(d_Mjac_.p, Bi, d_pp_.p, dv.mdst.p, d_mcomp_.p, stream_);
+  CPX_HIP(hipEventRecord(dv.ev_a, stream_));
+  CPX_HIP(hipStreamWaitEvent(side_.stream, dv.ev_a, 0));
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side_.stream);
+  CPX_HIP(hipEventRecord(dv.ev_b, side_.stream));
+  tick("k_decompress", 0, (double)(B * NPP));
+  launch_decompress(dv.proofs.p, (int)(B * NPP), d_pp_.p, dv.dst.p, dv.status.p, 1, stream_, dv.src_off.p);
+  tock();
+  CPX_HIP(hipStreamWaitEvent(stream_, dv.ev_b, 0));
+  // -- V1: transcript up to the grand-product beta; D and A' as bytes; the rest of the transcript and the scalars
+  launch_vs_prefix(d, Bi, stream_);
+  exec_plan(dv.pd, dv.slotcomp.p);
+  launch_vs_scalars(d, Bi, stream_);
+  // -- V2: the accumulated check(s)
+  h_comp_.ensure(std::max<size_t>(B * 48, sizeof(Jac)));
+  h_u32_.ensure(B);
+  if (fused_partial) {
+    launch_vs_crs_sum(dv.scal_crs.p, Bi, (int)n, dv.scal.p + B * NPT, stream_);
+    d_tpart_.ensure(dv.fix_parts1);
+    ensure_raw_sets(std::max<size_t>(dv.NT * 32, dv.fix_parts1));
+    launch_msm_fix(dv.ftasks.p + B, 1, fixtab(), fix_bits_, dv.fix_wpw1, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
+    reduce_sets(dv.fix_parts1, 0);
+    const size_t NT = dv.NT, NT16 = (NT + 15) / 16 * 16, N = B * NPT;
+    d_part_.ensure(NT * 32);
+    d_wsum_.ensure(NT16 + NT16 / 16);
+    d_ttasks_.ensure(NT);
+    CPX_HIP(hipMemsetAsync(d_wsum_.p, 0, (NT16 + NT16 / 16) * sizeof(TJac), stream_));   // all-zero = identity: pads the summation levels
+    tick("k_msm_tblw<2, true>", 128.0 * N, (double)N);
+    launch_msm_endo(dv.gtasks.p, (int)NT, (int)(dv.G * NPT), d_conv_.p, d_digits_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
+    tock();
+    reduce_sets(0, NT * 32, d_part_.p);
+    tick("k_msm_tail", 0, (double)NT, true);
+    launch_msm_tail(d_part_.p, d_wsum_.p, nullptr, (int)NT, 16, 8, stream_, nullptr, 0, 2);                               // windows of a group
+    launch_msm_tail(d_wsum_.p, d_wsum_.p + NT16, nullptr, (int)(NT16 / 16), 16, 0, stream_);                              // 16 groups each
+    launch_msm_tail(d_wsum_.p + NT16, nullptr, d_res_.p, 1, (int)(NT16 / 16), 0, stream_, d_tpart_.p, dv.fix_parts1);      // + the fixed-base part
+    tock();
+    CPX_HIP(hipMemcpyAsync(h_comp_.p, d_res_.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
+    CPX_HIP(hipMemcpyAsync(h_u32_.p, dv.flags.p, B * 4, hipMemcpyDeviceToHost, stream_));
+    wait_stream();
+    memcpy(fused_partial, h_comp_.p, sizeof(Jac));
+    int invalid = 0;
+    for (size_t p = 0; p < B; p++) invalid += h_u32_.p[p] ? 1 : 0;
+    if (fused_invalid) *fused_invalid = invalid;
+    flush_timers();
+    return;
+  }
+  d_tpart_.ensure(B * (size_t)dv.fix_parts);
+  ensure_raw_sets(B * std::max<size_t>(dv.fix_parts, 32));
+  tick(fix_kernel_name(fix_bits_, dv.fix_wpw), 128.0 * n * B, (double)(n * B));
+  launch_msm_fix(dv.ftasks.p, Bi, fixtab(), fix_bits_, dv.fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
+  tock();
+  reduce_sets(B * dv.fix_parts, 0);
+  tick("k_msm_tblw<2, true>", 128.0 * NPT * B, (double)(NPT * B));
+  launch_msm_endo(dv.mtasks.p, Bi, (int)NPT, d_conv_.p, d_digits_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
+  tock();
+  reduce_sets(0, B * 32, d_part_.p);
+  tick("k_msm_tail", 0, (double)B);
+  launch_msm_tail(d_part_.p, nullptr, d_res_.p, Bi, 16, 8, stream_, d_tpart_.p, dv.fix_parts, 2);
+  tock();
+  tick("k_finalize", 0, (double)B);
+  launch_finalize(d_res_.p, Bi, nullptr, nullptr, d_comp_.p, stream_);
+  tock();
+  CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
+  CPX_HIP(hipMemcpyAsync(h_u32_.p, dv.flags.p, B * 4, hipMemcpyDeviceToHost, stream_));
+  wait_stream();
+  for (size_t p = 0; p < B; p++) {
+    const uint32_t f = h_u32_.p[p];
+    const bool ok = h_comp_.p[p * 48] == 0xc0;
+    verdict[p] = (f & 1u) ? CPX_ERR_DESERIALIZE : (((f & 2u) || !ok) ? CPX_ERR_VERIFY : CPX_OK);
+  }
+  flush_timers();
+}
+
 void trace_scalar(const char* name, const Fr& x) {
   fprintf(stderr, "[cpx trace] %-12s ", name);
   for (int i = 7; i >= 0; i--) fprintf(stderr, "%08x", x.v[i]);

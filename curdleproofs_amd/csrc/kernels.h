@@ -123,7 +123,9 @@ void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_o
 void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, int stride, int batch, uint8_t* d_out, int out_stride, hipStream_t s);
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
-void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s);
+// d_src_offset (optional): encoding i starts at byte d_src_offset[i] of d_in (points inside serialized proofs) instead of 48 i
+void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
+                       const uint32_t* d_src_offset = nullptr);
 // Fr algebra of the prover's log rounds on device-resident vectors (kernels.hip: "Fr algebra of the log rounds"):
 // IPA vec [nproofs][4][n] = c | d | SG | SGp, out [nproofs][4 (n/2) + 2]; SameMSM vec [nproofs][2][n] = x | SM, out [nproofs][n];
 // gam [nproofs][2] = gamma, gamma^-1

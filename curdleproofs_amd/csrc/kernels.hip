@@ -909,10 +909,11 @@ __device__ __noinline__ F28 f28_sqrt_device(const F28& a) { return f28_sqrt_cand
 __device__ __noinline__ bool g1_in_subgroup_device(const Aff28& P) { return g1_28_in_subgroup(P); }
 
 __global__ __launch_bounds__(64, 2) void k_decompress(const uint8_t* __restrict__ in, int n, Aff* __restrict__ out,
-                                                   const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ status, int check_subgroup) {
+                                                   const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ status, int check_subgroup,
+                                                   const uint32_t* __restrict__ src_offset) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
-  const uint8_t* b = in + (size_t)g * 48;
+  const uint8_t* b = in + (src_offset ? (size_t)src_offset[g] : (size_t)g * 48);   // dense encodings, or byte offsets into serialized proofs
   const bool compressed = b[0] & 0x80, infinity = b[0] & 0x40, sort = b[0] & 0x20;
   Fp xc;
   for (int l = 0; l < 12; l++) {
@@ -1324,9 +1325,10 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
   const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 18 * SMUL_THREADS * sizeof(uint32_t);
   CPX_LAUNCH(k_smul, dim3((unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS)), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
 }
-void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s) {
+void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
+                       const uint32_t* d_src_offset) {
   if (n <= 0) return;
-  CPX_LAUNCH(k_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in, n, d_out, d_dst_index, d_status, check_subgroup);
+  CPX_LAUNCH(k_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in, n, d_out, d_dst_index, d_status, check_subgroup, d_src_offset);
 }
 void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s) {
   if (nproofs > 0) CPX_LAUNCH(k_ipa_round_scalars, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_beta, d_out);

@@ -111,7 +111,8 @@ struct VerifyDev {
   const uint8_t* inst_comp;       // [B][4 ell][48]
   const uint8_t* mcomp;           // [B][48]
   const uint8_t* status;          // [B][n_proof_points]  decompression status of the proof points
-  Fr* scal;                       // [B][4 ell + NM + n]: instance part | misc part | CRS part of the accumulated check
+  Fr* scal;                       // [B][4 ell + NM]: instance part | misc part of the accumulated check
+  Fr* scal_crs;                   // [B][n]: its CRS part (G | Hvec)
   uint32_t* flags;                // [B]: bit 0 = undecodable (bad scalar / point encoding), bit 1 = structural rejection
   uint8_t crs_h_comp[48];
 };
@@ -127,5 +128,7 @@ void launch_ps_smsm_round(const ProveDev& d, int B, int j, hipStream_t s);
 void launch_ps_serialize(const ProveDev& d, int B, hipStream_t s);
 void launch_vs_prefix(const VerifyDev& d, int B, hipStream_t s);
 void launch_vs_scalars(const VerifyDev& d, int B, hipStream_t s);
+// out[i] = sum_p scal_crs[p * n + i], i < n  (the CRS scalars of a fused batch)
+void launch_vs_crs_sum(const Fr* d_scal_crs, int B, int n, Fr* d_out, hipStream_t s);
 
 }  // namespace cpx

@@ -405,6 +405,340 @@ __global__ __launch_bounds__(64) void k_ps_serialize(const ProveDev d) {
   }
 }
 
+// ------------------------------------------------------------------ verifier
+namespace {
+struct VerifyView {
+  const VerifyDev& d;
+  int p;
+  __device__ VerifyView(const VerifyDev& d_, int p_) : d(d_), p(p_) {}
+  __device__ const uint8_t* pb() const { return d.proofs + (size_t)p * d.psz; }
+  // byte offset of proof point q (slot SL_A + q) inside the serialized proof: scalars are interleaved after 9, 11 + 4L and 15 + 4L points
+  __device__ size_t pt_off(int q) const { return 48 * (size_t)q + (q >= 9 ? 32 : 0) + (q >= 11 + 4 * d.L ? 64 : 0) + (q >= 15 + 4 * d.L ? 96 : 0); }
+  __device__ const uint8_t* P(int slot) const { return pb() + pt_off(slot - SL_A); }
+  __device__ size_t off_rp() const { return 48 * 9; }
+  __device__ size_t off_c() const { return off_rp() + 32 + 48 * (size_t)(2 + 4 * d.L); }
+  __device__ size_t off_zk() const { return off_c() + 64 + 48 * 4; }
+  __device__ size_t off_x() const { return off_zk() + 96 + 48 * (size_t)(3 + 6 * d.L); }
+  __device__ uint8_t* slot(int s) const { return d.slotcomp + ((size_t)p * d.NS + s) * 48; }
+  __device__ Fr* vsc() const { return d.vsc + (size_t)p * VSC_COUNT; }
+  __device__ uint64_t* tstate() const { return d.tstate + (size_t)p * 27; }
+  __device__ const Fr* rnd() const { return d.rnd + (size_t)p * d.rand_stride; }
+};
+// canonical little-endian scalar -> Montgomery; false (and zero) if >= r  (Fr::deserialize_compressed)
+__device__ bool load_scalar(const uint8_t* b, Fr& out) {
+  Fr c;
+  CPX_UNROLL for (int j = 0; j < 8; j++) c.v[j] = (uint32_t)b[4 * j] | ((uint32_t)b[4 * j + 1] << 8) | ((uint32_t)b[4 * j + 2] << 16) | ((uint32_t)b[4 * j + 3] << 24);
+  bool lt = false;
+  for (int j = 7; j >= 0; j--) {
+    if (c.v[j] != FrCfg::P[j]) {
+      lt = c.v[j] < FrCfg::P[j];
+      break;
+    }
+  }
+  out = lt ? fe_to_mont(c) : Fr::zero();
+  return lt;
+}
+__device__ Fr fr_pow_u32(const Fr& a, uint32_t e) {
+  Fr r = Fr::one();
+  for (int i = 31; i >= 0; i--) {
+    r = fe_mul(r, r);
+    if ((e >> i) & 1) r = fe_mul(r, a);
+  }
+  return r;
+}
+}  // namespace
+
+// V1 (after decompression of the proof points and the transcript prefix): deserialisation verdict, the transcript up to the
+//    grand-product beta, the scalars of D.  curdleproofs.rs:213-222, same_permutation_argument.rs:131-145,
+//    grand_product_argument.rs:200-223
+__global__ __launch_bounds__(64) void k_vs_prefix(const VerifyDev d) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  Fr* buf = reinterpret_cast<Fr*>(smem);
+  uint8_t* scratch = smem + (size_t)d.n * 32;
+  const VerifyView v(d, blockIdx.x);
+  const int lane = threadIdx.x, ell = d.ell;
+  const SlotMap sm(d.L);
+  const uint8_t* pb = v.pb();
+  // the seven scalars of the proof must be canonical, every proof point must have decoded (status != 0: malformed / off the curve / outside the subgroup)
+  Fr r_p, c_fin, d_fin, z_k, z_t, z_u, x_fin;
+  bool ok = load_scalar(pb + v.off_rp(), r_p);
+  ok &= load_scalar(pb + v.off_c(), c_fin);
+  ok &= load_scalar(pb + v.off_c() + 32, d_fin);
+  ok &= load_scalar(pb + v.off_zk(), z_k);
+  ok &= load_scalar(pb + v.off_zk() + 32, z_t);
+  ok &= load_scalar(pb + v.off_zk() + 64, z_u);
+  ok &= load_scalar(pb + v.off_x(), x_fin);
+  const int npp = sm.n_proof_points();
+  int badpt = 0;
+  for (int q = lane; q < npp; q += 64) badpt |= d.status[(size_t)v.p * npp + q];
+  const bool bad = !ok || __any(badpt != 0);
+  const uint8_t* ic = d.inst_comp + (size_t)v.p * 4 * ell * 48;
+  const bool reject = ic[(size_t)2 * ell * 48] == 0xc0;   // curdleproofs.rs:218: the randomiser must not have wiped the ciphertexts
+  const Fr* veca = d.veca + (size_t)v.p * ell;
+  WaveStrobe t;
+  t.load(v.tstate(), lane & 31);
+  t.append_message(LBL("same_perm_step1"), v.P(SL_A), 48, scratch);
+  t.append_message(LBL("same_perm_step1"), d.mcomp + (size_t)v.p * 48, 48, scratch);
+  uint32_t* w = reinterpret_cast<uint32_t*>(buf);
+  for (int i = lane; i < ell; i += 64) {
+    const Fr c = fe_from_mont(veca[i]);
+    CPX_UNROLL for (int j = 0; j < 8; j++) w[8 * i + j] = c.v[j];
+  }
+  if (lane < 8) scratch[8 + lane] = (uint8_t)((uint64_t)ell >> (8 * lane));
+  __syncthreads();
+  t.append_begin(LBL("same_perm_step1"), 8 + 32 * (size_t)ell, scratch);
+  t.absorb(scratch + 8, 8);
+  t.absorb(reinterpret_cast<const uint8_t*>(buf), 32 * (size_t)ell);
+  const Fr alpha_sp = t.challenge_scalar(LBL("same_perm_alpha"), scratch);
+  const Fr beta_sp = t.challenge_scalar(LBL("same_perm_beta"), scratch);
+  __syncthreads();
+  // gprod = prod (a_i + i alpha + beta)
+  for (int i = lane; i < ell; i += 64) buf[i] = fe_add(fe_add(veca[i], fe_mul(fr_from_u32((uint32_t)i), alpha_sp)), beta_sp);
+  __syncthreads();
+  scan_mul(buf, ell);
+  const Fr gprod = buf[ell - 1];
+  t.append_message(LBL("gprod_step1"), v.P(SL_B), 48, scratch);
+  t.append_scalar(LBL("gprod_step1"), gprod, scratch);
+  const Fr alpha_g = t.challenge_scalar(LBL("gprod_alpha"), scratch);
+  t.append_message(LBL("gprod_step2"), v.P(SL_C), 48, scratch);
+  t.append_scalar(LBL("gprod_step2"), r_p, scratch);
+  const Fr beta_g = t.challenge_scalar(LBL("gprod_beta"), scratch);
+  if (lane < 32) t.store(v.tstate());
+  const Fr beta_g_inv = fr_inv_divsteps(beta_g);
+  if (lane == 0) {
+    Fr* sc = v.vsc();
+    sc[VSC_NEG_BETA_G_INV] = fe_neg(beta_g_inv);
+    sc[VSC_ALPHA_G] = alpha_g;
+    sc[VSC_ALPHA_SP] = alpha_sp;
+    sc[VSC_BETA_SP] = beta_sp;
+    sc[VSC_GPROD] = gprod;
+    sc[VSC_BETA_G] = beta_g;
+    sc[VSC_BETA_G_INV] = beta_g_inv;
+    sc[VSC_RP] = r_p;
+    sc[VSC_CFIN] = c_fin;
+    sc[VSC_DFIN] = d_fin;
+    sc[VSC_ZK] = z_k;
+    sc[VSC_ZT] = z_t;
+    sc[VSC_ZU] = z_u;
+    sc[VSC_XFIN] = x_fin;
+    d.flags[v.p] = (bad ? 1u : 0u) | (reject ? 2u : 0u);
+  }
+}
+
+// V2 (after D and A' have been computed and compressed): the rest of the transcript and the scalars of the flattened
+//    accumulated check  sum_i a_i (lhs_i - x_i . V_i) == O  (msm_accumulator.rs:38-68):
+//    inner_product_argument.rs:202-326, same_scalar_argument.rs:112-137, same_multiscalar_argument.rs:153-261,
+//    grand_product_argument.rs:211-246, same_permutation_argument.rs:146-171, curdleproofs.rs:283-297.
+//    scal[p] = [ R | S | T | U (4 ell) | misc: CRS singles, M, every proof point (NM) ],  scal_crs[p] = [ G | Hvec (n) ]
+__global__ __launch_bounds__(64) void k_vs_scalars(const VerifyDev d) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  Fr* buf = reinterpret_cast<Fr*>(smem);                       // [n]
+  Fr* gam = buf + d.n;                                         // [4 L]: gamma_i | gamma_m | their inverses
+  uint8_t* scratch = reinterpret_cast<uint8_t*>(gam + 4 * d.L);   // [64]
+  uint8_t* tail = scratch + 64;                                // [4 * 48]
+  const VerifyView v(d, blockIdx.x);
+  const int lane = threadIdx.x, ell = d.ell, n = d.n, L = d.L;
+  const SlotMap sm(L);
+  const Fr* sc = v.vsc();
+  const Fr alpha_sp = sc[VSC_ALPHA_SP], beta_sp = sc[VSC_BETA_SP], gprod = sc[VSC_GPROD], alpha_g = sc[VSC_ALPHA_G], beta_g = sc[VSC_BETA_G],
+           beta_g_inv = sc[VSC_BETA_G_INV], r_p = sc[VSC_RP], c_fin = sc[VSC_CFIN], d_fin = sc[VSC_DFIN], z_k = sc[VSC_ZK], z_t = sc[VSC_ZT],
+           z_u = sc[VSC_ZU], x_fin = sc[VSC_XFIN];
+  const Fr beta_l = fr_pow_u32(beta_g, (uint32_t)ell), beta_l1 = fe_mul(beta_l, beta_g);
+  const Fr z_ip = fe_sub(fe_add(fe_mul(r_p, beta_l1), fe_mul(gprod, beta_l)), Fr::one());
+  WaveStrobe t;
+  t.load(v.tstate(), lane & 31);
+  t.append_message(LBL("ipa_step1"), v.P(SL_C), 48, scratch);
+  t.append_message(LBL("ipa_step1"), v.slot(sm.D()), 48, scratch);
+  t.append_scalar(LBL("ipa_step1"), z_ip, scratch);
+  t.append_message(LBL("ipa_step1"), v.P(SL_BC), 48, scratch);
+  t.append_message(LBL("ipa_step1"), v.P(SL_BD), 48, scratch);
+  const Fr alpha_i = t.challenge_scalar(LBL("ipa_alpha"), scratch);
+  const Fr beta_i = t.challenge_scalar(LBL("ipa_beta"), scratch);
+  for (int j = 0; j < L; j++) {
+    t.append_message(LBL("ipa_loop"), v.P(sm.LC(j)), 48, scratch);
+    t.append_message(LBL("ipa_loop"), v.P(sm.LD(j)), 48, scratch);
+    t.append_message(LBL("ipa_loop"), v.P(sm.RC(j)), 48, scratch);
+    t.append_message(LBL("ipa_loop"), v.P(sm.RD(j)), 48, scratch);
+    const Fr g = t.challenge_scalar(LBL("ipa_gamma"), scratch);
+    if (lane == 0) gam[j] = g;
+  }
+  {
+    const int sp[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
+    for (int q = 0; q < 10; q++) t.append_message(LBL("sameexp_points"), v.P(sp[q]), 48, scratch);
+  }
+  const Fr alpha_s = t.challenge_scalar(LBL("same_scalar_alpha"), scratch);
+  t.append_message(LBL("same_msm_step1"), v.slot(sm.APRIME()), 48, scratch);
+  t.append_message(LBL("same_msm_step1"), v.P(SL_CMT2), 48, scratch);
+  t.append_message(LBL("same_msm_step1"), v.P(SL_CMU2), 48, scratch);
+  const uint8_t* ic = d.inst_comp + (size_t)v.p * 4 * ell * 48;
+  for (int which = 0; which < 2; which++) {   // vec_T || O O H O and vec_U || O O O H (curdleproofs.rs:262-276)
+    for (int i = lane; i < 4 * 48; i += 64) {
+      const int s = i / 48, b = i % 48;
+      const bool h = s == (which ? 3 : 2);
+      tail[i] = h ? d.crs_h_comp[b] : (b == 0 ? 0xc0 : 0);
+    }
+    if (lane < 8) scratch[8 + lane] = (uint8_t)((uint64_t)n >> (8 * lane));
+    __syncthreads();
+    t.append_begin(LBL("same_msm_step1"), 8 + 48 * (size_t)n, scratch);
+    t.absorb(scratch + 8, 8);
+    t.absorb(ic + (size_t)(2 + which) * ell * 48, 48 * (size_t)ell);
+    t.absorb(tail, 4 * 48);
+    __syncthreads();
+  }
+  t.append_message(LBL("same_msm_step1"), v.P(sm.BA()), 48, scratch);
+  t.append_message(LBL("same_msm_step1"), v.P(sm.BT()), 48, scratch);
+  t.append_message(LBL("same_msm_step1"), v.P(sm.BU()), 48, scratch);
+  const Fr alpha_m = t.challenge_scalar(LBL("same_msm_alpha"), scratch);
+  for (int j = 0; j < L; j++) {
+    const int six[6] = {sm.LA(j), sm.LT(j), sm.LU(j), sm.RA(j), sm.RT(j), sm.RU(j)};
+    for (int q = 0; q < 6; q++) t.append_message(LBL("same_msm_loop"), v.P(six[q]), 48, scratch);
+    const Fr g = t.challenge_scalar(LBL("same_msm_gamma"), scratch);
+    if (lane == 0) gam[L + j] = g;
+  }
+  if (lane < 32) t.store(v.tstate());
+  __syncthreads();
+  // the 2 L challenge inverses, one lane each (ark_ff::batch_inversion of the reference gives the same values)
+  if (lane < 2 * L) gam[2 * L + lane] = fr_inv_divsteps(gam[lane]);
+  __syncthreads();
+  const Fr *gam_i = gam, *gam_m = gam + L, *gam_i_inv = gam + 2 * L, *gam_m_inv = gam + 3 * L;
+  // u_i = beta^-(i+1), i < ell; beta^-(ell+1) on the blinder positions (grand_product_argument.rs:211-219)
+  for (int i = lane; i <= ell; i += 64) buf[i] = beta_g_inv;
+  __syncthreads();
+  scan_mul(buf, ell + 1);
+  const Fr* rnd = v.rnd();
+  const Fr a1 = rnd[0], a2 = rnd[1], a3 = rnd[2], a4 = rnd[3], a5 = rnd[4], a6 = rnd[5], a7 = rnd[6], a8 = rnd[7];
+  const Fr a2c = fe_mul(a2, c_fin), a3d = fe_mul(a3, d_fin), a4x = fe_mul(a4, x_fin), a5x = fe_mul(a5, x_fin), a6x = fe_mul(a6, x_fin);
+  const Fr a1b = fe_mul(a1, beta_sp);
+  const bool bad = d.flags[v.p] & 1u;   // an undecodable proof contributes nothing to a fused batch (it is counted as invalid)
+  const size_t NI = 4 * (size_t)ell, NPT = NI + d.NM;
+  Fr* out = d.scal + (size_t)v.p * NPT;
+  Fr* out_crs = d.scal_crs + (size_t)v.p * n;
+  // verification scalars s_i = prod_{j : bit (L-1-j) of i set} gamma_j  (util.rs:40-64)
+  auto svec = [&](const Fr* g, int i) {
+    Fr r = Fr::one();
+    for (int j = 0; j < L; j++)
+      if ((i >> (L - 1 - j)) & 1) r = fe_mul(r, g[j]);
+    return r;
+  };
+  Fr sm_l2 = Fr::zero(), sm_l3 = Fr::zero();   // s_m[ell + 2], s_m[ell + 3]
+  for (int i = lane; i < n; i += 64) {
+    const Fr s_i = svec(gam_i, i), s_i_inv = svec(gam_i_inv, i), s_m = svec(gam_m, i);
+    const Fr u = buf[i < ell ? i : ell];
+    // (1) CRS part over G | Hvec
+    Fr k1 = fe_add(fe_mul(a2c, s_i), fe_mul(a3d, fe_mul(s_i_inv, u)));
+    if (i < ell) k1 = fe_add(k1, a1b);
+    if (i < ell + 2) k1 = fe_add(k1, fe_mul(a4x, s_m));   // G_b = G | Hvec[0..2) | G_t | G_u
+    out_crs[i] = bad ? Fr::zero() : fe_neg(k1);
+    // (2) instance part over R | S | T | U
+    if (i < ell) {
+      const Fr va = d.veca[(size_t)v.p * ell + i];
+      out[i] = bad ? Fr::zero() : fe_neg(fe_mul(a7, va));
+      out[ell + i] = bad ? Fr::zero() : fe_neg(fe_mul(a8, va));
+      out[2 * ell + i] = bad ? Fr::zero() : fe_neg(fe_mul(a5x, s_m));
+      out[3 * ell + i] = bad ? Fr::zero() : fe_neg(fe_mul(a6x, s_m));
+    }
+    if (i == ell + 2) sm_l2 = s_m;
+    if (i == ell + 3) sm_l3 = s_m;
+  }
+  // s_m at the two positions the misc part needs: owned by the lanes (ell + 2) % 64 and (ell + 3) % 64
+  {
+    Fr t2 = sm_l2, t3 = sm_l3;
+    CPX_UNROLL for (int j = 0; j < 8; j++) {
+      t2.v[j] = (uint32_t)__shfl((int)sm_l2.v[j], (ell + 2) & 63, 64);
+      t3.v[j] = (uint32_t)__shfl((int)sm_l3.v[j], (ell + 3) & 63, 64);
+    }
+    sm_l2 = t2;
+    sm_l3 = t3;
+  }
+  // (3) misc part: singles, M, proof points.  Slot s sits at misc index s (SL_A == SL_M + 1).
+  Fr w1, w2, w3, w4;   // weights of the four SameScalar equalities (same_scalar_argument.rs:127-137; include/cpx.h)
+  if (d.rand_stride >= 12) {
+    w1 = rnd[8];
+    w2 = rnd[9];
+    w3 = rnd[10];
+    w4 = rnd[11];
+  } else {
+    w1 = fe_mul(a1, a2);
+    w2 = fe_mul(a3, a4);
+    w3 = fe_mul(a5, a6);
+    w4 = fe_mul(a7, a8);
+  }
+  const Fr a4am = fe_mul(a4, alpha_m), a5am = fe_mul(a5, alpha_m), a6am = fe_mul(a6, alpha_m), a3ai = fe_mul(a3, alpha_i);
+  for (int s = lane; s < d.NM; s += 64) {
+    Fr k = Fr::zero();
+    if (s == SL_H) {
+      k = fe_sub(fe_sub(fe_sub(fe_mul(a2, fe_mul(fe_mul(fe_mul(alpha_i, alpha_i), z_ip), beta_i)), fe_mul(fe_mul(a2c, d_fin), beta_i)), fe_mul(a5x, sm_l2)),
+                 fe_mul(a6x, sm_l3));
+      k = fe_sub(fe_sub(k, fe_mul(w2, z_t)), fe_mul(w4, z_u));
+    } else if (s == SL_GT) {
+      k = fe_neg(fe_add(fe_mul(a4x, sm_l2), fe_mul(w1, z_t)));
+    } else if (s == SL_GU) {
+      k = fe_neg(fe_add(fe_mul(a4x, sm_l3), fe_mul(w3, z_u)));
+    } else if (s == SL_GSUM) {
+      k = fe_neg(fe_mul(a3ai, beta_g_inv));
+    } else if (s == SL_HSUM) {
+      k = fe_mul(a3ai, alpha_g);
+    } else if (s == SL_M) {
+      k = fe_neg(fe_mul(a1, alpha_sp));
+    } else if (s == SL_A) {
+      k = fe_sub(a4am, a1);
+    } else if (s == SL_CMT1) {
+      k = fe_add(a4am, fe_mul(w1, alpha_s));
+    } else if (s == SL_CMT2) {
+      k = fe_add(a5am, fe_mul(w2, alpha_s));
+    } else if (s == SL_CMU1) {
+      k = fe_add(a4am, fe_mul(w3, alpha_s));
+    } else if (s == SL_CMU2) {
+      k = fe_add(a6am, fe_mul(w4, alpha_s));
+    } else if (s == SL_R) {
+      k = fe_sub(a7, fe_mul(w2, z_k));
+    } else if (s == SL_S) {
+      k = fe_sub(a8, fe_mul(w4, z_k));
+    } else if (s == SL_B) {
+      k = fe_add(a1, a3ai);
+    } else if (s == SL_C) {
+      k = fe_mul(a2, alpha_i);
+    } else if (s == SL_BC) {
+      k = a2;
+    } else if (s == SL_BD) {
+      k = a3;
+    } else if (s < sm.CMA1()) {   // IPA cross terms: L_C | R_C | L_D | R_D, L each
+      const int q = s - SL_IPA0, blk = q / L, j = q % L;
+      const Fr g = (blk & 1) ? gam_i_inv[j] : gam_i[j];
+      k = fe_mul(blk < 2 ? a2 : a3, g);
+    } else if (s == sm.CMA1()) {
+      k = w1;
+    } else if (s == sm.CMA2()) {
+      k = w2;
+    } else if (s == sm.CMB1()) {
+      k = w3;
+    } else if (s == sm.CMB2()) {
+      k = w4;
+    } else if (s == sm.BA()) {
+      k = a4;
+    } else if (s == sm.BT()) {
+      k = a5;
+    } else if (s == sm.BU()) {
+      k = a6;
+    } else {   // SameMSM cross terms: L_A | L_T | L_U | R_A | R_T | R_U, L each
+      const int q = s - sm.LA(0), blk = q / L, j = q % L;
+      const Fr g = blk < 3 ? gam_m[j] : gam_m_inv[j];
+      const int col = blk % 3;
+      k = fe_mul(col == 0 ? a4 : (col == 1 ? a5 : a6), g);
+    }
+    out[NI + s] = bad ? Fr::zero() : k;
+  }
+}
+
+// fused batch: sum over the proofs of the CRS scalars (the shared bases G | Hvec merge in Fr; msm_accumulator.rs:47-51)
+__global__ __launch_bounds__(64) void k_vs_crs_sum(const Fr* __restrict__ scal_crs, int B, int n, Fr* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Fr t = Fr::zero();
+  for (int p = 0; p < B; p++) t = fe_add(t, scal_crs[(size_t)p * n + i]);
+  out[i] = t;
+}
+
 // ------------------------------------------------------------------ launchers
 static inline size_t lds_vec(const ProveDev& d) { return (size_t)d.n * 32 + 64; }
 #define PS_LAUNCH(kern, B, lds, s, ...) hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, s, __VA_ARGS__)
@@ -416,5 +750,10 @@ void launch_ps_ipa_round(const ProveDev& d, int B, int j, hipStream_t s) { PS_LA
 void launch_ps_smsm_setup(const ProveDev& d, int B, hipStream_t s) { PS_LAUNCH(k_ps_smsm_setup, B, 64 + 4 * 48, s, d); }
 void launch_ps_smsm_round(const ProveDev& d, int B, int j, hipStream_t s) { PS_LAUNCH(k_ps_smsm_round, B, 64, s, d, j); }
 void launch_ps_serialize(const ProveDev& d, int B, hipStream_t s) { PS_LAUNCH(k_ps_serialize, B, 0, s, d); }
+void launch_vs_prefix(const VerifyDev& d, int B, hipStream_t s) { PS_LAUNCH(k_vs_prefix, B, (size_t)d.n * 32 + 64, s, d); }
+void launch_vs_scalars(const VerifyDev& d, int B, hipStream_t s) { PS_LAUNCH(k_vs_scalars, B, (size_t)d.n * 32 + (size_t)4 * d.L * 32 + 64 + 4 * 48, s, d); }
+void launch_vs_crs_sum(const Fr* d_scal_crs, int B, int n, Fr* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_vs_crs_sum, dim3((n + 63) / 64), dim3(64), 0, s, d_scal_crs, B, n, d_out);
+}
 
 }  // namespace cpx

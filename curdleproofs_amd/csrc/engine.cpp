@@ -236,30 +236,22 @@ void Engine::wait_stream() {
   if (had) baton_acquire();
 }
 
-// Transcript prefix of every loaded proof on the side stream (after the main stream has produced d_bytes_ / d_mcomp_):
-// k_transcript_step1, then the copies the host needs (state, vec_a, compressed instance vectors, compressed M).
-// Small batches hash on the host instead (device_prefix(B) false): a lone transcript is latency-bound on the GPU
-// (~4 us per permutation) while the host has idle cores (~0.25 us per permutation).
+// Batches of at least CPX_DEVICE_MIN_BATCH proofs (default 32) run the whole protocol on the GPU (engine_device.cpp).  Smaller
+// batches are driven from the host: a lone transcript is latency-bound on a GPU wave (~4 us per Keccak permutation against
+// ~0.25 us on a host core, ~1000 permutations per proof), and the host has idle cores.  In the host-driven mode the
+// transcript prefix of every loaded proof is hashed on the host as well.
 bool Engine::device_prefix(size_t B) const {
   static const size_t min_batch = [] {
-    const char* e = getenv("CPX_DEVICE_TRANSCRIPT_MIN_BATCH");
+    const char* e = getenv("CPX_DEVICE_MIN_BATCH");
+    if (!e) e = getenv("CPX_DEVICE_TRANSCRIPT_MIN_BATCH");   // former name
     return e ? (size_t)atol(e) : (size_t)32;
   }();
   return B >= min_batch;
 }
 void Engine::transcript_prefix_async(size_t B) {
-  d_tstate_.ensure(B * 27);
-  d_veca_.ensure(B * ell_);
-  h_tstate_.ensure(B * 27);
-  h_veca_.ensure(B * ell_);
   if (!side_.ev2) CPX_HIP(hipEventCreateWithFlags(&side_.ev2, hipEventDisableTiming));
   CPX_HIP(hipEventRecord(side_.ev2, stream_));
   CPX_HIP(hipStreamWaitEvent(side_.stream, side_.ev2, 0));
-  if (device_prefix(B)) {
-    launch_transcript_step1(d_bytes_.p, d_mcomp_.p, (int)B, (int)ell_, d_tstate_.p, d_veca_.p, side_.stream);
-    CPX_HIP(hipMemcpyAsync(h_tstate_.p, d_tstate_.p, B * 27 * sizeof(uint64_t), hipMemcpyDeviceToHost, side_.stream));
-    CPX_HIP(hipMemcpyAsync(h_veca_.p, d_veca_.p, B * ell_ * sizeof(Fr), hipMemcpyDeviceToHost, side_.stream));
-  }
   CPX_HIP(hipMemcpyAsync(h_inst_comp_.p, d_bytes_.p, B * 4 * ell_ * 48, hipMemcpyDeviceToHost, side_.stream));
   CPX_HIP(hipMemcpyAsync(h_mcomp_.p, d_mcomp_.p, B * 48, hipMemcpyDeviceToHost, side_.stream));
   CPX_HIP(hipEventRecord(side_.ev, side_.stream));
@@ -581,7 +573,7 @@ void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
     if (want_fix == 16) {   // 15 GB at ell = 252, 60 GB at ell = 1020: fall back to the radix-2^8 table (0.1 GB / 0.4 GB) when HBM is short
       size_t free_b = 0, total_b = 0;
       CPX_HIP(hipMemGetInfo(&free_b, &total_b));
-      const size_t need = (size_t)16 * ((size_t)1 << 15) * NC * sizeof(TAff) + (size_t)(16 * NC + 63) * 256 * sizeof(TblTmp);
+      const size_t need = (size_t)16 * ((size_t)1 << 15) * NC * sizeof(TFix) + (size_t)(16 * NC + 63) * 256 * sizeof(TblTmp);
       bool have = false;   // an existing shared table costs nothing
       for (auto& w : registry)
         if (auto sp = w.lock()) have |= sp->device == device_ && sp->fix_bits == 16 && sp->key.size() == (ell + 7) * sizeof(Aff) && !memcmp(sp->key.data(), points, sp->key.size());
@@ -937,23 +929,18 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     for (size_t p = 0; p < B; p++) dst[p] = (uint32_t)(p * NP + O_M);
     CPX_HIP(hipMemcpyAsync(d_dst_.p, dst, B * 4, hipMemcpyHostToDevice, stream_));
     launch_finalize(d_Mjac_.p, (int)B, d_psrc_.p, d_dst_.p, d_mcomp_.p, stream_);
-    transcript_prefix_async(B);   // side stream: k_transcript_step1 + copies of its outputs and of the compressed bytes
+    transcript_prefix_async(B);   // side stream: copies of the compressed bytes for the host's transcripts
     tick("k_table_build", 0, (double)(B * NP));
     launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
     tock();
     const uint8_t* mcomp = h_mcomp_.p;
-    const bool dev_prefix = device_prefix(B);
     wait_side();
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       s.rnd = rand + p * nrand * 32;
       s.comp.assign((size_t)NS * 48, 0);
       memcpy(&s.comp[SL_M * 48], &mcomp[p * 48], 48);
-      if (dev_prefix) {   // instance + M absorbed, vec_a drawn: hashed on the device (k_transcript_step1)
-        s.tr.load_state(h_tstate_.p + p * 27);
-        s.vec_a.resize(ell);
-        memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
-      } else {
+      {   // curdleproofs.rs:78-83
         const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
         for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
         s.tr.append_point_bytes("curdleproofs_step1", &s.comp[SL_M * 48]);
@@ -1543,7 +1530,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     d_mcomp_.ensure(B * 48);
     CPX_HIP(hipMemcpyAsync(d_dst_.p, mdst, B * 4, hipMemcpyHostToDevice, stream_));
     launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_mcomp_.p, stream_);
-    transcript_prefix_async(B);   // side stream: transcript prefix + copies of the compressed bytes
+    transcript_prefix_async(B);   // side stream: copies of the compressed bytes for the host's transcripts
     const uint8_t* status = h_status_.p;
     CPX_HIP(hipMemcpyAsync(h_status_.p, d_status_.p, npts, hipMemcpyDeviceToHost, stream_));
     wait_stream();
@@ -1557,7 +1544,6 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
   std::vector<uint8_t> comp;
 
   // -- V1a: transcript up to the grand-product beta
-  const bool dev_prefix = device_prefix(B);
   parallel_for(B, [&](size_t p) {
     VState& s = st[p];
     s.pb = proofs + p * psz;
@@ -1570,15 +1556,9 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     const uint8_t* ic = &inst_comp[p * 4 * ell * 48];
     // curdleproofs.rs:218: the randomiser must not have wiped the ciphertexts
     if (ic[2 * ell * 48] == ID0) s.reject = true;
-    if (dev_prefix) {   // instance + M absorbed, vec_a drawn: hashed on the device (k_transcript_step1)
-      s.tr.load_state(h_tstate_.p + p * 27);
-      s.vec_a.resize(ell);
-      memcpy(s.vec_a.data(), h_veca_.p + p * ell, ell * sizeof(Fr));
-    } else {
-      for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);
-      s.tr.append_point_bytes("curdleproofs_step1", &mcomp[p * 48]);
-      s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
-    }
+    for (int v = 0; v < 4; v++) s.tr.append_point_vec_bytes("curdleproofs_step1", ic + v * ell * 48, ell);   // curdleproofs.rs:213-222
+    s.tr.append_point_bytes("curdleproofs_step1", &mcomp[p * 48]);
+    s.vec_a = s.tr.get_and_append_challenges("curdleproofs_vec_a", ell);
     // same_permutation_argument.rs:131-145
     s.tr.append_point_bytes("same_perm_step1", P(SL_A));
     s.tr.append_point_bytes("same_perm_step1", &mcomp[p * 48]);

@@ -284,7 +284,7 @@ class Engine {
   void wait_stream();
   void wait_side();                          // blocks on the side stream's event (side_.ev)
   void transcript_prefix_async(size_t B);
-  bool device_prefix(size_t B) const;         // hash the transcript prefix on the GPU (large batches) or on the host
+  bool device_prefix(size_t B) const;         // run the whole protocol on the GPU (batches >= CPX_DEVICE_MIN_BATCH) or drive it from the host
   // per-device host baton between engines (engine.cpp)
   void baton_register(int delta);
   void baton_acquire();
@@ -329,11 +329,11 @@ class Engine {
     int device = 0, fix_bits = 0;
     std::vector<uint8_t> key;   // the CRS points the tables were built from
     DevBuf<TAff> ctab;         // shifted copies [copies][n+3] : G | Hvec | H | G_t | G_u   (table representation)
-    DevBuf<TAff> fixtab;       // multiples [256/c][2^(c-1)][n+3]
+    DevBuf<TFix> fixtab;       // multiples [256/c][2^(c-1)][n+5], one 128-byte line per entry
   };
   std::shared_ptr<CrsTables> crs_tab_;
   const TAff* ctab() const { return crs_tab_ ? crs_tab_->ctab.p : nullptr; }
-  const TAff* fixtab() const { return crs_tab_ ? crs_tab_->fixtab.p : nullptr; }
+  const TFix* fixtab() const { return crs_tab_ ? crs_tab_->fixtab.p : nullptr; }
   DevBuf<TAff> d_ptab_;      // per-proof tables [B][copies][NP]
   DevBuf<uint32_t> d_raw_, d_rawslot_;   // raw lane accumulators of k_msm_tblw / k_msm_fix and their partial-sum slots
   DevBuf<TJac> d_rawmid_;                // group sums between the two reduction launches
@@ -372,8 +372,6 @@ class Engine {
   DevBuf<uint8_t> d_mcomp_;                 // compressed M of every proof
   DevBuf<uint64_t> d_tstate_;               // transcript states after the prefix [B][27]
   DevBuf<Fr> d_veca_;                       // vec_a [B][ell]
-  PinBuf<uint64_t> h_tstate_;
-  PinBuf<Fr> h_veca_;
   DevBuf<uint8_t> d_vin_;
   DevBuf<uint32_t> d_vdst_;
   std::map<std::vector<uint32_t>, uint32_t*> idx_cache_;

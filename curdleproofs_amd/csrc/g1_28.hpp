@@ -241,6 +241,21 @@ namespace cpx {
 
 typedef F28 TF;
 typedef Aff28 TAff;
+// An entry of the fixed-base table of multiples (k_msm_fix gathers them at random from a 15 GB table): padded to one
+// 128-byte line, so that a gather touches ONE cache line / HBM burst instead of straddling two (112-byte entries at
+// 112-byte strides cross a 128-byte boundary 7 times out of 8).  -DCPX_FIXTAB_PAD=0 selects the dense layout (A/B runs).
+#ifndef CPX_FIXTAB_PAD
+#define CPX_FIXTAB_PAD 1
+#endif
+#if CPX_FIXTAB_PAD
+struct alignas(128) TFix {
+  Aff28 a;
+};
+#else
+struct TFix {
+  Aff28 a;
+};
+#endif
 typedef Jac28 TJac;
 CPX_HD TF t_one() { return f28_one(); }
 CPX_HD TF t_mul(const TF& a, const TF& b) { return f28_mul(a, b); }

@@ -252,12 +252,6 @@ using cpx::keccak_f1600;
 class Transcript {   // merlin::Transcript specialised to the operations the protocol performs
  public:
   explicit Transcript(const char* label) { s_.init(label); }
-  // continue a transcript whose prefix was hashed on the device (k_transcript_step1): 25 lanes + pos + pos_begin
-  void load_state(const uint64_t* words27) {
-    memcpy(s_.st, words27, 200);
-    s_.pos = (uint32_t)words27[25];
-    s_.pos_begin = (uint32_t)words27[26];
-  }
   void append_message(const char* label, const uint8_t* m, size_t len) { s_.append_message(label, m, len); }
   void challenge_bytes(const char* label, uint8_t* out, size_t len) { s_.challenge_bytes(label, out, len); }
   // --- CurdleproofsTranscript (transcript.rs:28-60) ---

@@ -561,7 +561,7 @@ template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint3
 // One wave = FIX_WPW windows x (64 / FIX_WPW) point slices of one task.  16 windows per wave (a whole radix-2^16
 // task) keeps the fixed 6-step tree reduction small against the per-lane additions (n/4 per lane); 8 windows
 // per wave double the number of waves when the launch would not fill the GPU otherwise.
-template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TAff* __restrict__ tab, int nc,
+template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TFix* __restrict__ tab, int nc,
                                                                      uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot) {
   constexpr int W = 256 / CB, WG = W / FIX_WPW;    // waves per task
   constexpr int LPW = 64 / FIX_WPW;                // lanes (point slices) per window
@@ -573,7 +573,7 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
   const int lane = threadIdx.x;
   const int wl = lane / LPW, sl = lane % LPW;
   const uint32_t w = (uint32_t)(wg * FIX_WPW + wl);
-  const TAff* wtab = tab + (size_t)w * M * nc;
+  const TFix* wtab = tab + (size_t)w * M * nc;
   TAcc xacc = TAcc::identity();
 
   for (uint32_t base = 0; base < task.n; base += FIX_CHUNK) {
@@ -591,7 +591,7 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
     auto fetch = [&](int i, int& d) {
       d = i < m ? row[i] : 0;
       const uint32_t g = base + i;
-      return d ? wtab[(size_t)((d < 0 ? -d : d) - 1) * nc + task.off + (task.idx ? task.idx[g] : g)] : TAff::identity();
+      return d ? wtab[(size_t)((d < 0 ? -d : d) - 1) * nc + task.off + (task.idx ? task.idx[g] : g)].a : TAff::identity();
     };
     int dn;
     TAff pn = fetch(sl, dn);
@@ -609,7 +609,7 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
 
 // Table of multiples from the shifted copies: thread per (window, base) walks m = 1..M with mixed additions and
 // normalises `chunk` entries at a time (own Montgomery trick + one inversion per work-group).
-template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* __restrict__ shift, int nc, TAff* __restrict__ tab, TblTmp* __restrict__ tmp, int chunk) {
+template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* __restrict__ shift, int nc, TFix* __restrict__ tab, TblTmp* __restrict__ tmp, int chunk) {
   constexpr int W = 256 / CB;
   constexpr uint32_t M = 1u << (CB - 1);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -620,7 +620,7 @@ template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* 
   const TAff S = live ? shift[(size_t)w * nc + i] : TAff::identity();
   const bool inf = S.is_identity();
   TblTmp* my = tmp + (size_t)g * chunk;
-  TAff* out = tab + (size_t)w * M * nc + i;
+  TFix* out = tab + (size_t)w * M * nc + i;
   TJac acc = TJac::identity();
   for (uint32_t m0 = 0; m0 < M; m0 += chunk) {
     TF prod = t_one();
@@ -642,7 +642,7 @@ template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* 
           inv = t_mul(inv, p.z);
           a = t_to_affine(p, zinv);
         }
-        out[(size_t)(m0 + j) * nc] = a;
+        out[(size_t)(m0 + j) * nc].a = a;
       }
     }
   }
@@ -1266,7 +1266,7 @@ int msm_fix_windows_per_wave(int ntasks, int cbits) {
   }
   return 8;
 }
-void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
+void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TFix* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
   if (ntasks <= 0) return;
   const size_t lds = 16 * FIX_CHUNK * 2;   // digit rows
   const dim3 grid(ntasks * (256 / cbits / wpw)), block(64);
@@ -1277,7 +1277,7 @@ void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TAff* d_fix_tab, i
   else if (wpw == 16) CPX_LAUNCH((k_msm_fix<8, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
   else CPX_LAUNCH((k_msm_fix<8, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
 }
-void launch_fix_build(const TAff* d_shift, int nc, int cbits, TAff* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
+void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
   const int W = 256 / cbits, total = W * nc;
   const size_t lds = 2 * 64 * sizeof(TF);
   if (cbits == 16) CPX_LAUNCH(k_fix_build<16>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);

@@ -513,20 +513,22 @@ def test_fused_batch_verifier_many_points(ctx, orc, ell, nproofs):
 THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAVE_MAX": "0", "CPX_FINALIZE_WAVE_MAX": "0"}
 
 
-@pytest.mark.parametrize("env", [{"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_TRANSCRIPT_MIN_BATCH": "1"}, THROUGHPUT_ENV,
-                                 dict(THROUGHPUT_ENV, CPX_DEVICE_TRANSCRIPT_MIN_BATCH="1")],
-                         ids=["fix8", "device_transcript", "throughput_kernels", "throughput_kernels_device_transcript"])
+@pytest.mark.parametrize("env", [{"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_MIN_BATCH": "1"}, {"CPX_DEVICE_MIN_BATCH": "1000000"}, THROUGHPUT_ENV,
+                                 dict(THROUGHPUT_ENV, CPX_DEVICE_MIN_BATCH="1")],
+                         ids=["fix8", "device_resident", "host_driven", "throughput_kernels", "throughput_kernels_device_resident"])
 def test_engine_variants_stay_bit_exact(env):
-    # the 8-bit fixed-base table, the device-side transcript (normally used from 32 proofs per batch on) and the
-    # throughput instantiations of the MSM / reduction / finalisation kernels are alternative engine configurations;
-    # all must reproduce the reference KAT (whisk.rs:416-456), the oracle's bytes at ell = 252 and the oracle's verdicts
+    # the 8-bit fixed-base table, the device-resident protocol (step kernels of protocol.hip; normally used from 32 proofs per
+    # batch on) forced on single proofs, the host-driven protocol forced on a batch of 40, and the throughput instantiations
+    # of the MSM / reduction / finalisation kernels are alternative engine configurations; all must reproduce the reference
+    # KAT (whisk.rs:416-456), the oracle's bytes at ell = 28 / 252 and the oracle's verdicts
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
                         "test_prove_matches_reference_kat_ell124 or test_verify_rejects_mutated_instances or test_fused_batch_verifier_config5 "
-                        "or test_prove_verify_ell252_batch or test_same_scalar_relations_are_checked"],
+                        "or test_prove_verify_ell252_batch or test_same_scalar_relations_are_checked or test_prove_verify_batch40_ell28 "
+                        "or test_verify_rejects_corrupted_proof_bytes"],
                        env=dict(os.environ, **env), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "7 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def _proof_offsets(ell):

@@ -78,6 +78,73 @@ def cpu_baseline(ell, data, gpu_proof0, budget_s=12.0):
                 prove_s=tp / reps, verify_s=tv / reps, accepted=bool(ok), gpu_proof_bit_exact=bool(parity))
 
 
+def effective_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container can see 256
+    logical CPUs and be throttled to a handful)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+def cpu_baseline_all_cores(ell, data, budget_s=10.0):
+    """SURVEY 8d (ii): the CPU oracle on every host core at once — one independent CurdleproofsProof::new + verify per thread
+    (the embarrassingly parallel form of BASELINE configs[3]; the oracle is a C library behind ctypes, so Python threads run it in
+    parallel).  Returns proofs/s over all threads."""
+    import threading
+    from tests.oracle_lib import Oracle
+    import curdleproofs_amd as cpx
+    orc = Oracle()
+    n = ell + 4
+    AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
+    inst = dict(ell=ell, vec_R=data["vec_R"][:ell * AFF], vec_S=data["vec_S"][:ell * AFF], vec_T=data["vec_T"][:ell * AFF],
+                vec_U=data["vec_U"][:ell * AFF], M=data["M"][:JAC], permutation=data["perms"][:ell], k=data["k"][:FR],
+                vec_m_blinders=data["mbl"][:4 * FR], prover_rand=data["prand"][:(3 * n + 9) * FR], verifier_rand=data["vrand"][:8 * FR])
+    cores = effective_cores()
+    ok, tp, tv = orc.time_prove_verify(inst, data["crs"], 1)
+    reps = max(1, int(budget_s / max(tp + tv, 1e-3) / 1.5))
+    done = [0] * cores
+
+    def work(t):
+        ok_t, _, _ = orc.time_prove_verify(inst, data["crs"], reps)
+        done[t] = reps if ok_t else 0
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return dict(value=sum(done) / dt, unit="proofs/s", cores=cores, logical_cpus=os.cpu_count(), kind="port", cpu_model=model,
+                sample="%d threads x %d x (CurdleproofsProof::new + verify) of instance 0 at ell=%d, oracle/ (one independent proof per thread), %.1f s wall"
+                       % (cores, reps, ell, dt))
+
+
 def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, red_dev="cuda"):
     """BASELINE config 5: batched verifier.  Proofs are produced once (untimed); a step = every context's fused
     verification of its share (one accumulated MSM per context), the per-GPU partial sums added on the GPU, one
@@ -178,8 +245,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per engine context (0 = cores / (ranks x contexts), clamped to [2, 24])")
     ap.add_argument("--synth-cache", default="", help="pickle file for the synthetic batch (created if missing): keeps profiled runs free of setup kernels")
-    ap.add_argument("--ctxs", type=int, default=4, help="engine contexts (HIP streams + host threads) per GPU; the batch is split over them so that "
-                    "one context's Fiat-Shamir / scalar work on the host overlaps the other's kernels")
+    ap.add_argument("--ctxs", type=int, default=2, help="engine contexts (HIP streams, one host thread each) per GPU; the batch is split over them: the "
+                    "protocol is device-resident, two streams let one context's latency-bound kernels (reductions, finalisation, step "
+                    "kernels) run beside the other's MSM waves")
+    ap.add_argument("--no-extra-shapes", action="store_true", help="skip the extra keys: throughput at BASELINE's literal batch shapes (128 / 1024 proofs per "
+                    "GPU), ell=1020 throughput and the all-cores CPU baseline")
     args = ap.parse_args()
 
     # --gpus N without a launcher around us: start the N ranks ourselves (one process per GPU, the same command line the
@@ -240,7 +310,7 @@ def main():
     assert B % K == 0, "--batch must be a multiple of --ctxs"
     ctxs = [cpx.Context(local_rank) for _ in range(K)]          # raises without a GPU: no CPU fallback
     # host worker threads per context: the cores of the node divided over ranks x contexts (all ranks share one node)
-    host_threads = args.host_threads or max(2, min(24, (os.cpu_count() or 64) // (world * K)))
+    host_threads = args.host_threads or max(2, min(24, effective_cores() // (world * K)))
     for c in ctxs:
         c.set_host_threads(host_threads)
     ctx = ctxs[0]
@@ -435,9 +505,50 @@ def main():
             tv.append(t2 - t1)
         out["single_proof"] = dict(prove_ms=1e3 * min(tp), verify_ms=1e3 * min(tv), accepted=v1 == [cpx.CPX_OK],
                                    note="BASELINE configs[1] as a latency figure: one ell=%d proof alone on the GPU (best of 4)" % ell)
+        psz_bench = c0.proof_size   # (context 0 takes another CRS below)
+        if not args.no_extra_shapes:
+            # BASELINE configs[3] at its literal shapes: 1024 proofs total = 128 per GPU on 8 GPUs; and 1024 on one GPU.  One context, proofs of the
+            # bench batch; steady-state prove + verify passes (not the headline: smaller batches fill the GPU less)
+            shapes = {}
+            for nb in (128, 1024):
+                if nb > B:
+                    continue
+                c0.load_batch(data["vec_R"][:nb * ell * AFF], data["vec_S"][:nb * ell * AFF], data["vec_T"][:nb * ell * AFF], data["vec_U"][:nb * ell * AFF],
+                              data["M"][:nb * JAC])
+                a_ = [c0.marshal(x) for x in (data["perms"][:nb * ell], data["k"][:nb * FR], data["mbl"][:nb * 4 * FR], data["prand"][:nb * (3 * n_ + 9) * FR],
+                                              data["vrand"][:nb * 8 * FR])]
+                reps, okall = 0, True
+                t0 = time.perf_counter()
+                while reps < 3 or (time.perf_counter() - t0 < 1.0 and reps < 50):
+                    pr_ = c0.prove_batch(a_[0], a_[1], a_[2], a_[3], raw=True)
+                    okall &= all(v == cpx.CPX_OK for v in c0.verify_batch(pr_, a_[4]))
+                    reps += 1
+                dt_ = time.perf_counter() - t0
+                shapes["batch_%d_per_gpu" % nb] = dict(value=nb * reps / dt_, unit="proofs/s", ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall))
+            out["baseline_shapes"] = dict(note="BASELINE configs[3] (1024 independent ell=%d proofs) at its literal shapes, one engine context: 128 proofs per GPU "
+                                               "(the per-GPU share on 8 GPUs) and 1024 proofs on one GPU" % ell, **shapes)
+            if ell == 252:   # BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
+                try:
+                    e3, b3 = 1020, 256
+                    d3 = synth_batch(c0, e3, b3, seed=4321)
+                    c0.load_batch(d3["vec_R"], d3["vec_S"], d3["vec_T"], d3["vec_U"], d3["M"])
+                    a3 = [c0.marshal(d3[k_]) for k_ in ("perms", "k", "mbl", "prand", "vrand")]
+                    reps, okall = 0, True
+                    pr_ = c0.prove_batch(a3[0], a3[1], a3[2], a3[3], raw=True)   # warm-up (buffers, plans)
+                    t0 = time.perf_counter()
+                    while reps < 2 or (time.perf_counter() - t0 < 2.0 and reps < 20):
+                        pr_ = c0.prove_batch(a3[0], a3[1], a3[2], a3[3], raw=True)
+                        okall &= all(v == cpx.CPX_OK for v in c0.verify_batch(pr_, a3[4]))
+                        reps += 1
+                    dt_ = time.perf_counter() - t0
+                    out["ell_1020"] = dict(value=b3 * reps / dt_, unit="proofs/s", batch=b3, ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall),
+                                           note="BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput: %d proofs per pass, one engine context" % b3)
+                except Exception as e:   # e.g. not enough free HBM for the ell = 1020 fixed-base table beside the bench's buffers
+                    out["ell_1020"] = dict(value=None, error=repr(e))
         if not args.no_cpu_baseline:
-            psz = ctxs[0].proof_size
-            out["cpu_baseline"] = cpu_baseline(ell, data, bytes(proofs[0])[:psz])
+            out["cpu_baseline"] = cpu_baseline(ell, data, bytes(proofs[0])[:psz_bench])
+            if not args.no_extra_shapes:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ell, data)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

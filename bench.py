@@ -440,7 +440,8 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs)
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_counters.json")) as f:
+            import glob
+            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.json")))[-1]) as f:   # the newest round's PMC passes
                 hc = json.load(f).get("cpx::" + dom)   # per instantiation, as rocprofv3 names it
             if hc and hc["batch_per_gpu"] == B and hc.get("engine_contexts_per_gpu", 1) == K:
                 # counters are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)
@@ -506,7 +507,7 @@ def main():
         out["single_proof"] = dict(prove_ms=1e3 * min(tp), verify_ms=1e3 * min(tv), accepted=v1 == [cpx.CPX_OK],
                                    note="BASELINE configs[1] as a latency figure: one ell=%d proof alone on the GPU (best of 4)" % ell)
         psz_bench = c0.proof_size   # (context 0 takes another CRS below)
-        if not args.no_extra_shapes:
+        if not args.no_extra_shapes and world == 1:   # (N > 1: the other ranks would idle at the final barrier meanwhile)
             # BASELINE configs[3] at its literal shapes: 1024 proofs total = 128 per GPU on 8 GPUs; and 1024 on one GPU.  One context, proofs of the
             # bench batch; steady-state prove + verify passes (not the headline: smaller batches fill the GPU less)
             shapes = {}
@@ -545,7 +546,7 @@ def main():
                                            note="BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput: %d proofs per pass, one engine context" % b3)
                 except Exception as e:   # e.g. not enough free HBM for the ell = 1020 fixed-base table beside the bench's buffers
                     out["ell_1020"] = dict(value=None, error=repr(e))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ell, data, bytes(proofs[0])[:psz_bench])
             if not args.no_extra_shapes:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ell, data)

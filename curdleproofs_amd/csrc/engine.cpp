@@ -46,6 +46,9 @@ Engine::~Engine() {
   for (auto p : idx_allocs_) (void)hipFree(p);
   if (side_.ev) (void)hipEventDestroy(side_.ev);
   if (side_.ev2) (void)hipEventDestroy(side_.ev2);
+  if (ev_block_) (void)hipEventDestroy(ev_block_);
+  for (hipEvent_t e : {dprove_.ev_a, dprove_.ev_b, dprove_.ev_c, dprove_.ev_d, dverify_.ev_a, dverify_.ev_b})
+    if (e) (void)hipEventDestroy(e);
   if (side_.stream) (void)hipStreamDestroy(side_.stream);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -248,6 +251,15 @@ bool Engine::device_prefix(size_t B) const {
   }();
   return B >= min_batch;
 }
+// hipStreamSynchronize spins on a host core; an event created with hipEventBlockingSync puts the thread to sleep instead.  With
+// one thread per engine context and per rank, and hosts that give a container a small CPU quota, that matters.
+void Engine::wait_stream_blocking() {
+  if (!ev_block_) CPX_HIP(hipEventCreateWithFlags(&ev_block_, hipEventBlockingSync | hipEventDisableTiming));
+  CPX_HIP(hipEventRecord(ev_block_, stream_));
+  HostSpan w(this, "host_wait_device");
+  CPX_HIP(hipEventSynchronize(ev_block_));
+}
+
 void Engine::transcript_prefix_async(size_t B) {
   if (!side_.ev2) CPX_HIP(hipEventCreateWithFlags(&side_.ev2, hipEventDisableTiming));
   CPX_HIP(hipEventRecord(side_.ev2, stream_));

@@ -282,6 +282,8 @@ class Engine {
     std::chrono::steady_clock::time_point t0_;
   };
   void wait_stream();
+  void wait_stream_blocking();                // sleeps instead of spinning: the one wait of a device-resident call lasts tens of milliseconds
+  hipEvent_t ev_block_ = nullptr;
   void wait_side();                          // blocks on the side stream's event (side_.ev)
   void transcript_prefix_async(size_t B);
   bool device_prefix(size_t B) const;         // run the whole protocol on the GPU (batches >= CPX_DEVICE_MIN_BATCH) or drive it from the host

@@ -429,7 +429,7 @@ void Engine::batch_prove_device(const uint32_t* permutation, const uint8_t* k_in
   }
   launch_ps_serialize(d, Bi, stream_);
   CPX_HIP(hipMemcpyAsync(proofs_out, dp.proofs.p, B * proof_size(), hipMemcpyDeviceToHost, stream_));
-  wait_stream();
+  wait_stream_blocking();
   flush_timers();
   if (getenv("CPX_TRACE")) {   // debugging aid: the challenges and responses of proof 0, same format as the host-driven prover prints
     std::vector<Fr> sc(SC_COUNT);
@@ -626,7 +626,7 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
     tock();
     CPX_HIP(hipMemcpyAsync(h_comp_.p, d_res_.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
     CPX_HIP(hipMemcpyAsync(h_u32_.p, dv.flags.p, B * 4, hipMemcpyDeviceToHost, stream_));
-    wait_stream();
+    wait_stream_blocking();
     memcpy(fused_partial, h_comp_.p, sizeof(Jac));
     int invalid = 0;
     for (size_t p = 0; p < B; p++) invalid += h_u32_.p[p] ? 1 : 0;
@@ -652,7 +652,7 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
   tock();
   CPX_HIP(hipMemcpyAsync(h_comp_.p, d_comp_.p, B * 48, hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipMemcpyAsync(h_u32_.p, dv.flags.p, B * 4, hipMemcpyDeviceToHost, stream_));
-  wait_stream();
+  wait_stream_blocking();
   for (size_t p = 0; p < B; p++) {
     const uint32_t f = h_u32_.p[p];
     const bool ok = h_comp_.p[p * 48] == 0xc0;

@@ -2,26 +2,27 @@
 # Regenerates the measurement artefacts of profiles/ on a GPU box (run from the repository root; results land in
 # gpurun_out/prof/, copy them to profiles/).  rocprofv3 wants a writable cwd/TMPDIR: the profiler runs from /tmp.
 # PMC passes are separate runs (no traces together with --pmc).  The HBM counter pass runs first because bench.py reads
-# profiles/r01_hbm_counters.json for roofline.traffic.
+# profiles/${RND}_hbm_counters.json for roofline.traffic.
 set -x
+RND=${RND:-r02}
 R=$PWD
 O=$R/gpurun_out/prof
 mkdir -p $O
-python bench.py --no-cpu-baseline --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > /dev/null 2>&1   # builds the synthetic batch cache
+python bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > /dev/null 2>&1   # builds the synthetic batch cache
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc2 -- python $R/bench.py --no-cpu-baseline --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc2.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc3 -- python $R/bench.py --no-cpu-baseline --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc3.log 2>&1
-python $R/scripts/hbm_counters.py $O/r01_hbm_counters.json 8192 4 $(find /tmp/pmc2 -name "*counter_collection.csv" | head -1) $(find /tmp/pmc3 -name "*counter_collection.csv" | head -1) > $O/r01_hbm_counters.txt 2>&1
-cp $O/r01_hbm_counters.json $R/profiles/r01_hbm_counters.json
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc1 -- python $R/bench.py --no-cpu-baseline --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc1.log 2>&1
-python $R/scripts/pmc_summary.py $(find /tmp/pmc1 -name "*counter_collection.csv" | head -1) $O/r01_pmc_sq.md > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --no-cpu-baseline --synth-cache /tmp/synth.pkl > $O/kt.log 2>&1
-cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/r01_kernel_stats.csv
-grep -o '{"metric.*' $O/kt.log | head -1 > $O/r01_bench_under_rocprof.json   # the bench line of the SAME process the kernel statistics come from
-python $R/scripts/gpu_busy.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) after_last=k_fix_build from_first=k_compress > $O/r01_gpu_busy.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc2 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc2.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc3 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc3.log 2>&1
+python $R/scripts/hbm_counters.py $O/${RND}_hbm_counters.json 8192 2 $(find /tmp/pmc2 -name "*counter_collection.csv" | head -1) $(find /tmp/pmc3 -name "*counter_collection.csv" | head -1) > $O/${RND}_hbm_counters.txt 2>&1
+cp $O/${RND}_hbm_counters.json $R/profiles/${RND}_hbm_counters.json
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc1 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc1.log 2>&1
+python $R/scripts/pmc_summary.py $(find /tmp/pmc1 -name "*counter_collection.csv" | head -1) $O/${RND}_pmc_sq.md > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl > $O/kt.log 2>&1
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/${RND}_kernel_stats.csv
+grep -o '{"metric.*' $O/kt.log | head -1 > $O/${RND}_bench_under_rocprof.json   # the bench line of the SAME process the kernel statistics come from
+python $R/scripts/gpu_busy.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) after_last=k_fix_build from_first=k_compress > $O/${RND}_gpu_busy.txt 2>&1
 cd $R
 python bench.py --synth-cache /tmp/synth.pkl > $O/bench_default.log 2>&1
-tail -1 $O/bench_default.log > $O/r01_bench.json
-python bench.py --fused-verify --synth-cache /tmp/synth.pkl 2>/dev/null | tail -1 > $O/r01_bench_config5.json
-python scripts/single_proof_latency.py > $O/r01_single_proof_latency.txt 2>&1
-cut -c1-300 $O/r01_bench.json; head -3 $O/r01_gpu_busy.txt
+tail -1 $O/bench_default.log > $O/${RND}_bench.json
+python bench.py --fused-verify --synth-cache /tmp/synth.pkl 2>/dev/null | tail -1 > $O/${RND}_bench_config5.json
+python scripts/single_proof_latency.py > $O/${RND}_single_proof_latency.txt 2>&1
+cut -c1-300 $O/${RND}_bench.json; head -3 $O/${RND}_gpu_busy.txt

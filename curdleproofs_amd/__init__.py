@@ -50,7 +50,7 @@ class ProofError(CpxError):
 _lib = None
 
 EXPORTS = [
-    "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size",
+    "cpx_host_alloc", "cpx_host_free", "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size",
     "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress",
     "cpx_accum_new", "cpx_accum_free", "cpx_accum_check", "cpx_accum_verify",
     "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify", "cpx_batch_verify_fused", "cpx_g1_sum_jac",
@@ -70,6 +70,10 @@ def load_library():
                           "(hipcc, gfx950). There is no CPU fallback." % _LIB_PATH)
     L = ctypes.CDLL(path)
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.cpx_host_alloc.argtypes = [sz]
+    L.cpx_host_alloc.restype = vp
+    L.cpx_host_free.argtypes = [vp]
+    L.cpx_host_free.restype = None
     L.cpx_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.cpx_ctx_destroy.argtypes = [vp]
     L.cpx_ctx_destroy.restype = None
@@ -126,6 +130,29 @@ def _len(b):
 
 def _out(n):
     return (ctypes.c_uint8 * max(n, 1))()
+
+
+class _PinnedOwner:
+    def __init__(self, L, addr):
+        self.L, self.addr = L, addr
+
+    def __del__(self):
+        try:
+            self.L.cpx_host_free(self.addr)
+        except Exception:
+            pass
+
+
+def _pinned_array(ctype, n):
+    """ctypes array of n elements in page-locked host memory (falls back to ordinary memory if the allocation fails)."""
+    L = load_library()
+    nbytes = ctypes.sizeof(ctype) * n
+    addr = None if os.environ.get("CPX_PINNED") == "0" else L.cpx_host_alloc(nbytes)   # CPX_PINNED=0: ordinary memory (A/B runs)
+    if not addr:
+        return (ctype * n)()
+    arr = (ctype * n).from_address(addr)
+    arr._cpx_owner = _PinnedOwner(L, addr)   # freed when the array object goes away
+    return arr
 
 
 class Context:
@@ -240,15 +267,19 @@ class Context:
 
     @staticmethod
     def marshal(data):
-        """Pre-marshal a bytes object (or a list of u32 for permutations) into a ctypes buffer once, so that
-        repeated batch calls do not pay Python-side copies."""
+        """Pre-marshal a bytes object (or a list of u32 for permutations) into a page-locked ctypes buffer once (cpx_host_alloc), so
+        that repeated batch calls pay neither Python-side copies nor staging copies: the library moves it by asynchronous DMA."""
         if isinstance(data, (bytes, bytearray)):
-            return (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) if len(data) else b"\0")
-        return (ctypes.c_uint32 * len(data))(*data)
+            buf = _pinned_array(ctypes.c_uint8, max(len(data), 1))
+            ctypes.memmove(buf, bytes(data) if len(data) else b"\0", max(len(data), 1))
+            return buf
+        buf = _pinned_array(ctypes.c_uint32, max(len(data), 1))
+        buf[:len(data)] = data
+        return buf
 
     def prove_batch(self, permutations, k, vec_m_blinders, rand, raw=False):
-        """CurdleproofsProof::new for every loaded instance; returns a list of serialized proofs
-        (or, with raw=True, the ctypes buffer holding all of them back to back)."""
+        """CurdleproofsProof::new for every loaded instance; returns a list of serialized proofs (or, with raw=True, a page-locked
+        ctypes buffer holding all of them back to back; it is reused by the second-next raw prove of this context)."""
         B, ell, n = self.batch, self.ell, self.n
         if not isinstance(permutations, ctypes.Array):
             if len(permutations) != B * ell:
@@ -258,7 +289,16 @@ class Context:
         if ctypes.sizeof(perm) != 4 * B * ell or _len(k) != B * FR or _len(vec_m_blinders) != B * 4 * FR or _len(rand) != B * (3 * n + 9) * FR:
             raise ValueError("prove_batch: per instance ell u32 permutation entries, k (32 B), 4 blinders, 3n+9 random scalars")
         psz = self.proof_size
-        out = _out(B * psz)
+        if raw:   # two page-locked output buffers per context, used alternately: a returned buffer stays valid until the prove after the next
+            pool = self.__dict__.setdefault("_raw_pool", {})
+            slot = pool.get("next", 0)
+            if pool.get(("size", slot)) != B * psz:
+                pool[("buf", slot)] = _pinned_array(ctypes.c_uint8, B * psz)
+                pool[("size", slot)] = B * psz
+            out = pool[("buf", slot)]
+            pool["next"] = 1 - slot
+        else:
+            out = _out(B * psz)
         self._check(self._L.cpx_batch_prove(self._h, perm, _in(k), _in(vec_m_blinders), _in(rand), out))
         if raw:
             return out

@@ -65,6 +65,15 @@ int cpx_device_count(void) {
   return n;
 }
 
+void* cpx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void cpx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int cpx_ctx_create(int device_id, cpx_ctx** out) {
   if (!out) return CPX_ERR_ARG;
   *out = nullptr;

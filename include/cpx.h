@@ -46,6 +46,11 @@ void cpx_ctx_destroy(cpx_ctx* ctx);
 const char* cpx_last_error(const cpx_ctx* ctx); /* message of the last failing call on this ctx    */
 int cpx_device_count(void);
 
+/* Optional: page-locked host buffers.  Any host memory may be passed to the calls below; buffers obtained here let the batch calls
+ * move their inputs / outputs by asynchronous DMA (no staging copies, transfers overlap the kernels of other contexts). */
+void* cpx_host_alloc(size_t bytes);
+void cpx_host_free(void* p);
+
 /* crs.rs:37-58 `CurdleproofsCrs::from_points(ell, points)`: ell + 7 affine points in the order
  * vec_G[ell] | vec_H[4] | H | G_t | G_u.  Uploads them, computes G_sum / H_sum on the device and builds the fixed-base
  * tables (radix 2^16: 15 GB at ell = 252; falls back to radix 2^8 when free HBM is short).  `n_points` is the number of

@@ -1,4 +1,12 @@
 cd $GRAFT_REPO_ROOT
-python scripts/single_proof_breakdown.py 2>&1 | tail -25
-cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us 2>/dev/null; python -c "
-import os; print(len(os.sched_getaffinity(0)), os.cpu_count())"
+run() { echo "=== $*"; env "$@" timeout 900 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl $EXTRA 2>&1 | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+print(round(d['value']), round(d['ms_per_step']), d['all_verified'])
+"; }
+EXTRA="--ctxs 2" run CPX_PINNED=1
+EXTRA="--ctxs 2" run CPX_PINNED=0
+EXTRA="--ctxs 2" run CPX_PINNED=1
+EXTRA="--ctxs 2" run CPX_PINNED=0
+EXTRA="--ctxs 1" run CPX_PINNED=1
+EXTRA="--ctxs 1" run CPX_PINNED=0

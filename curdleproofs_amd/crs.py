@@ -1,0 +1,61 @@
+"""CRS hex/JSON tooling: host-side mirror of the reference's `CurdleproofsCrsHex` (src/crs.rs:77-142).
+
+The JSON object has the fields vec_G, vec_H, H, G_t, G_u, G_sum, H_sum; every point is "0x" + the hex of its 48-byte
+compressed encoding.  Decoding validates every point on the GPU (on curve, in the subgroup: `from_bytes_g1affine`); G_sum /
+H_sum are recomputed by `Context.set_crs` and compared with the file's, so a CRS whose sums do not match its vectors is
+refused (the reference trusts the file).  No CPU group arithmetic here.
+"""
+import json
+
+from . import AFF, N_BLINDERS, CPX_ERR_DESERIALIZE, CpxError
+from . import whisk
+
+
+def crs_to_hex(ctx):
+    """`CurdleproofsCrsHex::try_from(&crs)` for the CRS loaded into ctx: dict of hex strings"""
+    ell, n = ctx.ell, ctx.n
+    pts = ctx.crs_points
+    g_sum, h_sum = ctx.crs_sums()
+    allp = pts + g_sum + h_sum
+    jac = b"".join(allp[i * AFF:(i + 1) * AFF] + (bytes(48) if allp[i * AFF:(i + 1) * AFF] == bytes(AFF) else whisk.pr.fp_to_wire(1)) for i in range(ell + 9))
+    comp = ctx.normalize(jac, compressed=True)[1]
+    hx = ["0x" + comp[48 * i:48 * i + 48].hex() for i in range(ell + 9)]
+    return dict(vec_G=hx[:ell], vec_H=hx[ell:n], H=hx[n], G_t=hx[n + 1], G_u=hx[n + 2], G_sum=hx[n + 3], H_sum=hx[n + 4])
+
+
+def crs_from_hex(ctx, obj):
+    """`TryInto<CurdleproofsCrs> for &CurdleproofsCrsHex` followed by `Context.set_crs`: loads the CRS into ctx.
+    Raises whisk.SerializationError for a malformed string / point (SerializationError::InvalidData in the reference)."""
+    def unhex(s):
+        if not isinstance(s, str) or not s.startswith("0x"):
+            raise whisk.SerializationError("missing 0x prefix")
+        try:
+            b = bytes.fromhex(s[2:])
+        except ValueError:
+            raise whisk.SerializationError("not hex")
+        if len(b) != 48:
+            raise whisk.SerializationError("a compressed G1 point has 48 bytes")
+        return b
+    vec_G, vec_H = [unhex(s) for s in obj["vec_G"]], [unhex(s) for s in obj["vec_H"]]
+    if len(vec_H) != N_BLINDERS:
+        raise ValueError("vec_H must hold N_BLINDERS = 4 points")
+    ell = len(vec_G)
+    comp = b"".join(vec_G + vec_H + [unhex(obj["H"]), unhex(obj["G_t"]), unhex(obj["G_u"]), unhex(obj["G_sum"]), unhex(obj["H_sum"])])
+    try:
+        pts = ctx.decompress(comp, check_subgroup=True)
+    except CpxError as e:
+        if e.code == CPX_ERR_DESERIALIZE:
+            raise whisk.SerializationError(str(e))
+        raise
+    ctx.set_crs(ell, pts[:(ell + 7) * AFF])
+    if ctx.crs_sums() != (pts[(ell + 7) * AFF:(ell + 8) * AFF], pts[(ell + 8) * AFF:(ell + 9) * AFF]):
+        raise ValueError("G_sum / H_sum of the file are not the sums of vec_G / vec_H")
+    return ell
+
+
+def crs_to_json(ctx):
+    return json.dumps(crs_to_hex(ctx))
+
+
+def crs_from_json(ctx, text):
+    return crs_from_hex(ctx, json.loads(text))

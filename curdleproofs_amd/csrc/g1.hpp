@@ -57,23 +57,41 @@ CPX_HD Aff jac_to_affine_with_zinv(const Jac& p, const Fp& zinv) {
 }
 
 // zcash / ark-bls12-381 compressed encoding of an affine point (48 bytes, big-endian x,
-// bit7 = compressed, bit6 = infinity, bit5 = y lexicographically largest i.e. y > -y).
-CPX_HD void aff_compress(const Aff& p, uint8_t* out) {
+// bit7 = compressed, bit6 = infinity, bit5 = y lexicographically largest i.e. y > -y), as twelve 32-bit words whose
+// little-endian memory image is the encoding: a kernel stores them with three 16-byte stores.
+CPX_HD uint32_t bswap32(uint32_t w) { return (w >> 24) | ((w >> 8) & 0xff00u) | ((w << 8) & 0xff0000u) | (w << 24); }
+CPX_HD void aff_compress_words(const Aff& p, uint32_t w[12]) {
   if (p.is_identity()) {
-    out[0] = 0xc0;
-    for (int i = 1; i < 48; i++) out[i] = 0;
+    w[0] = 0xc0u;   // byte 0
+    CPX_UNROLL for (int i = 1; i < 12; i++) w[i] = 0;
     return;
   }
-  Fp xc = fe_from_mont(p.x), yc = fe_from_mont(p.y), nyc = fe_from_mont(fe_neg(p.y));
-  CPX_UNROLL for (int l = 0; l < 12; l++) {
-    uint32_t w = xc.v[11 - l];
-    out[4 * l + 0] = (uint8_t)(w >> 24);
-    out[4 * l + 1] = (uint8_t)(w >> 16);
-    out[4 * l + 2] = (uint8_t)(w >> 8);
-    out[4 * l + 3] = (uint8_t)w;
+  const Fp xc = fe_from_mont(p.x), yc = fe_from_mont(p.y);
+  // y > -y  <=>  y > p - y (canonical integers; y != 0 on this curve: there is no point of order two)
+  Fp pm, nyc;
+  CPX_UNROLL for (int i = 0; i < 12; i++) pm.v[i] = FpCfg::P[i];
+  {
+    uint32_t borrow = 0;
+    CPX_UNROLL for (int i = 0; i < 12; i++) {
+      const uint64_t d = (uint64_t)pm.v[i] - yc.v[i] - borrow;
+      nyc.v[i] = (uint32_t)d;
+      borrow = (uint32_t)(d >> 63);
+    }
   }
-  out[0] |= 0x80;
-  if (fe_raw_gt(yc, nyc)) out[0] |= 0x20;
+  uint32_t top = xc.v[11] | 0x80000000u;
+  if (fe_raw_gt(yc, nyc)) top |= 0x20000000u;
+  w[0] = bswap32(top);
+  CPX_UNROLL for (int l = 1; l < 12; l++) w[l] = bswap32(xc.v[11 - l]);
+}
+CPX_HD void aff_compress(const Aff& p, uint8_t* out) {
+  uint32_t w[12];
+  aff_compress_words(p, w);
+  CPX_UNROLL for (int l = 0; l < 12; l++) {
+    out[4 * l + 0] = (uint8_t)w[l];
+    out[4 * l + 1] = (uint8_t)(w[l] >> 8);
+    out[4 * l + 2] = (uint8_t)(w[l] >> 16);
+    out[4 * l + 3] = (uint8_t)(w[l] >> 24);
+  }
 }
 
 // Signed-digit (NAF-like, width w) recoding helpers operate on canonical 256-bit scalars held as

@@ -37,6 +37,17 @@
 
 namespace cpx {
 
+// compressed encoding of a point to a 16-byte-aligned destination (every compressed-point buffer of the engine is: 48-byte records
+// in hipMalloc'ed arrays): three 16-byte stores instead of 48 single-byte ones
+__device__ __forceinline__ void aff_compress_store(const Aff& a, uint8_t* out) {
+  uint32_t w[12];
+  aff_compress_words(a, w);
+  uint4* o = reinterpret_cast<uint4*>(out);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  o[2] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+
 // ------------------------------------------------------------------ inversion on device
 // One inversion per work-group by batched division steps (modinv30.hpp): ~0.05 ms of single-wave latency instead of
 // the ~0.25 ms of the binary Euclidean algorithm or the ~0.55 ms of Fermat's a^(p-2) (571 dependent products);
@@ -674,7 +685,7 @@ __global__ __launch_bounds__(64) void k_finalize_ranges(const TJac* __restrict__
   if (g >= n) return;
   const Aff a = inf ? Aff::identity() : t_to_std(t_to_affine(p, zinv));
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
-  if (out_comp) aff_compress(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
+  if (out_comp) aff_compress_store(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
 }
 
 // Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per request.  The lanes add the
@@ -718,7 +729,7 @@ __global__ __launch_bounds__(256) void k_finalize_ranges_wave(const TJac* __rest
   if (!owner) return;
   const Aff a = inf ? Aff::identity() : t_to_std(t_to_affine(p, zinv));
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
-  if (out_comp) aff_compress(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
+  if (out_comp) aff_compress_store(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
 }
 
 // ------------------------------------------------------------------ table construction
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(64) void k_finalize(const Jac* __restrict__ in, int
   if (g >= n) return;
   Aff a = inf ? Aff::identity() : jac_to_affine_with_zinv(p, zinv);
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
-  if (out_comp) aff_compress(a, out_comp + (size_t)g * 48);
+  if (out_comp) aff_compress_store(a, out_comp + (size_t)g * 48);
 }
 
 // affine -> compressed bytes only; `batch` strided input rows of n points each, dense output
@@ -842,14 +853,14 @@ __global__ __launch_bounds__(256) void k_compress(const Aff* __restrict__ in, in
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const size_t row = blockIdx.y;
-  aff_compress(in[row * stride + g], out + (row * out_stride + g) * 48);
+  aff_compress_store(in[row * stride + g], out + (row * out_stride + g) * 48);
 }
 
 // selected columns of strided rows: out[(row * out_stride + cols[t]) * 48] = compress(in[row * stride + cols[t]]), t < ncols
 __global__ __launch_bounds__(64) void k_compress_cols(const Aff* __restrict__ in, const uint32_t* __restrict__ cols, int ncols, int stride, uint8_t* __restrict__ out,
                                                       int out_stride) {
   const size_t row = blockIdx.x;
-  for (int t = threadIdx.x; t < ncols; t += 64) aff_compress(in[row * stride + cols[t]], out + (row * out_stride + cols[t]) * 48);
+  for (int t = threadIdx.x; t < ncols; t += 64) aff_compress_store(in[row * stride + cols[t]], out + (row * out_stride + cols[t]) * 48);
 }
 
 // ------------------------------------------------------------------ per-element scalar-mul (+ add)
@@ -914,13 +925,18 @@ __global__ __launch_bounds__(64, 2) void k_decompress(const uint8_t* __restrict_
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const uint8_t* b = in + (src_offset ? (size_t)src_offset[g] : (size_t)g * 48);   // dense encodings, or byte offsets into serialized proofs
-  const bool compressed = b[0] & 0x80, infinity = b[0] & 0x40, sort = b[0] & 0x20;
   Fp xc;
-  for (int l = 0; l < 12; l++) {
-    uint32_t w = ((uint32_t)b[4 * l] << 24) | ((uint32_t)b[4 * l + 1] << 16) | ((uint32_t)b[4 * l + 2] << 8) | b[4 * l + 3];
-    if (l == 0) w &= 0x1fffffffu;
-    xc.v[11 - l] = w;
+  if ((reinterpret_cast<uintptr_t>(b) & 15) == 0) {   // 16-byte aligned (device-resident proofs / dense arrays): three 16-byte loads
+    const uint4* q = reinterpret_cast<const uint4*>(b);
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const uint32_t ww[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    CPX_UNROLL for (int l = 0; l < 12; l++) xc.v[11 - l] = bswap32(ww[l]);
+  } else {
+    for (int l = 0; l < 12; l++) xc.v[11 - l] = ((uint32_t)b[4 * l] << 24) | ((uint32_t)b[4 * l + 1] << 16) | ((uint32_t)b[4 * l + 2] << 8) | b[4 * l + 3];
   }
+  const uint8_t b0 = (uint8_t)(xc.v[11] >> 24);
+  xc.v[11] &= 0x1fffffffu;
+  const bool compressed = b0 & 0x80, infinity = b0 & 0x40, sort = b0 & 0x20;
   Aff res = Aff::identity();
   uint8_t st = 0;
   if (!compressed) {

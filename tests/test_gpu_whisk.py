@@ -116,3 +116,31 @@ def test_whisk_scalar_and_point_helpers(ctx, orc, whisk_kat):
     assert whisk.to_bytes_g1affine(ctx, whisk.from_bytes_g1affine(ctx, gb)) == gb  # whisk.rs:363-368
     assert whisk.from_bytes_g1affine(ctx, gb) == whisk.g1_generator(ctx) == orc.g1_generator()
     assert whisk.to_bytes_g1affine(ctx, bytes(96)) == bytes([0xc0]) + bytes(47)
+
+
+def test_crs_hex_json_roundtrip(ctx, orc):
+    """crs.rs:77-142 CurdleproofsCrsHex: "0x" + compressed hex per point; decode validates the points and the two sums"""
+    import json
+    from curdleproofs_amd import crs as crsmod, whisk
+    ell = 28
+    pts = orc.generate_crs_points(ell)
+    ctx.set_crs(ell, pts)
+    obj = crsmod.crs_to_hex(ctx)
+    assert len(obj["vec_G"]) == ell and len(obj["vec_H"]) == 4 and all(s.startswith("0x") and len(s) == 98 for s in obj["vec_G"])
+    assert obj["vec_G"][0] == "0x" + orc.g1_compress(pts[:96]).hex()
+    gs, hs = orc.crs_sums(ell, pts)
+    assert obj["G_sum"] == "0x" + orc.g1_compress(gs).hex() and obj["H_sum"] == "0x" + orc.g1_compress(hs).hex()
+    text = json.dumps(obj)
+    import curdleproofs_amd as cpx
+    c2 = cpx.Context(0)
+    assert crsmod.crs_from_json(c2, text) == ell
+    assert c2.crs_points == pts and c2.crs_sums() == (gs, hs)
+    bad = dict(obj, H=obj["H"][2:])                       # missing 0x
+    with pytest.raises(whisk.SerializationError):
+        crsmod.crs_from_hex(c2, bad)
+    bad = dict(obj, G_t="0x" + "00" * 48)                 # not a compressed encoding
+    with pytest.raises(whisk.SerializationError):
+        crsmod.crs_from_hex(c2, bad)
+    bad = dict(obj, G_sum=obj["H_sum"])                   # sums that do not belong to the vectors
+    with pytest.raises(ValueError):
+        crsmod.crs_from_hex(c2, bad)

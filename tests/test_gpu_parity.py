@@ -675,3 +675,25 @@ def test_large_batch_four_contexts_every_proof_matches_oracle(orc):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on real hardware: bench.py starts its two ranks itself (torch.distributed.run), both
+    ranks share GPU 0 (CPX_BENCH_DEVICE) and meet over gloo (RCCL refuses two ranks on one device), every rank proves and verifies its
+    own batch, rank 0 prints ONE line with n_gpus = 2 and the whole-job rate.  Small shapes: this checks the plumbing, not the speed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPX_BENCH_BACKEND="gloo", CPX_BENCH_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ell", "28", "--batch", "128", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extra-shapes"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["all_verified"] is True and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 256 and d["config"]["batch_per_gpu"] == 128
+    assert abs(d["value"] - 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]

@@ -34,15 +34,12 @@ Engine::Engine(int device) : device_(device) {
     if (stream_) (void)hipStreamDestroy(stream_);
     throw;
   }
-  baton_register(+1);
   if (const char* e = getenv("CPX_FIX_BITS")) {
     int c = atoi(e);
     if (c == 8 || c == 16) fix_bits_cfg_ = fix_bits_ = c;   // radix of the fixed-base CRS table (8: 0.1 GB, 16: 15 GB at ell = 252)
   }
 }
 Engine::~Engine() {
-  baton_release();
-  baton_register(-1);
   for (auto p : idx_allocs_) (void)hipFree(p);
   if (side_.ev) (void)hipEventDestroy(side_.ev);
   if (side_.ev2) (void)hipEventDestroy(side_.ev2);
@@ -184,59 +181,9 @@ Engine::HostSpan::~HostSpan() {
   st.launches++;
   st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
 }
-// ---- host baton (off unless CPX_HOST_BATON=1) -----------------------------------------------------------
-// Written for TWO engines per GPU; with the four the bench runs now the host phases of different engines run side
-// by side faster than one after the other (bench.py at 32 cores per rank: 8.5k proofs/s with the baton, 10.7k without).
-// Several engines on one GPU (one host thread each) take turns on the HOST side: an engine holds the device's
-// baton while it runs host work and enqueues kernels, and passes it on whenever it blocks on its stream.  Kernels
-// of different engines still overlap freely on the GPU.  Two effects: the engines fall into anti-phase (one
-// hashes transcripts and prepares scalars while the other one's kernels run) instead of the lock-step that
-// fair GPU sharing otherwise pulls them into (both finish their kernels together, then both leave the GPU idle
-// during their host halves), and their worker pools never compete for the same cores.
-namespace {
-struct HostBaton {   // FIFO ticket lock
-  std::mutex mu;
-  std::condition_variable cv;
-  uint64_t next = 0, serving = 0;
-  std::atomic<int> engines{0};
-};
-HostBaton g_batons[64];
-bool baton_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("CPX_HOST_BATON");   // off by default: with 4 contexts per GPU and 8-24 worker threads each the host phases
-    return e && atoi(e) != 0;                    // of different contexts run side by side faster than one after the other
-  }();
-  return on;
-}
-}  // namespace
-void Engine::baton_register(int delta) { g_batons[device_ & 63].engines += delta; }
-void Engine::baton_acquire() {
-  HostBaton& g = g_batons[device_ & 63];
-  if (baton_held_ || !baton_enabled() || g.engines.load(std::memory_order_relaxed) < 2) return;
-  HostSpan w(this, "host_wait_baton");
-  std::unique_lock<std::mutex> lk(g.mu);
-  const uint64_t my = g.next++;
-  g.cv.wait(lk, [&] { return g.serving == my; });
-  baton_held_ = true;
-}
-void Engine::baton_release() {
-  if (!baton_held_) return;
-  HostBaton& g = g_batons[device_ & 63];
-  {
-    std::lock_guard<std::mutex> lk(g.mu);
-    g.serving++;
-  }
-  g.cv.notify_all();
-  baton_held_ = false;
-}
 void Engine::wait_stream() {
-  const bool had = baton_held_;
-  baton_release();
-  {
-    HostSpan w(this, "host_wait_device");
-    CPX_HIP(hipStreamSynchronize(stream_));
-  }
-  if (had) baton_acquire();
+  HostSpan w(this, "host_wait_device");
+  CPX_HIP(hipStreamSynchronize(stream_));
 }
 
 // Batches of at least CPX_DEVICE_MIN_BATCH proofs (default 32) run the whole protocol on the GPU (engine_device.cpp).  Smaller
@@ -269,13 +216,8 @@ void Engine::transcript_prefix_async(size_t B) {
   CPX_HIP(hipEventRecord(side_.ev, side_.stream));
 }
 void Engine::wait_side() {
-  const bool had = baton_held_;
-  baton_release();
-  {
-    HostSpan w(this, "host_wait_device");
-    CPX_HIP(hipEventSynchronize(side_.ev));
-  }
-  if (had) baton_acquire();
+  HostSpan w(this, "host_wait_device");
+  CPX_HIP(hipEventSynchronize(side_.ev));
 }
 
 const uint32_t* Engine::idx_list(const std::vector<uint32_t>& v) {
@@ -900,7 +842,6 @@ void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const
 // folds, no per-round normalisation, every MSM runs on pre-shifted tables (k_msm_tbl) without a doubling tail.
 void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   HostSpan wall(this, "host_prove_wall");
-  BatonScope baton(this);
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;
   const SlotMap sm(L);
@@ -974,6 +915,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       for (size_t i = 0; i < n; i++) s.scal[1][i] = s.draw(I_VR + i);
       s.scal[2] = {s.draw(I_RT), s.draw(I_RU), s.draw(I_RA), s.draw(I_RB)};
       s.scal[3] = {kk, r_k};                                   // scalars of the four T_2 scalar multiplications
+      s.scal[4].resize(n);                                     // r_c of the IPA (inner_product_argument.rs:46): B_c = msm(G | Hvec, r_c)
+      for (size_t i = 0; i < n; i++) s.scal[4][i] = s.draw(I_IR + i);
     });
   }
   auto take = [&](size_t p, int slot_id, size_t req_index) { memcpy(&st[p].comp[(size_t)slot_id * 48], &comp[req_index * 48], 48); };
@@ -1044,13 +987,14 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       reqs.push_back({cseg(0, 1, iH), ru, none, nullptr, slot_index(p, sm.TMP(1))});
       reqs.push_back({cseg(0, 1, iH), ra, none, nullptr, slot_index(p, sm.TMP(2))});
       reqs.push_back({cseg(0, 1, iH), rb, none, nullptr, slot_index(p, sm.TMP(3))});
+      reqs.push_back({cseg(0, (uint32_t)n), s.scal[4].data(), none, nullptr});                        // B_c: depends on the randomness only
     }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      const int ids[12] = {SL_A, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), -1, -1, -1, -1};
-      for (int i = 0; i < 12; i++)
-        if (ids[i] >= 0) take(p, ids[i], p * 12 + i);
+      const int ids[13] = {SL_A, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), -1, -1, -1, -1, SL_BC};
+      for (int i = 0; i < 13; i++)
+        if (ids[i] >= 0) take(p, ids[i], p * 13 + i);
       // same_permutation_argument.rs:60-83
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_A * 48]);
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_M * 48]);
@@ -1068,6 +1012,12 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       // single-point terms (G_sum sits in the CRS tables)
       s.scal[5] = {s.beta_sp};
       s.scal[6] = {s.alpha_sp};
+      // the partial products c (grand_product_argument.rs:66-75) need the factors only, so C joins the phase of B and A'
+      s.c.assign(1, S::one());
+      for (size_t i = 0; i + 1 < ell; i++) s.c.push_back(s.c[i] * s.factors[i]);
+      s.vec_c_blinders.resize(N_BLINDERS);
+      for (size_t i = 0; i < N_BLINDERS; i++) s.vec_c_blinders[i] = s.draw(I_CB + i);
+      s.c.insert(s.c.end(), s.vec_c_blinders.begin(), s.vec_c_blinders.end());
     });
   }
 
@@ -1092,7 +1042,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipEventRecord(side_.ev, side_.stream));
   }
 
-  // -- P2: B, and A' = A + cm_T.T_1 + cm_U.T_1 (curdleproofs.rs:134) as a sum of three points of phase 1
+  // -- P2: B, A' = A + cm_T.T_1 + cm_U.T_1 (curdleproofs.rs:134) as a sum of three points of phase 1, and C = msm(G | Hvec, c)
+  //    (grand_product_argument.rs:76).  The transcript takes B, draws alpha, then takes C: an order of hashing, not of computing.
   {
     std::vector<TblReq> reqs;
     for (size_t p = 0; p < B; p++) {
@@ -1104,31 +1055,17 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       ra.add[2] = slot_index(p, SL_CMU1);
       reqs.push_back(rb);
       reqs.push_back(ra);
+      reqs.push_back({cseg(0, (uint32_t)n), st[p].c.data(), none, nullptr});
     }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      take(p, SL_B, p * 2);
-      take(p, sm.APRIME(), p * 2 + 1);
+      take(p, SL_B, p * 3);
+      take(p, sm.APRIME(), p * 3 + 1);
+      take(p, SL_C, p * 3 + 2);
       s.tr.append_point_bytes("gprod_step1", &s.comp[SL_B * 48]);
       s.tr.append_scalar("gprod_step1", s.gprod);
       s.alpha_g = s.tr.get_and_append_challenge("gprod_alpha");
-      s.c.assign(1, S::one());
-      for (size_t i = 0; i + 1 < ell; i++) s.c.push_back(s.c[i] * s.factors[i]);
-      s.vec_c_blinders.resize(N_BLINDERS);
-      for (size_t i = 0; i < N_BLINDERS; i++) s.vec_c_blinders[i] = s.draw(I_CB + i);
-      s.c.insert(s.c.end(), s.vec_c_blinders.begin(), s.vec_c_blinders.end());
-    });
-  }
-
-  // -- P3: C
-  {
-    std::vector<TblReq> reqs;
-    for (size_t p = 0; p < B; p++) reqs.push_back({cseg(0, (uint32_t)n), st[p].c.data(), none, nullptr});
-    run_tbl_phase(reqs, &comp);
-    parallel_for(B, [&](size_t p) {
-      ProverState& s = st[p];
-      take(p, SL_C, p);
       const S mb[4] = {S_from_wire(m_blinders + (p * 4 + 0) * 32), S_from_wire(m_blinders + (p * 4 + 1) * 32),
                        S_from_wire(m_blinders + (p * 4 + 2) * 32), S_from_wire(m_blinders + (p * 4 + 3) * 32)};
       const S ab[4] = {s.draw(I_AB), s.draw(I_AB + 1), S::zero(), S::zero()};
@@ -1176,7 +1113,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     });
   }
 
-  // -- P4: D, B_c, B_d
+  // -- P3: D, B_d
   h_rvec_.ensure(B * 4 * n);
   h_rfin_.ensure(B * 3);   // c_final, d_final, x_final of every proof
   h_rgam_.ensure(B * 2);
@@ -1191,15 +1128,13 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       TblReq rd{cseg(n + 3, 2), s.scal[0].data(), none, nullptr};   // G_sum, H_sum are columns n+3, n+4 of the CRS tables
       rd.add[0] = slot_index(p, SL_B);
       reqs.push_back(rd);
-      reqs.push_back({cseg(0, (uint32_t)n), s.scal[1].data(), none, nullptr});
       reqs.push_back({cseg(0, (uint32_t)n), s.scal[3].data(), none, nullptr});
     }
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      take(p, sm.D(), p * 3);
-      take(p, SL_BC, p * 3 + 1);
-      take(p, SL_BD, p * 3 + 2);
+      take(p, sm.D(), p * 2);
+      take(p, SL_BD, p * 2 + 1);
       s.tr.append_point_bytes("ipa_step1", &s.comp[SL_C * 48]);
       s.tr.append_point_bytes("ipa_step1", &s.comp[sm.D() * 48]);
       s.tr.append_scalar("ipa_step1", s.z_ip);
@@ -1279,15 +1214,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   {
     std::vector<uint8_t> id_comp(48, 0);
     id_comp[0] = 0xc0;
-    {
-      const bool had = baton_held_;
-      baton_release();
-      {
-        HostSpan w(this, "host_wait_device");
-        CPX_HIP(hipEventSynchronize(side_.ev));
-      }
-      if (had) baton_acquire();
-    }   // R, S and the four T_2 commitments from the side stream
+    wait_side();   // R, S and the four T_2 commitments from the side stream
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
       memcpy(s.c_final.f.v, &h_rfin_.p[3 * p], sizeof(Fr));       // c[0], d[0] after the last fold (device-resident vectors)
@@ -1447,7 +1374,6 @@ void Engine::batch_verify_fused(const uint8_t* proofs, const uint8_t* rand, uint
 // engine's partial sum, which must add up to the identity over all engines / GPUs.
 void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid) {
   HostSpan wall(this, "host_verify_wall");
-  BatonScope baton(this);
   if (!B_) throw std::logic_error("batch_load first");
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;

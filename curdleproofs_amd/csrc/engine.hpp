@@ -287,16 +287,6 @@ class Engine {
   void wait_side();                          // blocks on the side stream's event (side_.ev)
   void transcript_prefix_async(size_t B);
   bool device_prefix(size_t B) const;         // run the whole protocol on the GPU (batches >= CPX_DEVICE_MIN_BATCH) or drive it from the host
-  // per-device host baton between engines (engine.cpp)
-  void baton_register(int delta);
-  void baton_acquire();
-  void baton_release();
-  bool baton_held_ = false;
-  struct BatonScope {
-    explicit BatonScope(Engine* e) : e_(e) { e_->baton_acquire(); }
-    ~BatonScope() { e_->baton_release(); }
-    Engine* e_;
-  };
 
   // per-proof table row: copy-major [copies][NP]
   size_t np() const { return 1 + 2 * n_; }   // M | T_b | U_b   (R and S are used once: no table)

@@ -14,8 +14,6 @@
 
 namespace cpx {
 
-static const size_t N_BLINDERS = 4;
-
 // ---------------------------------------------------------------- plans
 // Layout of a table-backed MSM phase whose requests all read device-resident scalars (TblReq::dev): the CRS segments go to
 // k_msm_fix, the per-proof segments to k_msm_tblw; k_reduce_sets turns the raw lane accumulators into partial sums,

@@ -240,6 +240,7 @@ class Engine {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   };
   DevProver dprove_;
+  void enqueue_prove_device();
   struct DevVerifier {
     std::vector<const void*> signature;
     VerifyDev dev;

@@ -351,26 +351,35 @@ void Engine::prepare_device_prover() {
     CPX_HIP(hipEventCreateWithFlags(&dp.ev_c, hipEventDisableTiming));
     CPX_HIP(hipEventCreateWithFlags(&dp.ev_d, hipEventDisableTiming));
   }
+  // the shared scratch of exec_plan sized for the largest phase now: nothing is allocated (no implicit device synchronisation)
+  // between the first and the last launch of a prove
+  {
+    size_t max_parts = 1, max_sets = 1;
+    auto upd = [&](const TblPlan& pl) {
+      max_parts = std::max(max_parts, pl.nparts);
+      max_sets = std::max(max_sets, pl.fix_sets + pl.tbl_sets);
+    };
+    upd(dp.p1);
+    upd(dp.p2);
+    upd(dp.p3);
+    for (auto& pl : dp.ipa) upd(*pl);
+    for (auto& pl : dp.smsm) upd(*pl);
+    d_tpart_.ensure(max_parts);
+    ensure_raw_sets(max_sets);
+    d_tbltmp_.ensure(B * NP * (size_t)(copies_ / 2 - 1));
+  }
   dp.signature = sig;
 }
 
-void Engine::batch_prove_device(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
-  HostSpan wall(this, "host_prove_wall");
-  CPX_HIP(hipSetDevice(device_));
+// The kernel launches of one device-resident prove (everything between the upload of the witnesses and the download of the proofs),
+// on the main stream and — forked and joined through events — the side stream.  No host synchronisation, no allocation.
+void Engine::enqueue_prove_device() {
   const size_t B = B_, ell = ell_, n = n_, L = L_;
   const SlotMap sm(L);
-  const size_t NP = np(), NS = sm.count(), nrand = 3 * n + 9;
-  prepare_device_prover();
+  const size_t NP = np(), NS = sm.count();
   DevProver& dp = dprove_;
   const ProveDev& d = dp.dev;
   const int Bi = (int)B;
-
-  // witnesses and the prover's random draws: the only host -> device traffic of a prove
-  CPX_HIP(hipMemcpyAsync(dp.perm.p, permutation, B * ell * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-  CPX_HIP(hipMemcpyAsync(dp.k.p, k_in, B * sizeof(Fr), hipMemcpyHostToDevice, stream_));
-  CPX_HIP(hipMemcpyAsync(dp.mbl.p, m_blinders, B * 4 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
-  CPX_HIP(hipMemcpyAsync(dp.rnd.p, rand, B * nrand * sizeof(Fr), hipMemcpyHostToDevice, stream_));
-
   // -- P0: compressed instance vectors, M -> affine (table source slot 0); side stream: transcript prefix (instance + M
   //    absorbed, vec_a drawn), then R and S; main stream: the per-proof tables
   tick("k_compress", 0, (double)(4 * ell * B));
@@ -426,6 +435,22 @@ void Engine::batch_prove_device(const uint32_t* permutation, const uint8_t* k_in
     launch_smsm_round_fold(dp.rvec2.p, Bi, (int)n, half, d_rgam_.p, stream_);
   }
   launch_ps_serialize(d, Bi, stream_);
+}
+
+void Engine::batch_prove_device(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
+  HostSpan wall(this, "host_prove_wall");
+  CPX_HIP(hipSetDevice(device_));
+  const size_t B = B_, ell = ell_, n = n_, nrand = 3 * n + 9;
+  prepare_device_prover();
+  DevProver& dp = dprove_;
+
+  // witnesses and the prover's random draws: the only host -> device traffic of a prove
+  CPX_HIP(hipMemcpyAsync(dp.perm.p, permutation, B * ell * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dp.k.p, k_in, B * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dp.mbl.p, m_blinders, B * 4 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(dp.rnd.p, rand, B * nrand * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+
+  enqueue_prove_device();
   CPX_HIP(hipMemcpyAsync(proofs_out, dp.proofs.p, B * proof_size(), hipMemcpyDeviceToHost, stream_));
   wait_stream_blocking();
   flush_timers();

@@ -1181,7 +1181,8 @@ int launches_since_set() { return tl_launches; }
 #define CPX_LAUNCH(kern, grid, block, lds, stream, ...)                                                   \
   do {                                                                                                    \
     tl_launches++;                                                                                        \
-    hipExtLaunchKernelGGL(kern, grid, block, lds, stream, tl_ev_start, tl_ev_stop, 0, __VA_ARGS__);       \
+    if (tl_ev_start || tl_ev_stop) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, tl_ev_start, tl_ev_stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);   /* plain launch: capturable into a HIP graph */ \
   } while (0)
 void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, TJac* d_wsum, hipStream_t s) {
   if (ntasks <= 0) return;

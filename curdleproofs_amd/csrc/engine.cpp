@@ -370,18 +370,22 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     pts_fix += (f0 ? r.seg0.n : 0) + (f1 ? r.seg1.n : 0);
     pts_tbl += (f0 ? 0 : r.seg0.n) + (f1 ? 0 : r.seg1.n);
   }
-  d_scal_.ensure(total);
-  d_ttasks_.ensure(std::max<size_t>(ntt, 1));
-  d_ftasks_.ensure(std::max<size_t>(nft, 1));
   d_tpart_.ensure(nparts);
-  d_pfirst_.ensure(nt);
-  d_pcount_.ensure(nt);
   d_comp_.ensure(nt * 48);
+  // everything the phase's kernels read — scalars, task descriptors, partial ranges, destinations, addends — is staged in ONE pinned
+  // buffer with the layout [Fr scalars | TblTask | FixTask | u32 arrays] and uploaded with ONE copy into a device blob of the same
+  // layout (a handful of separate small copies cost ~30 us of host time per phase, which a lone proof waits for)
   const size_t b_scal = total * sizeof(Fr), b_tt = ntt * sizeof(TblTask), b_ft = nft * sizeof(FixTask);
+  static_assert(sizeof(TblTask) % 8 == 0 && sizeof(FixTask) % 8 == 0 && sizeof(Fr) % 8 == 0, "blob sections keep pointer alignment");
   bool any_add = false;
   for (const TblReq& r : reqs) any_add |= r.add[0] != ~0u;
-  h_stage_.ensure(b_scal + b_tt + b_ft + 6 * nt * sizeof(uint32_t));
-  d_dst_.ensure(nt);
+  const size_t b_blob = b_scal + b_tt + b_ft + 6 * nt * sizeof(uint32_t);
+  h_stage_.ensure(b_blob);
+  d_blob_.ensure(b_blob);
+  Fr* const d_scal = reinterpret_cast<Fr*>(d_blob_.p);
+  TblTask* const d_tt = reinterpret_cast<TblTask*>(d_blob_.p + b_scal);
+  FixTask* const d_ft = reinterpret_cast<FixTask*>(d_blob_.p + b_scal + b_tt);
+  uint32_t* const d_u32 = reinterpret_cast<uint32_t*>(d_blob_.p + b_scal + b_tt + b_ft);
   const uint32_t dummy_dst = slot_index(0, SlotMap(L_).TMP(7));   // results nobody reads land in a scratch slot
   Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
   TblTask* ht = reinterpret_cast<TblTask*>(h_stage_.p + b_scal);
@@ -390,7 +394,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   const TblSeg none{nullptr, nullptr, 0, 0};
   parallel_for(nt, [&](size_t i) {
     const TblReq& r = reqs[i];
-    const Fr* sbase = r.dev ? r.dev : d_scal_.p + soff[i];   // where this request's scalars are (or will be) on the device
+    const Fr* sbase = r.dev ? r.dev : d_scal + soff[i];   // where this request's scalars are (or will be) on the device
     if (!r.dev) {
       Fr* d = hs + soff[i];
       for (uint32_t j = 0; j < r.seg0.n; j++) d[j] = r.s0[j].f;
@@ -427,31 +431,22 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     hp[2 * nt + i] = r.dst != ~0u ? r.dst : dummy_dst;
     for (int j = 0; j < 3; j++) hp[3 * nt + 3 * i + j] = r.add[j];
   });
-  if (any_add) {
-    d_padd_.ensure(3 * nt);
-    CPX_HIP(hipMemcpyAsync(d_padd_.p, hp + 3 * nt, 3 * nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-  }
-  if (b_scal) CPX_HIP(hipMemcpyAsync(d_scal_.p, hs, b_scal, hipMemcpyHostToDevice, stream_));
-  if (ntt) CPX_HIP(hipMemcpyAsync(d_ttasks_.p, ht, b_tt, hipMemcpyHostToDevice, stream_));
-  if (nft) CPX_HIP(hipMemcpyAsync(d_ftasks_.p, hf, b_ft, hipMemcpyHostToDevice, stream_));
-  CPX_HIP(hipMemcpyAsync(d_pfirst_.p, hp, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-  CPX_HIP(hipMemcpyAsync(d_pcount_.p, hp + nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
-  CPX_HIP(hipMemcpyAsync(d_dst_.p, hp + 2 * nt, nt * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  CPX_HIP(hipMemcpyAsync(d_blob_.p, h_stage_.p, b_blob, hipMemcpyHostToDevice, stream_));
   const size_t fix_sets = nft * fix_parts, tbl_sets = ntt * tbl_parts;   // raw sets: [fixed-base waves | bucket sets of the table waves]
   ensure_raw_sets(fix_sets + tbl_sets);
   if (nft) {
     tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * pts_fix, pts_fix);
-    launch_msm_fix(d_ftasks_.p, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
+    launch_msm_fix(d_ft, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
     tock();
   }
   if (ntt) {
     tick(tblw_kernel_name(tbl_wpw), 128.0 * pts_tbl, pts_tbl);
-    launch_msm_tblw(d_ttasks_.p, (int)ntt, tbl_wpw, d_raw_.p + fix_sets * raw_set_words(), d_rawslot_.p + fix_sets, stream_);
+    launch_msm_tblw(d_tt, (int)ntt, tbl_wpw, d_raw_.p + fix_sets * raw_set_words(), d_rawslot_.p + fix_sets, stream_);
     tock();
   }
   reduce_sets(fix_sets, tbl_sets);
   tick("k_finalize_ranges", 0, (double)nt);
-  launch_finalize_ranges(d_tpart_.p, d_pfirst_.p, d_pcount_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_, any_add ? d_padd_.p : nullptr);
+  launch_finalize_ranges(d_tpart_.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, d_comp_.p, stream_, any_add ? d_u32 + 3 * nt : nullptr);
   tock();
   if (comp_out) {
     h_comp_.ensure(nt * 48);

@@ -337,7 +337,7 @@ class Engine {
   int fix_bits_cfg_ = 16;    // configured radix of the fixed-base CRS table of multiples: 2^16 (15 GB at ell = 252) or 2^8 (0.1 GB)
   int fix_bits_ = 16;        // radix of the table in use (set_crs falls back to 2^8 when the 2^16 table does not fit in free HBM)
   DevBuf<FixTask> d_ftasks_;
-  DevBuf<uint32_t> d_pfirst_, d_pcount_, d_padd_;
+  DevBuf<uint8_t> d_blob_;   // scalars + task descriptors + ranges of a host-driven table phase, one upload (run_tbl_phase)
 
   // batch
   size_t B_ = 0;

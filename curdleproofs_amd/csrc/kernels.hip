@@ -688,45 +688,46 @@ __global__ __launch_bounds__(64) void k_finalize_ranges(const TJac* __restrict__
   if (out_comp) aff_compress_store(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
 }
 
-// Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per request.  The lanes add the
-// request's partial sums in a tree (log2(count) dependent additions instead of count), lane 0 adds the affine addends;
-// the inversion is shared by the 4 requests of a work-group.
-__global__ __launch_bounds__(256) void k_finalize_ranges_wave(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
-                                                              int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
-                                                              const uint32_t* __restrict__ addends, const uint32_t* __restrict__ comp_index) {
+// Small grids (a few proofs in flight: latency matters, not throughput): one single-wave WORK-GROUP per request.  The lanes add the
+// request's partial sums in a tree (ceil(log2(count)) dependent additions instead of count), lane 0 adds the affine addends, inverts
+// Z and emits the point.  One wave per group on purpose: the four waves of a 256-thread group (the first version: four requests
+// sharing one inversion) were often placed two or more to a SIMD — these 241-VGPR waves then time-share its VALU, and the tree ran
+// 1x ... 2.8x slower from launch to launch (83 ... 229 us for the same 16 partials); single-wave groups spread over the CUs.
+__global__ __launch_bounds__(64) void k_finalize_ranges_wave(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
+                                                             int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
+                                                             const uint32_t* __restrict__ addends, const uint32_t* __restrict__ comp_index) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  TF* buf = reinterpret_cast<TF*>(smem);                                     // 2 * 256 field elements (batch inversion)
-  TJac* red = reinterpret_cast<TJac*>(smem + 2 * 256 * sizeof(TF));          // [256]
-  const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x * 4 + (tid >> 6);
+  TJac* red = reinterpret_cast<TJac*>(smem);   // [64]
+  const int lane = threadIdx.x, g = blockIdx.x;
+  const TJac* src = part + first[g];
+  const uint32_t c = count[g];
   TJac p = TJac::identity();
-  if (g < n) {
-    const TJac* src = part + first[g];
-    const uint32_t c = count[g];
-    for (uint32_t j = lane; j < c; j += 64) p = t_add(p, src[j]);
-  }
-  red[tid] = p;
+  if ((uint32_t)lane < c) p = src[lane];                                  // (no addition to the identity first)
+  for (uint32_t j = lane + 64; j < c; j += 64) p = t_add(p, src[j]);
+  red[lane] = p;
   __syncthreads();
-  for (int sft = 32; sft >= 1; sft >>= 1) {
+  int top = 32;   // lanes >= c hold the identity: start the tree at the smallest power of two that covers c
+  while (top >= 1 && (uint32_t)top >= c) top >>= 1;
+  for (int sft = top; sft >= 1; sft >>= 1) {
     const bool has = lane < sft;
     TJac other;
-    if (has) other = red[tid + sft];
+    if (has) other = red[lane + sft];
     __syncthreads();
     if (has) {
       p = t_add(p, other);
-      red[tid] = p;
+      red[lane] = p;
     }
     __syncthreads();
   }
-  const bool owner = lane == 0 && g < n;
-  if (owner && addends) {
+  if (lane != 0) return;
+  if (addends) {
     for (int j = 0; j < 3; j++) {
       const uint32_t a = addends[3 * g + j];
       if (a != ~0u) p = t_add_mixed(p, t_from_std(out_aff[a]));
     }
   }
   const bool inf = p.is_identity();
-  const TF zinv = t_block_batch_inverse(owner ? p.z : t_one(), buf);
-  if (!owner) return;
+  const TF zinv = inf ? t_one() : t_inv_device(p.z);
   const Aff a = inf ? Aff::identity() : t_to_std(t_to_affine(p, zinv));
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
   if (out_comp) aff_compress_store(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
@@ -1308,8 +1309,7 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
     return e ? atol(e) : 512L;
   }();
   if (n <= wave_max) {   // a few proofs: wave per request (tree over the partial sums)
-    const size_t lds = 2 * 256 * sizeof(TF) + 256 * sizeof(TJac);
-    CPX_LAUNCH(k_finalize_ranges_wave, dim3((n + 3) / 4), dim3(256), lds, s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
+    CPX_LAUNCH(k_finalize_ranges_wave, dim3(n), dim3(64), 64 * sizeof(TJac), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
     return;
   }
   CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);

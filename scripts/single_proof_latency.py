@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import curdleproofs_amd as cpx
 from tests.oracle_lib import Oracle
 orc = Oracle()

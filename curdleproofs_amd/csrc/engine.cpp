@@ -44,6 +44,9 @@ Engine::~Engine() {
   if (side_.ev) (void)hipEventDestroy(side_.ev);
   if (side_.ev2) (void)hipEventDestroy(side_.ev2);
   if (ev_block_) (void)hipEventDestroy(ev_block_);
+  for (hipEvent_t e : {tab_.ev_start, tab_.ev_m, tab_.ev_done})
+    if (e) (void)hipEventDestroy(e);
+  if (tab_.stream) (void)hipStreamDestroy(tab_.stream);
   for (hipEvent_t e : {dprove_.ev_a, dprove_.ev_b, dprove_.ev_c, dprove_.ev_d, dverify_.ev_a, dverify_.ev_b})
     if (e) (void)hipEventDestroy(e);
   if (side_.stream) (void)hipStreamDestroy(side_.stream);
@@ -878,9 +881,20 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(d_dst_.p, dst, B * 4, hipMemcpyHostToDevice, stream_));
     launch_finalize(d_Mjac_.p, (int)B, d_psrc_.p, d_dst_.p, d_mcomp_.p, stream_);
     transcript_prefix_async(B);   // side stream: copies of the compressed bytes for the host's transcripts
-    tick("k_table_build", 0, (double)(B * NP));
-    launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
-    tock();
+    // the per-proof tables on the table stream: M's row first (phase 2 needs it: B = A + alpha M + ...), then T and U (needed from
+    // SameMSM step 1 on), beside phase 1 instead of in front of it
+    if (!tab_.stream) {
+      CPX_HIP(hipStreamCreateWithFlags(&tab_.stream, hipStreamNonBlocking));
+      CPX_HIP(hipEventCreateWithFlags(&tab_.ev_start, hipEventDisableTiming));
+      CPX_HIP(hipEventCreateWithFlags(&tab_.ev_m, hipEventDisableTiming));
+      CPX_HIP(hipEventCreateWithFlags(&tab_.ev_done, hipEventDisableTiming));
+    }
+    CPX_HIP(hipEventRecord(tab_.ev_start, stream_));
+    CPX_HIP(hipStreamWaitEvent(tab_.stream, tab_.ev_start, 0));
+    const size_t tmp_m = B * (size_t)(copies_ / 2 - 1);   // scratch entries of the M launch; the T | U launch takes the rest
+    launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, 1, (int)NP, copies_, true, d_tbltmp_.p, tab_.stream);
+    CPX_HIP(hipEventRecord(tab_.ev_m, tab_.stream));
+    launch_table_build(d_psrc_.p + 1, NP, d_ptab_.p + 1, (int)B, (size_t)copies_ * NP, (int)(2 * n), (int)NP, copies_, true, d_tbltmp_.p + tmp_m, tab_.stream);
     const uint8_t* mcomp = h_mcomp_.p;
     wait_side();
     parallel_for(B, [&](size_t p) {
@@ -960,6 +974,50 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     launch_finalize(side_.res.p, (int)nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
   }
 
+  // -- table stream: B_t = msm(T_b, vec_r), B_u = msm(U_b, vec_r) (same_multiscalar_argument.rs:81-82) right behind the tables of T and U
+  {
+    const size_t nt = 2 * B;
+    const int wpw = msm_tblw_windows_per_wave((int)nt);
+    const uint32_t parts = (uint32_t)msm_tblw_parts(wpw);
+    const size_t b_scal = B * n * sizeof(Fr), b_tt = nt * sizeof(TblTask), b_blob = b_scal + b_tt + 3 * nt * sizeof(uint32_t);
+    tab_.blob.ensure(b_blob);
+    tab_.stage.ensure(b_blob);
+    tab_.raw.ensure(nt * parts * raw_set_words());
+    tab_.rawslot.ensure(nt * parts);
+    tab_.mid.ensure(nt * parts * 16);
+    tab_.part.ensure(nt * parts);
+    tab_.comp.ensure(nt * 48);
+    tab_.hcomp.ensure(nt * 48);
+    Fr* hs = reinterpret_cast<Fr*>(tab_.stage.p);
+    TblTask* ht = reinterpret_cast<TblTask*>(tab_.stage.p + b_scal);
+    uint32_t* hu = reinterpret_cast<uint32_t*>(tab_.stage.p + b_scal + b_tt);
+    const Fr* d_scal = reinterpret_cast<const Fr*>(tab_.blob.p);
+    const uint32_t dummy_dst = slot_index(0, sm.TMP(7));
+    for (size_t p = 0; p < B; p++) {
+      for (size_t i = 0; i < n; i++) hs[p * n + i] = st[p].scal[1][i].f;
+      for (int q = 0; q < 2; q++) {
+        TblTask t;
+        t.seg[0] = pseg(p, q ? O_U : O_T, (uint32_t)n);
+        t.seg[1] = none;
+        t.scalars = d_scal + p * n;
+        t.flags = 0;
+        t.pad = (uint32_t)((2 * p + q) * parts);
+        t.digits = nullptr;
+        ht[2 * p + q] = t;
+        hu[2 * p + q] = (uint32_t)((2 * p + q) * parts);
+        hu[nt + 2 * p + q] = parts;
+        hu[2 * nt + 2 * p + q] = dummy_dst;
+      }
+    }
+    CPX_HIP(hipMemcpyAsync(tab_.blob.p, tab_.stage.p, b_blob, hipMemcpyHostToDevice, tab_.stream));
+    const uint32_t* d_u32 = reinterpret_cast<const uint32_t*>(tab_.blob.p + b_scal + b_tt);
+    launch_msm_tblw(reinterpret_cast<const TblTask*>(tab_.blob.p + b_scal), (int)nt, wpw, tab_.raw.p, tab_.rawslot.p, tab_.stream);
+    launch_reduce_sets(tab_.raw.p, tab_.rawslot.p, 0, (int)(nt * parts), tab_.mid.p, tab_.part.p, tab_.stream);
+    launch_finalize_ranges(tab_.part.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, tab_.comp.p, tab_.stream);
+    CPX_HIP(hipMemcpyAsync(tab_.hcomp.p, tab_.comp.p, nt * 48, hipMemcpyDeviceToHost, tab_.stream));
+    CPX_HIP(hipEventRecord(tab_.ev_done, tab_.stream));
+  }
+
   // -- P1: everything that depends only on vec_a and the prover's randomness
   {
     std::vector<TblReq> reqs;
@@ -971,8 +1029,6 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       const S* rb = &s.scal[2][3];
       reqs.push_back({cseg(0, (uint32_t)n), s.scal[0].data(), none, nullptr, slot_index(p, SL_A)});  // A (kept as a point: B and A' add it)
       reqs.push_back({cseg(0, (uint32_t)n, iGb), s.scal[1].data(), none, nullptr});                   // B_a (same_multiscalar_argument.rs:80)
-      reqs.push_back({pseg(p, O_T, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_t
-      reqs.push_back({pseg(p, O_U, (uint32_t)n), s.scal[1].data(), none, nullptr});                   // B_u
       reqs.push_back({cseg(0, 1, iGt), rt, none, nullptr, slot_index(p, SL_CMT1)});                   // cm_T.T_1 = r_t G_t
       reqs.push_back({cseg(0, 1, iGu), ru, none, nullptr, slot_index(p, SL_CMU1)});                   // cm_U.T_1
       reqs.push_back({cseg(0, 1, iGt), ra, none, nullptr});                                           // cm_A.T_1
@@ -987,9 +1043,9 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
-      const int ids[13] = {SL_A, sm.BA(), sm.BT(), sm.BU(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), -1, -1, -1, -1, SL_BC};
-      for (int i = 0; i < 13; i++)
-        if (ids[i] >= 0) take(p, ids[i], p * 13 + i);
+      const int ids[11] = {SL_A, sm.BA(), SL_CMT1, SL_CMU1, sm.CMA1(), sm.CMB1(), -1, -1, -1, -1, SL_BC};
+      for (int i = 0; i < 11; i++)
+        if (ids[i] >= 0) take(p, ids[i], p * 11 + i);
       // same_permutation_argument.rs:60-83
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_A * 48]);
       s.tr.append_point_bytes("same_perm_step1", &s.comp[SL_M * 48]);
@@ -1052,6 +1108,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       reqs.push_back(ra);
       reqs.push_back({cseg(0, (uint32_t)n), st[p].c.data(), none, nullptr});
     }
+    CPX_HIP(hipStreamWaitEvent(stream_, tab_.ev_m, 0));   // M's table row (table stream)
     run_tbl_phase(reqs, &comp);
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
@@ -1210,8 +1267,15 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     std::vector<uint8_t> id_comp(48, 0);
     id_comp[0] = 0xc0;
     wait_side();   // R, S and the four T_2 commitments from the side stream
+    {
+      HostSpan w(this, "host_wait_device");
+      CPX_HIP(hipEventSynchronize(tab_.ev_done));   // the tables of T and U, B_t and B_u from the table stream
+    }
+    CPX_HIP(hipStreamWaitEvent(stream_, tab_.ev_done, 0));
     parallel_for(B, [&](size_t p) {
       ProverState& s = st[p];
+      memcpy(&s.comp[(size_t)sm.BT() * 48], tab_.hcomp.p + (2 * p) * 48, 48);
+      memcpy(&s.comp[(size_t)sm.BU() * 48], tab_.hcomp.p + (2 * p + 1) * 48, 48);
       memcpy(s.c_final.f.v, &h_rfin_.p[3 * p], sizeof(Fr));       // c[0], d[0] after the last fold (device-resident vectors)
       memcpy(s.d_final.f.v, &h_rfin_.p[3 * p + 1], sizeof(Fr));
       const int side_slots[6] = {SL_R, SL_S, SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2()};

@@ -205,6 +205,20 @@ class Engine {
     PinBuf<uint8_t> stage, hcomp;
   };
   SideBufs side_;
+  // third stream of the host-driven prover: the per-proof tables of T and U and the two commitments that need them first (B_t, B_u of
+  // SameMSM step 1) are not on the critical path of a lone proof until the SameMSM transcript step — they run here, beside phases 1..3
+  // and the IPA rounds
+  struct TabBufs {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_m = nullptr, ev_done = nullptr;   // M finalised (main) / M's table row built / B_t, B_u compressed
+    DevBuf<uint8_t> blob;      // vec_r scalars | TblTask | first | count | dst
+    PinBuf<uint8_t> stage;
+    DevBuf<uint32_t> raw, rawslot;
+    DevBuf<TJac> mid, part;
+    DevBuf<uint8_t> comp;
+    PinBuf<uint8_t> hcomp;
+  };
+  TabBufs tab_;
   struct Timed {
     hipEvent_t a, b;
     std::string name;

@@ -638,6 +638,7 @@ def test_large_batch_four_contexts_every_proof_matches_oracle(orc):
         insts = list(ex.map(lambda s: orc.make_instance(ell, 5000 + s, crs), range(N)))
     per = N // K
     errors = []
+    partials, partials_bad = [None] * K, [None] * K
 
     def run(k):
         try:
@@ -665,6 +666,12 @@ def test_large_batch_four_contexts_every_proof_matches_oracle(orc):
                 want[j] = {1: cpx.CPX_OK, 0: cpx.CPX_ERR_VERIFY, -1: cpx.CPX_ERR_DESERIALIZE}[o]
             if got != want:
                 errors.append("context %d: verdicts differ at %s" % (k, [j for j in range(per) if got[j] != want[j]][:8]))
+            # BASELINE config 5 at this scale: the context's share of ONE accumulated check over all N proofs (12 factors per proof);
+            # the four partial sums are added below like the all-gather step does
+            frand = orc.rng(9000 + k).fr(12 * per)
+            good = [i["proof"] for i in mine]
+            partials[k] = c.verify_batch_fused_partial(good, frand)
+            partials_bad[k] = c.verify_batch_fused_partial(proofs, frand) if k == 2 else partials[k]   # context 2 holds three wrong proofs
             c.close()
         except Exception as e:   # surfaced below (an exception in a thread would otherwise be lost)
             errors.append("context %d: %r" % (k, e))
@@ -675,6 +682,10 @@ def test_large_batch_four_contexts_every_proof_matches_oracle(orc):
     for t in th:
         t.join()
     assert not errors, errors
+    c = cpx.Context(0)
+    assert all(b == 0 for _, b in partials)
+    assert c.sum_jac(b"".join(p for p, _ in partials))[1], "the partial sums of %d valid proofs on four contexts must add up to the identity" % N
+    assert not c.sum_jac(b"".join(p for p, _ in partials_bad))[1]
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -697,3 +708,36 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["all_verified"] is True and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 256 and d["config"]["batch_per_gpu"] == 128
     assert abs(d["value"] - 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("copies", [1, 33], ids=["host_driven", "device_resident"])
+def test_instances_with_identity_points_and_repeated_points(ctx, orc, copies):
+    """Edge instances the reference accepts as inputs: a ciphertext whose components are the point at infinity (R_i = S_i = O, hence an
+    identity column in the per-proof tables of T and U, an identity base in the R / S MSMs and a 0xc0 encoding in the hashed instance)
+    and two identical ciphertexts (equal bases next to each other in every bucket list).  Proof bytes and verdicts must equal the
+    oracle's, on the host-driven path (one proof) and on the device-resident path (33 copies of the instance)."""
+    import curdleproofs_amd as cpx
+    ell = 28
+    crs = orc.generate_crs_points(ell)
+    base = orc.make_instance(ell, 4242, crs)
+    R, S = bytearray(base["vec_R"]), bytearray(base["vec_S"])
+    perm = list(base["permutation"])
+    i0 = next(i for i in range(ell) if perm.index(i) != 0)            # its image must not land on T[0] (curdleproofs.rs:218 would reject)
+    R[i0 * AFF:(i0 + 1) * AFF] = bytes(AFF)
+    S[i0 * AFF:(i0 + 1) * AFF] = bytes(AFF)
+    a, b = [i for i in range(ell) if i != i0][:2]
+    R[b * AFF:(b + 1) * AFF] = R[a * AFF:(a + 1) * AFF]               # two identical ciphertexts
+    S[b * AFF:(b + 1) * AFF] = S[a * AFF:(a + 1) * AFF]
+    R, S = bytes(R), bytes(S)
+    T, U, M = orc.shuffle_permute_and_commit_input(ell, crs, R, S, perm, base["k"], base["vec_m_blinders"])
+    want = orc.prove(ell, crs, R, S, T, U, M, perm, base["k"], base["vec_m_blinders"], base["prover_rand"])
+    assert orc.verify(ell, crs, R, S, T, U, M, want, base["verifier_rand"]) == 1
+    ctx.set_crs(ell, crs)
+    ctx.load_batch(R * copies, S * copies, T * copies, U * copies, M * copies)
+    proofs = ctx.prove_batch(perm * copies, base["k"] * copies, base["vec_m_blinders"] * copies, base["prover_rand"] * copies)
+    assert all(p == want for p in proofs)
+    assert ctx.verify_batch(proofs, base["verifier_rand"] * copies) == [cpx.CPX_OK] * copies
+    # the same proof against the unmodified instance must fail, as it does for the oracle
+    ctx.load_batch(base["vec_R"] * copies, base["vec_S"] * copies, base["vec_T"] * copies, base["vec_U"] * copies, base["M"] * copies)
+    assert orc.verify(ell, crs, base["vec_R"], base["vec_S"], base["vec_T"], base["vec_U"], base["M"], want, base["verifier_rand"]) == 0
+    assert ctx.verify_batch(proofs, base["verifier_rand"] * copies) == [cpx.CPX_ERR_VERIFY] * copies

@@ -831,6 +831,46 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const T
   else out[t] = acc;
 }
 
+// A few outputs (a lone proof's verification, tier-0 MSMs): one wave per output.  Lane j adds the `dup` inputs of weight 2^(shift j) and
+// shifts its sum by shift * j doublings on its own — the doublings of the 16 windows run side by side instead of one after the other in
+// a Horner chain — then the lanes (and the extra partial sums, one lane each) are added in a tree: shift * (group - 1) doublings and
+// ~6 additions deep instead of shift * (group - 1) doublings and (dup * group + extra) additions (1.6 ms -> 1.1 ms for the verifier's
+// 16 x 2 + 8 partial sums).
+template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail_wave(const TJac* __restrict__ in, TJac* __restrict__ out, Jac* __restrict__ out_std,
+                                                                              int group, int shift, const TJac* __restrict__ extra, int extra_per_out, int dup) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  TJac* red = reinterpret_cast<TJac*>(smem);   // [64]
+  const int t = blockIdx.x, lane = threadIdx.x;
+  TJac acc = TJac::identity();
+  if (lane < group) {
+    const TJac* src = in + ((size_t)t * group + lane) * dup;
+    acc = src[0];
+    for (int d = 1; d < dup; d++) acc = t_add(acc, src[d]);
+    for (int s = 0; s < shift * lane; s++) acc = t_dbl(acc);
+  } else if (lane < group + extra_per_out) {
+    acc = extra[(size_t)t * extra_per_out + (lane - group)];
+  }
+  red[lane] = acc;
+  __syncthreads();
+  const int c = group + extra_per_out;
+  int top = 32;
+  while (top >= 1 && top >= c) top >>= 1;
+  for (int sft = top; sft >= 1; sft >>= 1) {
+    const bool has = lane < sft;
+    TJac other;
+    if (has) other = red[lane + sft];
+    __syncthreads();
+    if (has) {
+      acc = t_add(acc, other);
+      red[lane] = acc;
+    }
+    __syncthreads();
+  }
+  if (lane != 0) return;
+  if (STD_OUT) out_std[t] = t_jac_to_std(acc);
+  else out[t] = acc;
+}
+
 // ------------------------------------------------------------------ normalise + compress
 // Thread per point: Jacobian -> affine (one inversion per work-group) and, optionally, the 48-byte
 // compressed encoding the transcript and the proof bytes need.
@@ -1198,6 +1238,16 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_con
 }
 void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra, int extra_per_out, int dup) {
   if (nout <= 0) return;
+  static const long wave_max = [] {   // CPX_TAIL_WAVE_MAX moves the switch-over (tests reach both forms with small inputs)
+    const char* e = getenv("CPX_TAIL_WAVE_MAX");
+    return e ? atol(e) : 256L;
+  }();
+  if (nout <= wave_max && shift > 0 && group + extra_per_out <= 64) {   // a few outputs: wave per output, windows shifted side by side
+    const size_t lds = 64 * sizeof(TJac);
+    if (d_out_std) CPX_LAUNCH(k_msm_tail_wave<true>, dim3(nout), dim3(64), lds, s, d_in, d_out, d_out_std, group, shift, d_extra, extra_per_out, dup);
+    else CPX_LAUNCH(k_msm_tail_wave<false>, dim3(nout), dim3(64), lds, s, d_in, d_out, d_out_std, group, shift, d_extra, extra_per_out, dup);
+    return;
+  }
   if (d_out_std) CPX_LAUNCH(k_msm_tail<true>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out, dup);
   else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out, dup);
 }

@@ -509,8 +509,8 @@ def test_fused_batch_verifier_many_points(ctx, orc, ell, nproofs):
 # thread-per-group reductions (k_reduce_sets / k_reduce_groups) and the thread-per-request k_finalize_ranges, none of which
 # a batch of a few proofs reaches.  THROUGHPUT_ENV moves every switch-over so that small batches run exactly those
 # instantiations (kernels.hip: msm_fix_windows_per_wave, msm_tblw_windows_per_wave, launch_reduce_sets,
-# launch_finalize_ranges).
-THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAVE_MAX": "0", "CPX_FINALIZE_WAVE_MAX": "0"}
+# launch_finalize_ranges, launch_msm_tail).
+THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAVE_MAX": "0", "CPX_FINALIZE_WAVE_MAX": "0", "CPX_TAIL_WAVE_MAX": "0"}
 
 
 @pytest.mark.parametrize("env", [{"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_MIN_BATCH": "1"}, {"CPX_DEVICE_MIN_BATCH": "1000000"}, THROUGHPUT_ENV,

@@ -29,6 +29,7 @@
 #include <hip/hip_ext.h>
 #include "g1.hpp"
 #include "g1_28.hpp"
+#include "g1_28_quad.hpp"
 #include "strobe.hpp"
 #include "wave_strobe.hpp"
 #include "recode.hpp"
@@ -311,49 +312,134 @@ template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_groups(c
   part[slot[set]] = v;
 }
 
-// Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per set, the classic tree — suffix
-// scan (weighted sets) + tree sum, 6 + 6 dependent additions instead of the ~40 of the work-efficient form above.
+// Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per set and every point addition spread over the
+// four lanes of a quad (g1_28_quad.hpp: 6 us instead of 18-20 us per dependent addition), 16 additions per wave and round.  The
+// rounds of a set are a fixed PROGRAM of (operand, operand, destination) jobs over an array of points in LDS, one job per quad:
+//   plain    (k_msm_fix):  the tree over 64 lanes, 32 + 16 + ... + 1 additions in 7 rounds.
+//   weighted (k_msm_tblw): sum_l (l + 1) A_l with l = 8 a + b is 8 sum_a a R_a + sum_b (b + 1) C_b over the row sums R_a and the
+//            column sums C_b of the 8 x 8 arrangement (three tree levels for both, 7 rounds); a weighted sum of EIGHT points is,
+//            bit by bit of the weights, three sums of four points (2 rounds), so that seven points with weights 2^0 .. 2^6 remain
+//            (2^6: the plain sum, for the upper half of the magnitudes): shifted side by side (<= 6 doubling rounds) and added in a
+//            tree (3 rounds).  13 addition + 6 doubling rounds, ~105 us, against the 12 + 1 additions and 6 doublings of one lane
+//            each (~310 us) of the scan + tree this replaces.
+struct QuadJob {
+  uint8_t a, b, dst, on;
+};
+constexpr int QP_ROW = 64, QP_COL = 96, QP_T = 128, QP_P = 140, QP_IDENT = 144, QP_ENTRIES = 145, QP_MAX_ROUNDS = 20;
+struct QuadProgram {
+  int nrounds;
+  int result;
+  uint8_t dbl[QP_MAX_ROUNDS];
+  QuadJob job[QP_MAX_ROUNDS][16];
+};
+constexpr void qp_level(QuadProgram& p, const QuadJob* jobs, int n, bool dbl) {
+  for (int base = 0; base < n; base += 16) {
+    for (int q = 0; q < 16; q++) p.job[p.nrounds][q] = base + q < n ? jobs[base + q] : QuadJob{(uint8_t)QP_IDENT, (uint8_t)QP_IDENT, (uint8_t)QP_IDENT, 0};
+    p.dbl[p.nrounds++] = dbl;
+  }
+}
+constexpr QuadJob qp_job(int a, int b, int dst) { return QuadJob{(uint8_t)a, (uint8_t)b, (uint8_t)dst, 1}; }
+constexpr QuadProgram qp_plain() {
+  QuadProgram p{};
+  QuadJob jobs[32]{};
+  for (int m = 32; m >= 1; m >>= 1) {
+    for (int j = 0; j < m; j++) jobs[j] = qp_job(j, j + m, j);
+    qp_level(p, jobs, m, false);
+  }
+  p.result = 0;
+  return p;
+}
+// element i (0..3) of the numbers 0..7 with bit k set
+constexpr int qp_with_bit(int i, int k) { return ((i >> k) << (k + 1)) | (1 << k) | (i & ((1 << k) - 1)); }
+constexpr QuadProgram qp_weighted(bool upper) {
+  QuadProgram p{};
+  QuadJob jobs[64]{};
+  for (int j = 0; j < 32; j++) {   // rows: A[8a+b] + A[8a+b+4]; columns: A[8a+b] + A[8(a+4)+b]
+    jobs[j] = qp_job(8 * (j >> 2) + (j & 3), 8 * (j >> 2) + (j & 3) + 4, QP_ROW + j);
+    jobs[32 + j] = qp_job(8 * (j >> 3) + (j & 7), 8 * ((j >> 3) + 4) + (j & 7), QP_COL + j);
+  }
+  qp_level(p, jobs, 64, false);
+  for (int j = 0; j < 16; j++) {
+    const int r = QP_ROW + 4 * (j >> 1) + (j & 1), c = QP_COL + 8 * (j >> 3) + (j & 7);
+    jobs[j] = qp_job(r, r + 2, r);
+    jobs[16 + j] = qp_job(c, c + 16, c);
+  }
+  qp_level(p, jobs, 32, false);
+  for (int j = 0; j < 8; j++) {    // R_a = ROW[4a], C_b = COL[b]
+    jobs[j] = qp_job(QP_ROW + 4 * j, QP_ROW + 4 * j + 1, QP_ROW + 4 * j);
+    jobs[8 + j] = qp_job(QP_COL + j, QP_COL + 8 + j, QP_COL + j);
+  }
+  qp_level(p, jobs, 16, false);
+  // bit sums: T[2g] = sum of the four R_a with bit g of a set (g < 3), of the four C_(w-1) with bit g - 3 of w set (w = 1..7)
+  int n = 0;
+  for (int g = 0; g < 6; g++)
+    for (int h = 0; h < 2; h++) {
+      const int k = g % 3, e0 = qp_with_bit(2 * h, k), e1 = qp_with_bit(2 * h + 1, k);
+      jobs[n++] = g < 3 ? qp_job(QP_ROW + 4 * e0, QP_ROW + 4 * e1, QP_T + 2 * g + h) : qp_job(QP_COL + e0 - 1, QP_COL + e1 - 1, QP_T + 2 * g + h);
+    }
+  if (upper) for (int a = 0; a < 4; a++) jobs[n++] = qp_job(QP_ROW + 4 * a, QP_ROW + 4 * (a + 4), QP_P + a);   // the plain sum
+  qp_level(p, jobs, n, false);
+  n = 0;
+  for (int g = 0; g < 6; g++) jobs[n++] = qp_job(QP_T + 2 * g, QP_T + 2 * g + 1, QP_T + 2 * g);
+  if (upper) for (int a = 0; a < 2; a++) jobs[n++] = qp_job(QP_P + a, QP_P + a + 2, QP_P + a);
+  qp_level(p, jobs, n, false);
+  n = 0;
+  jobs[n++] = qp_job(QP_T + 0, QP_COL + 7, QP_T + 0);   // weight 8: R-bit 0 and C_7
+  if (upper) jobs[n++] = qp_job(QP_P + 0, QP_P + 1, QP_P + 0);
+  qp_level(p, jobs, n, false);
+  // weights 2^0 .. 2^6 at T[6], T[8], T[10], T[0], T[2], T[4], P[0]
+  const int loc[7] = {QP_T + 6, QP_T + 8, QP_T + 10, QP_T + 0, QP_T + 2, QP_T + 4, QP_P + 0};
+  const int nitems = upper ? 7 : 6;
+  for (int sft = 0; sft < nitems - 1; sft++) {
+    n = 0;
+    for (int w = sft + 1; w < nitems; w++) jobs[n++] = qp_job(loc[w], loc[w], loc[w]);
+    qp_level(p, jobs, n, true);
+  }
+  n = 0;
+  jobs[n++] = qp_job(loc[0], loc[1], loc[0]);
+  jobs[n++] = qp_job(loc[2], loc[3], loc[2]);
+  jobs[n++] = qp_job(loc[4], loc[5], loc[4]);
+  qp_level(p, jobs, n, false);
+  n = 0;
+  jobs[n++] = qp_job(loc[0], loc[2], loc[0]);
+  if (upper) jobs[n++] = qp_job(loc[4], loc[6], loc[4]);
+  qp_level(p, jobs, n, false);
+  jobs[0] = qp_job(loc[0], loc[4], loc[0]);
+  qp_level(p, jobs, 1, false);
+  p.result = loc[0];
+  return p;
+}
+__constant__ QuadProgram c_quad_prog[3] = {qp_plain(), qp_weighted(false), qp_weighted(true)};
+
+// One round per iteration: quad q of the wave runs job(q) — the SAME code for every round, a few KB that stay in the
+// instruction cache.  `dbl` must be uniform over the wave.
+template <class JobFn> __device__ __forceinline__ void quad_exec(TAcc* buf, int nrounds, JobFn fn) {
+  const int quad = threadIdx.x >> 2, sub = threadIdx.x & 3;
+  for (int r = 0; r < nrounds; r++) {
+    bool dbl = false;
+    const QuadJob jb = fn(r, quad, dbl);
+    TAcc res;
+    if (dbl) res = xyzz28_dbl_quad(buf[jb.a]);
+    else res = xyzz28_add_quad_mem(buf, jb.a, jb.b);
+    if (jb.on && sub == 0) buf[jb.dst] = res;
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(64) void k_reduce_sets_wave(const uint32_t* __restrict__ raw, const uint32_t* __restrict__ slot, int nplain, TJac* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  TJac* red = reinterpret_cast<TJac*>(smem);   // [65]
+  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [QP_ENTRIES]
   const int set = blockIdx.x, lane = threadIdx.x;
-  const bool WEIGHTED = set >= nplain;   // sets [0, nplain) are plain (k_msm_fix), the rest bucket sets (k_msm_tblw), lower / upper half alternating
-  TJac acc = t_acc_to_jac(raw_load(raw + (size_t)set * RAW_SET_WORDS, lane));
-  red[lane] = acc;
+  // sets [0, nplain) are plain (k_msm_fix), the rest bucket sets (k_msm_tblw), lower / upper half of the magnitudes alternating
+  const QuadProgram& prog = c_quad_prog[set < nplain ? 0 : 1 + ((set - nplain) & 1)];
+  buf[lane] = raw_load(raw + (size_t)set * RAW_SET_WORDS, lane);
+  if (lane == 0) buf[QP_IDENT] = TAcc::identity();
   __syncthreads();
-  if (WEIGHTED) {
-    for (int sft = 1; sft < 64; sft <<= 1) {        // suffix sums S_l = A_l + ... + A_63
-      const bool has = lane + sft < 64;
-      TJac other;
-      if (has) other = red[lane + sft];
-      __syncthreads();
-      if (has) {
-        acc = t_add(acc, other);
-        red[lane] = acc;
-      }
-      __syncthreads();
-    }
-    if (lane == 0) red[64] = acc;                   // the plain sum
-  }
-  for (int sft = 32; sft >= 1; sft >>= 1) {         // tree sum (of the suffix sums: sum_l (l + 1) A_l)
-    const bool has = lane < sft;
-    TJac other;
-    if (has) other = red[lane + sft];
-    __syncthreads();
-    if (has) {
-      acc = t_add(acc, other);
-      red[lane] = acc;
-    }
-    __syncthreads();
-  }
-  if (lane == 0) {
-    if (WEIGHTED && ((set - nplain) & 1)) {         // upper half: magnitudes 64 + (l + 1)
-      TJac plain = red[64];
-      for (int d = 0; d < 6; d++) plain = t_dbl(plain);
-      acc = t_add(acc, plain);
-    }
-    part[slot[set]] = acc;
-  }
+  quad_exec(buf, prog.nrounds, [&](int r, int quad, bool& dbl) {
+    dbl = prog.dbl[r] != 0;
+    return prog.job[r][quad];
+  });
+  if (lane == 0) part[slot[set]] = t_acc_to_jac(buf[prog.result]);
 }
 
 // ------------------------------------------------------------------ table-backed MSM, barrier-free single-wave groups
@@ -688,38 +774,51 @@ __global__ __launch_bounds__(64) void k_finalize_ranges(const TJac* __restrict__
   if (out_comp) aff_compress_store(a, out_comp + (size_t)(comp_index ? comp_index[g] : (uint32_t)g) * 48);
 }
 
-// Small grids (a few proofs in flight: latency matters, not throughput): one single-wave WORK-GROUP per request.  The lanes add the
-// request's partial sums in a tree (ceil(log2(count)) dependent additions instead of count), lane 0 adds the affine addends, inverts
-// Z and emits the point.  One wave per group on purpose: the four waves of a 256-thread group (the first version: four requests
-// sharing one inversion) were often placed two or more to a SIMD — these 241-VGPR waves then time-share its VALU, and the tree ran
-// 1x ... 2.8x slower from launch to launch (83 ... 229 us for the same 16 partials); single-wave groups spread over the CUs.
+// Small grids (a few proofs in flight: latency matters, not throughput): one single-wave WORK-GROUP per request.  The quads of the
+// wave add the request's partial sums in a tree (ceil(log2(count)) rounds of quad additions, 6 us each, instead of count additions
+// of 18-20 us), lane 0 adds the affine addends, inverts Z and emits the point.  One wave per group on purpose: the four waves of a
+// 256-thread group (the first version: four requests sharing one inversion) were often placed two or more to a SIMD — these
+// 241-VGPR waves then time-share its VALU, and the tree ran 1x ... 2.8x slower from launch to launch (83 ... 229 us for the same
+// 16 partials); single-wave groups spread over the CUs.
 __global__ __launch_bounds__(64) void k_finalize_ranges_wave(const TJac* __restrict__ part, const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
                                                              int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
                                                              const uint32_t* __restrict__ addends, const uint32_t* __restrict__ comp_index) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  TJac* red = reinterpret_cast<TJac*>(smem);   // [64]
+  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [65]: 64 sums + the identity for idle quads
   const int lane = threadIdx.x, g = blockIdx.x;
   const TJac* src = part + first[g];
   const uint32_t c = count[g];
-  TJac p = TJac::identity();
-  if ((uint32_t)lane < c) p = src[lane];                                  // (no addition to the identity first)
-  for (uint32_t j = lane + 64; j < c; j += 64) p = t_add(p, src[j]);
-  red[lane] = p;
-  __syncthreads();
-  int top = 32;   // lanes >= c hold the identity: start the tree at the smallest power of two that covers c
-  while (top >= 1 && (uint32_t)top >= c) top >>= 1;
-  for (int sft = top; sft >= 1; sft >>= 1) {
-    const bool has = lane < sft;
-    TJac other;
-    if (has) other = red[lane + sft];
-    __syncthreads();
-    if (has) {
-      p = t_add(p, other);
-      red[lane] = p;
-    }
-    __syncthreads();
+  {
+    TJac p = TJac::identity();
+    if ((uint32_t)lane < c) p = src[lane];                                  // (no addition to the identity first)
+    for (uint32_t j = lane + 64; j < c; j += 64) p = t_add(p, src[j]);
+    buf[lane] = xyzz28_from_jac(p);
+    if (lane == 0) buf[64] = TAcc::identity();
   }
+  __syncthreads();
+  // level by level: live entries [0, m); top = the largest power of two below m; entries [top, m) fold onto [0, m - top)
+  int m = c < 64 ? (int)c : 64, nrounds = 0;
+  for (int mm = m; mm > 1;) {
+    int top = 1;
+    while (top * 2 < mm) top *= 2;
+    nrounds += (mm - top + 15) / 16;
+    mm = top;
+  }
+  int top = 1, done = 0;
+  if (m > 1) while (top * 2 < m) top *= 2;
+  quad_exec(buf, nrounds, [&](int, int quad, bool&) {
+    const int j = done + quad, njobs = m - top;
+    const QuadJob jb = j < njobs ? QuadJob{(uint8_t)j, (uint8_t)(j + top), (uint8_t)j, 1} : QuadJob{64, 64, 64, 0};
+    done += 16;
+    if (done >= njobs) {   // next level
+      m = top;
+      top = top > 1 ? top / 2 : 1;
+      done = 0;
+    }
+    return jb;
+  });
   if (lane != 0) return;
+  TJac p = t_acc_to_jac(buf[0]);
   if (addends) {
     for (int j = 0; j < 3; j++) {
       const uint32_t a = addends[3 * g + j];
@@ -1306,7 +1405,7 @@ void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int n
     return e ? atol(e) : 2048L;
   }();
   if (nsets <= wave_max) {   // a few proofs: wave per set, both kinds in one launch
-    CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), 65 * sizeof(TJac), s, d_raw, d_raw_slot, nplain, d_part);
+    CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), QP_ENTRIES * sizeof(TAcc), s, d_raw, d_raw_slot, nplain, d_part);
     return;
   }
   const dim3 block(64);
@@ -1359,7 +1458,7 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
     return e ? atol(e) : 512L;
   }();
   if (n <= wave_max) {   // a few proofs: wave per request (tree over the partial sums)
-    CPX_LAUNCH(k_finalize_ranges_wave, dim3(n), dim3(64), 64 * sizeof(TJac), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
+    CPX_LAUNCH(k_finalize_ranges_wave, dim3(n), dim3(64), 65 * sizeof(TAcc), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
     return;
   }
   CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);

@@ -931,39 +931,49 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   auto take = [&](size_t p, int slot_id, size_t req_index) { memcpy(&st[p].comp[(size_t)slot_id * 48], &comp[req_index * 48], 48); };
 
   // -- side stream: R = a x vec_R and S = a x vec_S (curdleproofs.rs:112-113).  The instance points R_i, S_i are
-  //    used by exactly these two MSMs, so they get no table: plain Pippenger (k_msm_accum + tails) off the
+  //    used by exactly these MSMs, so they get no table: the endomorphism bucket-list kernel (the verifier's) + tails off the
   //    critical path; the affine results land in the slots SL_R / SL_S.
+  //    The four scalar multiplications k R, k S (curdleproofs.rs:115-116), r_k R, r_k S (same_scalar_argument.rs:60-61) ride along
+  //    as four more MSMs over the same points with the scalars k a and r_k a: k (a x vec_R) = (k a) x vec_R.  A 255-bit
+  //    double-and-add chain of one lane (k_smul: 4.6 ms) was what a lone proof waited for at the SameScalar step; as MSM tasks
+  //    they run beside R and S and finish with them.
   const int CW0 = SL_CMT1, CWN = sm.CMB2() - SL_CMT1 + 1;   // slot window compressed on the side stream
   {
-    const size_t nt = 2 * B, total = B * ell;
-    side_.scal.ensure(total + 2 * B);
+    const size_t nt = 6 * B, total = B * ell;
+    side_.scal.ensure(3 * total);
     side_.tasks.ensure(nt);
-    side_.stasks.ensure(4 * B);
     side_.res.ensure(nt);
-    side_.dst.ensure(nt);
+    side_.dst.ensure(2 * nt);
     side_.comp.ensure(B * (size_t)CWN * 48);
     side_.hcomp.ensure(B * (size_t)CWN * 48);
-    const size_t o_tasks = (total + 2 * B) * sizeof(Fr), o_dst = o_tasks + nt * sizeof(MsmTask), o_st = o_dst + nt * sizeof(uint32_t);
-    side_.stage.ensure(o_st + 4 * B * sizeof(SmulTask));
+    const size_t o_tasks = 3 * total * sizeof(Fr), o_dst = o_tasks + nt * sizeof(MsmTask);
+    side_.stage.ensure(o_dst + 2 * nt * sizeof(uint32_t));
     Fr* hs = reinterpret_cast<Fr*>(side_.stage.p);
     MsmTask* ht = reinterpret_cast<MsmTask*>(side_.stage.p + o_tasks);
-    uint32_t* hd = reinterpret_cast<uint32_t*>(side_.stage.p + o_dst);
+    uint32_t* hd = reinterpret_cast<uint32_t*>(side_.stage.p + o_dst);   // [nt] destination slots, [nt] addend slots
     parallel_for(B, [&](size_t p) {
-      for (size_t i = 0; i < ell; i++) hs[p * ell + i] = st[p].vec_a[i].f;
-      hs[total + 2 * p] = st[p].scal[3][0].f;       // k
-      hs[total + 2 * p + 1] = st[p].scal[3][1].f;   // r_k
-      ht[2 * p] = MsmTask{pp(p), nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0, (uint32_t)(2 * p * ell)};
-      ht[2 * p + 1] = MsmTask{pp(p) + ell, nullptr, side_.scal.p + p * ell, (uint32_t)ell, 0, (uint32_t)((2 * p + 1) * ell)};
-      hd[2 * p] = slot_index(p, SL_R);
-      hd[2 * p + 1] = slot_index(p, SL_S);
+      const S kk = st[p].scal[3][0], r_k = st[p].scal[3][1];
+      for (size_t i = 0; i < ell; i++) {
+        hs[p * ell + i] = st[p].vec_a[i].f;
+        hs[total + p * ell + i] = (st[p].vec_a[i] * kk).f;
+        hs[2 * total + p * ell + i] = (st[p].vec_a[i] * r_k).f;
+      }
+      // tasks [0, 2B): R, S; tasks [2B, 6B): k R, k S, r_k R, r_k S (finalised later, on top of the r H points of phase 1)
+      const int dsts[6] = {SL_R, SL_S, SL_CMT2, SL_CMU2, sm.CMA2(), sm.CMB2()};
+      for (int j = 0; j < 6; j++) {
+        const size_t t = j < 2 ? 2 * p + j : 2 * B + 4 * p + (j - 2);
+        const Fr* sc = side_.scal.p + (size_t)(j / 2) * total + p * ell;
+        ht[t] = MsmTask{pp(p) + (j & 1) * ell, nullptr, sc, (uint32_t)ell, 0, (uint32_t)(t * ell)};
+        hd[t] = slot_index(p, dsts[j]);
+        hd[nt + t] = j < 2 ? ~0u : slot_index(p, sm.TMP(j - 2));
+      }
     });
-    CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, (total + 2 * B) * sizeof(Fr), hipMemcpyHostToDevice, side_.stream));
+    CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, 3 * total * sizeof(Fr), hipMemcpyHostToDevice, side_.stream));
     CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, side_.stream));
-    CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, nt * sizeof(uint32_t), hipMemcpyHostToDevice, side_.stream));
-    // endomorphism split + radix-256 bucket lists per window (the verifier's kernel), 32 additions per point instead of 60
-    side_.conv.ensure(4 * total);   // 2 tasks per proof, points and images
+    CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, 2 * nt * sizeof(uint32_t), hipMemcpyHostToDevice, side_.stream));
+    side_.conv.ensure(2 * nt * ell);   // per task: points and images
     side_.ttasks.ensure(nt);
-    side_.digits.ensure(9 * 2 * total);
+    side_.digits.ensure(9 * nt * ell);
     side_.raw.ensure(nt * 32 * raw_set_words());
     side_.rawslot.ensure(nt * 32);
     side_.mid.ensure(nt * 32 * 16);
@@ -971,7 +981,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
     launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nt * 32, side_.mid.p, side_.part.p, side_.stream);
     launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, side_.stream, nullptr, 0, 2);
-    launch_finalize(side_.res.p, (int)nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
+    launch_finalize(side_.res.p, (int)(2 * B), d_pp_.p, side_.dst.p, nullptr, side_.stream);
   }
 
   // -- table stream: B_t = msm(T_b, vec_r), B_u = msm(U_b, vec_r) (same_multiscalar_argument.rs:81-82) right behind the tables of T and U
@@ -1073,21 +1083,11 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   }
 
   // -- side stream: cm_T.T_2 = k R + r_t H, cm_U.T_2 = k S + r_u H (curdleproofs.rs:115-116), cm_A.T_2 = r_k R + r_a H,
-  //    cm_B.T_2 = r_k S + r_b H (same_scalar_argument.rs:60-61): four scalar multiplications of R / S per proof
-  //    (k_smul) on top of the r*H points phase 1 left in TMP0..3; needed only at the SameScalar transcript step.
+  //    cm_B.T_2 = r_k S + r_b H (same_scalar_argument.rs:60-61): the four MSM results of the side stream on top of the r*H points
+  //    phase 1 left in TMP0..3 (complete by now: the host has taken phase 1's results); needed only at the SameScalar transcript step.
   {
-    const size_t total = B * ell;
-    const size_t o_st = (total + 2 * B) * sizeof(Fr) + 2 * B * sizeof(MsmTask) + 2 * B * sizeof(uint32_t);
-    SmulTask* hst = reinterpret_cast<SmulTask*>(side_.stage.p + o_st);
-    for (size_t p = 0; p < B; p++) {
-      const Fr* kk = side_.scal.p + total + 2 * p;
-      hst[4 * p + 0] = SmulTask{slot(p, sm.TMP(0)), slot(p, SL_R), slot(p, SL_CMT2), kk, 0, 0};
-      hst[4 * p + 1] = SmulTask{slot(p, sm.TMP(1)), slot(p, SL_S), slot(p, SL_CMU2), kk, 0, 0};
-      hst[4 * p + 2] = SmulTask{slot(p, sm.TMP(2)), slot(p, SL_R), slot(p, sm.CMA2()), kk + 1, 0, 0};
-      hst[4 * p + 3] = SmulTask{slot(p, sm.TMP(3)), slot(p, SL_S), slot(p, sm.CMB2()), kk + 1, 0, 0};
-    }
-    CPX_HIP(hipMemcpyAsync(side_.stasks.p, hst, 4 * B * sizeof(SmulTask), hipMemcpyHostToDevice, side_.stream));
-    launch_smul(side_.stasks.p, (int)(4 * B), 1, side_.stream);
+    const size_t nt = 6 * B;
+    launch_finalize(side_.res.p + 2 * B, (int)(4 * B), d_pp_.p, side_.dst.p + 2 * B, nullptr, side_.stream, side_.dst.p + nt + 2 * B);
     launch_compress(d_pp_.p + 4 * ell + CW0, CWN, (int)pp_stride_, (int)B, side_.comp.p, side_.stream);
     CPX_HIP(hipMemcpyAsync(side_.hcomp.p, side_.comp.p, B * (size_t)CWN * 48, hipMemcpyDeviceToHost, side_.stream));
     CPX_HIP(hipEventRecord(side_.ev, side_.stream));

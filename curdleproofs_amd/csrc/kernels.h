@@ -116,7 +116,8 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_con
 void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra = nullptr,
                      int extra_per_out = 0, int dup = 1);
 // Jacobian -> affine (+ optional scatter through dst_index) and optional 48-byte compressed form.
-void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s);
+// d_addend_index (optional): entry g != ~0u names a point of d_aff that is added to input g before it is normalised
+void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s, const uint32_t* d_addend_index = nullptr);
 // `batch` rows of n points, row r starting at d_in + r*stride; output dense [batch][n][48]
 void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s, int out_stride = 0);   // out_stride (points per output row), 0 = dense
 // `batch` strided rows; only the columns d_cols[0..ncols) are compressed, each to the same column of the output row

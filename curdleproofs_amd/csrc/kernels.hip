@@ -974,12 +974,14 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail_wave(co
 // Thread per point: Jacobian -> affine (one inversion per work-group) and, optionally, the 48-byte
 // compressed encoding the transcript and the proof bytes need.
 __global__ __launch_bounds__(64) void k_finalize(const Jac* __restrict__ in, int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index,
-                                                   uint8_t* __restrict__ out_comp) {
+                                                   uint8_t* __restrict__ out_comp, const uint32_t* __restrict__ addend_index) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   Fp* buf = reinterpret_cast<Fp*>(smem);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   Jac p = Jac::identity();
   if (g < n) p = in[g];
+  if (addend_index && g < n && addend_index[g] != ~0u)   // + an already-normalised point of out_aff (a result of an earlier phase)
+    p = t_jac_to_std(t_add_mixed(t_jac_from_std(p), t_from_std(out_aff[addend_index[g]])));
   const bool inf = p.is_identity();
   Fp zinv = block_batch_inverse(p.z, buf);
   if (g >= n) return;
@@ -987,8 +989,6 @@ __global__ __launch_bounds__(64) void k_finalize(const Jac* __restrict__ in, int
   if (out_aff) out_aff[dst_index ? dst_index[g] : g] = a;
   if (out_comp) aff_compress_store(a, out_comp + (size_t)g * 48);
 }
-
-// affine -> compressed bytes only; `batch` strided input rows of n points each, dense output
 __global__ __launch_bounds__(256) void k_compress(const Aff* __restrict__ in, int n, int stride, uint8_t* __restrict__ out, int out_stride) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
@@ -1473,9 +1473,9 @@ void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, 
   CPX_LAUNCH(k_table_build, dim3((unsigned)((total + blk - 1) / blk)), dim3(blk), 2 * blk * sizeof(TF), s, d_src, src_row_stride, d_table, rows, row_stride, npts,
                      copy_stride, copies, endo ? 1 : 0, d_tmp);
 }
-void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s) {
+void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s, const uint32_t* d_addend_index) {
   if (n <= 0) return;
-  CPX_LAUNCH(k_finalize, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(Fp), s, d_in, n, d_aff, d_dst_index, d_comp);
+  CPX_LAUNCH(k_finalize, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(Fp), s, d_in, n, d_aff, d_dst_index, d_comp, d_addend_index);
 }
 void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s, int out_stride) {
   if (n <= 0 || batch <= 0) return;

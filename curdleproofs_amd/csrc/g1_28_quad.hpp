@@ -101,6 +101,22 @@ __device__ __forceinline__ Xyzz28 xyzz28_dbl_quad(const Xyzz28& p) {
   return r;
 }
 
+// 2 P in Jacobian coordinates over a quad (the formulas of jac28_dbl): A = X^2, B = Y^2, Y Z | C = B^2, X B, F = (3A)^2 | E (D - X3):
+// the chain Y -> Y^2 -> (B^2, X B) -> E (D - X3) is three products deep, so three rounds per doubling instead of seven products.
+__device__ __forceinline__ Jac28 jac28_dbl_quad(const Jac28& p) {
+  const int sub = threadIdx.x & 3;
+  F28 t = f28_mul(quad_sel(sub, p.x, p.y, p.y, p.y), quad_sel(sub, p.x, p.y, p.z, p.z));
+  const F28 A = quad_bcast<0>(t), B = quad_bcast<1>(t), yz = quad_bcast<2>(t);
+  const F28 E = f28_add(f28_shl<1>(A), A);
+  t = f28_mul(quad_sel(sub, B, p.x, E, E), quad_sel(sub, B, B, E, E));
+  const F28 C = quad_bcast<0>(t), D = f28_shl<2>(quad_bcast<1>(t)), F = quad_bcast<2>(t);
+  Jac28 r;
+  r.x = f28_sub(F, f28_shl<1>(D));
+  r.y = f28_sub(f28_mul(E, f28_sub(D, r.x)), f28_shl<3>(C));   // the same product in the four lanes: nothing to exchange
+  r.z = f28_shl<1>(yz);                                        // exact zero stays exact zero
+  return r;
+}
+
 // Jacobian (X, Y, Z) <-> XYZZ (X, Y, Z^2, Z^3): the partial-sum arrays between the kernels stay Jacobian
 __device__ __forceinline__ Xyzz28 xyzz28_from_jac(const Jac28& p) {
   if (p.is_identity()) return Xyzz28::identity();

@@ -911,6 +911,64 @@ __global__ __launch_bounds__(64) void k_table_build(const Aff* __restrict__ src,
   }
 }
 
+// A few rows (a lone proof): one QUAD per base point.  The chain of doublings is what the build waits for (120 of them for the
+// 16 + 16 copies of an endomorphism row): three product rounds per doubling over the quad instead of seven products of one lane;
+// the copies are dealt to the four lanes, which normalise their four each (the work-group's one inversion as before).  The copies
+// wait in LDS instead of the scratch buffer.
+constexpr int TBQ_CHUNK = 4;   // copies per lane: real - 1 <= 16
+__global__ __launch_bounds__(64) void k_table_build_quad(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
+                                                          int npts, int copy_stride, int copies, int endo) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  TF* buf = reinterpret_cast<TF*>(smem);                         // [2 * 64] batch inversion
+  TF* pre_s = buf + 2 * 64;                                      // [TBQ_CHUNK][64]
+  TJac* cp_s = reinterpret_cast<TJac*>(pre_s + TBQ_CHUNK * 64);  // [TBQ_CHUNK][64]
+  const int tid = threadIdx.x, sub = tid & 3;
+  const long g = (long)blockIdx.x * 16 + (tid >> 2);
+  const long total = (long)rows * npts;
+  const bool live = g < total;
+  const int real = endo ? copies / 2 : copies;
+  const int sb = (endo ? 128 : 256) / real;
+  const TF beta = t_beta();
+  TAff* col = nullptr;
+  TAff P = TAff::identity();
+  if (live) {
+    const long r = g % rows, i = g / rows;
+    col = table + r * row_stride + i;
+    P = t_from_std(src[r * src_row_stride + i]);
+  }
+  const bool inf = P.is_identity();
+  if (live && sub == 0) {
+    col[0] = P;
+    if (endo) col[(size_t)real * copy_stride] = inf ? P : TAff{t_mul(P.x, beta), t_neg(P.y)};
+  }
+  TF prod = t_one();
+  TJac acc = TJac::from_affine(P);   // (the identity doubles to the identity: idle quads just run along)
+  int mine = 0;
+  for (int c = 1; c < real; c++) {
+    for (int s = 0; s < sb; s++) acc = jac28_dbl_quad(acc);
+    if (((c - 1) & 3) == sub) {      // copy c belongs to lane (c - 1) mod 4
+      cp_s[mine * 64 + tid] = acc;
+      pre_s[mine * 64 + tid] = prod;
+      if (!inf) prod = t_mul(prod, acc.z);
+      mine++;
+    }
+  }
+  TF inv = t_block_batch_inverse(prod, buf);
+  if (!live) return;
+  for (int k = mine - 1; k >= 0; k--) {
+    const int c = 4 * k + sub + 1;
+    TAff a = TAff::identity();
+    if (!inf) {
+      const TJac p = cp_s[k * 64 + tid];
+      const TF zinv = t_mul(inv, pre_s[k * 64 + tid]);
+      inv = t_mul(inv, p.z);
+      a = t_to_affine(p, zinv);
+    }
+    col[(size_t)c * copy_stride] = a;
+    if (endo) col[(size_t)(real + c) * copy_stride] = inf ? a : TAff{t_mul(a.x, beta), t_neg(a.y)};
+  }
+}
+
 // ------------------------------------------------------------------ MSM: Horner tails
 // out[t] = sum_{j < group} 2^(shift*j) in[t*group + j], one lane per output; the last stage hands the result
 // over in the standard form.
@@ -930,44 +988,66 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const T
   else out[t] = acc;
 }
 
-// A few outputs (a lone proof's verification, tier-0 MSMs): one wave per output.  Lane j adds the `dup` inputs of weight 2^(shift j) and
-// shifts its sum by shift * j doublings on its own — the doublings of the 16 windows run side by side instead of one after the other in
-// a Horner chain — then the lanes (and the extra partial sums, one lane each) are added in a tree: shift * (group - 1) doublings and
-// ~6 additions deep instead of shift * (group - 1) doublings and (dup * group + extra) additions (1.6 ms -> 1.1 ms for the verifier's
-// 16 x 2 + 8 partial sums).
+// A few outputs (a lone proof's verification, tier-0 MSMs, R and S of a lone prover): one wave per output and one QUAD per window.
+// Quad j adds the `dup` inputs of weight 2^(shift j) and shifts the sum by shift * j doublings — the doublings of the 16 windows run
+// side by side instead of one after the other in a Horner chain, each spread over the four lanes (g1_28_quad.hpp: 4.4 us instead of
+// 7.6 us) — then the window sums and the extra partial sums are added in a tree of quad additions: shift * (group - 1) doublings
+// and ~6 additions deep (0.6 ms for the verifier's 16 x 2 + 8 partial sums; the one-lane Horner chain took 1.6 ms).
+// Needs group <= 16 and group * dup + extra_per_out <= 64.
 template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail_wave(const TJac* __restrict__ in, TJac* __restrict__ out, Jac* __restrict__ out_std,
                                                                               int group, int shift, const TJac* __restrict__ extra, int extra_per_out, int dup) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  TJac* red = reinterpret_cast<TJac*>(smem);   // [64]
-  const int t = blockIdx.x, lane = threadIdx.x;
-  TJac acc = TJac::identity();
-  if (lane < group) {
-    const TJac* src = in + ((size_t)t * group + lane) * dup;
-    acc = src[0];
-    for (int d = 1; d < dup; d++) acc = t_add(acc, src[d]);
-    for (int s = 0; s < shift * lane; s++) acc = t_dbl(acc);
-  } else if (lane < group + extra_per_out) {
-    acc = extra[(size_t)t * extra_per_out + (lane - group)];
+  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [65]: the inputs, then the window sums and extras; [64] = identity
+  const int t = blockIdx.x, lane = threadIdx.x, quad = lane >> 2, sub = lane & 3;
+  const int nin = group * dup;
+  {
+    TJac p = TJac::identity();
+    if (lane < nin) p = in[(size_t)t * nin + lane];
+    else if (lane < nin + extra_per_out) p = extra[(size_t)t * extra_per_out + (lane - nin)];
+    buf[lane] = xyzz28_from_jac(p);
+    if (lane == 0) buf[64] = TAcc::identity();
   }
-  red[lane] = acc;
   __syncthreads();
-  const int c = group + extra_per_out;
-  int top = 32;
-  while (top >= 1 && top >= c) top >>= 1;
-  for (int sft = top; sft >= 1; sft >>= 1) {
-    const bool has = lane < sft;
-    TJac other;
-    if (has) other = red[lane + sft];
-    __syncthreads();
-    if (has) {
-      acc = t_add(acc, other);
-      red[lane] = acc;
-    }
-    __syncthreads();
+  // the inputs of a window: dup - 1 rounds, quad j adds input d of window j to input 0
+  quad_exec(buf, dup - 1, [&](int r, int q, bool&) {
+    return q < group ? QuadJob{(uint8_t)(q * dup), (uint8_t)(q * dup + r + 1), (uint8_t)(q * dup), 1} : QuadJob{64, 64, 64, 0};
+  });
+  TAcc acc = buf[quad < group ? quad * dup : 64];
+  TAcc ex = buf[64];
+  if (lane < extra_per_out) ex = buf[nin + lane];
+  const int nd = shift * (group - 1), mine = quad < group ? shift * quad : 0;
+  for (int s = 0; s < nd; s++) {
+    const TAcc d = xyzz28_dbl_quad(acc);
+    if (s < mine) acc = d;
   }
+  __syncthreads();                              // every quad holds its window sum: the inputs may go
+  if (quad < group && sub == 0) buf[quad] = acc;
+  if (lane < extra_per_out) buf[group + lane] = ex;
+  __syncthreads();
+  int m = group + extra_per_out, nrounds = 0;
+  for (int mm = m; mm > 1;) {
+    int top = 1;
+    while (top * 2 < mm) top *= 2;
+    nrounds += (mm - top + 15) / 16;
+    mm = top;
+  }
+  int top = 1, done = 0;
+  while (top * 2 < m) top *= 2;
+  quad_exec(buf, nrounds, [&](int, int q, bool&) {
+    const int j = done + q, njobs = m - top;
+    const QuadJob jb = j < njobs ? QuadJob{(uint8_t)j, (uint8_t)(j + top), (uint8_t)j, 1} : QuadJob{64, 64, 64, 0};
+    done += 16;
+    if (done >= njobs) {   // next level
+      m = top;
+      top = top > 1 ? top / 2 : 1;
+      done = 0;
+    }
+    return jb;
+  });
   if (lane != 0) return;
-  if (STD_OUT) out_std[t] = t_jac_to_std(acc);
-  else out[t] = acc;
+  const TJac res = t_acc_to_jac(buf[0]);
+  if (STD_OUT) out_std[t] = t_jac_to_std(res);
+  else out[t] = res;
 }
 
 // ------------------------------------------------------------------ normalise + compress
@@ -1341,8 +1421,8 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
     const char* e = getenv("CPX_TAIL_WAVE_MAX");
     return e ? atol(e) : 256L;
   }();
-  if (nout <= wave_max && shift > 0 && group + extra_per_out <= 64) {   // a few outputs: wave per output, windows shifted side by side
-    const size_t lds = 64 * sizeof(TJac);
+  if (nout <= wave_max && shift > 0 && group <= 16 && group * dup + extra_per_out <= 64) {   // a few outputs: wave per output, windows shifted side by side
+    const size_t lds = 65 * sizeof(TAcc);
     if (d_out_std) CPX_LAUNCH(k_msm_tail_wave<true>, dim3(nout), dim3(64), lds, s, d_in, d_out, d_out_std, group, shift, d_extra, extra_per_out, dup);
     else CPX_LAUNCH(k_msm_tail_wave<false>, dim3(nout), dim3(64), lds, s, d_in, d_out, d_out_std, group, shift, d_extra, extra_per_out, dup);
     return;
@@ -1470,6 +1550,17 @@ void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, 
   // single-wave work-groups: a 256-thread group of this 241-VGPR kernel only ever got one group per CU (38 ms against 19 ms per
   // 2048 proofs); one inversion per 64 bases instead of per 256 costs ~5 % of a wave's time
   constexpr int blk = 64;
+  static const long quad_max = [] {   // CPX_TABLE_QUAD_MAX moves the switch-over (tests reach both forms with small inputs)
+    const char* e = getenv("CPX_TABLE_QUAD_MAX");
+    return e ? atol(e) : 4096L;
+  }();
+  const int real = endo ? copies / 2 : copies;
+  if (total <= quad_max && real - 1 <= 4 * TBQ_CHUNK) {   // a few rows: quad per base point
+    const size_t lds = (2 * 64 + TBQ_CHUNK * 64) * sizeof(TF) + TBQ_CHUNK * 64 * sizeof(TJac);
+    CPX_LAUNCH(k_table_build_quad, dim3((unsigned)((total + 15) / 16)), dim3(blk), lds, s, d_src, src_row_stride, d_table, rows, row_stride, npts, copy_stride, copies,
+               endo ? 1 : 0);
+    return;
+  }
   CPX_LAUNCH(k_table_build, dim3((unsigned)((total + blk - 1) / blk)), dim3(blk), 2 * blk * sizeof(TF), s, d_src, src_row_stride, d_table, rows, row_stride, npts,
                      copy_stride, copies, endo ? 1 : 0, d_tmp);
 }

@@ -50,6 +50,9 @@ Engine::~Engine() {
   for (hipEvent_t e : {dprove_.ev_a, dprove_.ev_b, dprove_.ev_c, dprove_.ev_d, dverify_.ev_a, dverify_.ev_b})
     if (e) (void)hipEventDestroy(e);
   if (side_.stream) (void)hipStreamDestroy(side_.stream);
+  if (side_.lat_stream) (void)hipStreamDestroy(side_.lat_stream);
+  if (side_.lat_main) (void)hipStreamDestroy(side_.lat_main);
+  if (side_.lat_ev) (void)hipEventDestroy(side_.lat_ev);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -838,10 +841,62 @@ void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const
 // rescaled basis G' = u o G of grand_product_argument.rs:90-102, which is never materialised).  Likewise every
 // commitment (B, D, cm_T, cm_A, A', ...) expands into an MSM over CRS / instance points.  Hence: no basis
 // folds, no per-round normalisation, every MSM runs on pre-shifted tables (k_msm_tbl) without a doubling tail.
+// The side and table streams of the host-driven prover: their kernels (a few long single-wave groups: the doubling chains of the table
+// build and of the MSM tails) run BESIDE the phases of the main stream, and the dispatcher likes to put the main stream's single-wave
+// groups onto the very SIMDs those long waves occupy — two 200-VGPR waves then time-share one SIMD and a 120 us reduction took
+// 370 us.  The queues of these streams are therefore confined to the upper half of the CU mask (hipExtStreamCreateWithCUMask); the
+// main stream, unconfined, fills the GPU from the low end.  CPX_CU_MASK=0 creates plain streams (A/B runs).
+hipStream_t Engine::create_masked_stream(bool upper) {
+  hipStream_t st = nullptr;
+  const char* e = getenv("CPX_CU_MASK");
+  hipDeviceProp_t prop;
+  CPX_HIP(hipGetDeviceProperties(&prop, device_));
+  const int ncu = prop.multiProcessorCount;
+  if ((e && atoi(e) == 0) || ncu < 64) {
+    CPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+  }
+  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+  for (int cu = upper ? ncu / 2 : 0; cu < (upper ? ncu : ncu / 2); cu++) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    CPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  }
+  return st;
+}
+namespace {
+// the engine's main stream replaced for the lifetime of the guard; work already queued on the old stream is waited for, and the old
+// stream waits for the new one at the end
+struct StreamSwap {
+  hipStream_t& ref;
+  hipStream_t saved;
+  hipEvent_t ev;
+  StreamSwap(hipStream_t& r, hipStream_t s, hipEvent_t e) : ref(r), saved(r), ev(e) {
+    if (!s) return;
+    (void)hipEventRecord(ev, saved);
+    (void)hipStreamWaitEvent(s, ev, 0);
+    ref = s;
+  }
+  ~StreamSwap() {
+    if (ref == saved) return;
+    (void)hipEventRecord(ev, ref);
+    (void)hipStreamWaitEvent(saved, ev, 0);
+    ref = saved;
+  }
+};
+}  // namespace
+
 void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   HostSpan wall(this, "host_prove_wall");
   CPX_HIP(hipSetDevice(device_));
   const size_t B = B_, ell = ell_, n = n_, L = L_;
+  if (!side_.lat_stream) {
+    side_.lat_stream = create_masked_stream(true);
+    side_.lat_main = create_masked_stream(false);
+    CPX_HIP(hipEventCreateWithFlags(&side_.lat_ev, hipEventDisableTiming));
+  }
+  const hipStream_t sside = side_.lat_stream;
+  StreamSwap lat_main(stream_, B <= 8 ? side_.lat_main : nullptr, side_.lat_ev);   // a few proofs: the phases on the lower half of the CUs
   const SlotMap sm(L);
   const size_t nrand = 3 * n + 9;
   const int NS = sm.count();
@@ -884,7 +939,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     // the per-proof tables on the table stream: M's row first (phase 2 needs it: B = A + alpha M + ...), then T and U (needed from
     // SameMSM step 1 on), beside phase 1 instead of in front of it
     if (!tab_.stream) {
-      CPX_HIP(hipStreamCreateWithFlags(&tab_.stream, hipStreamNonBlocking));
+      tab_.stream = create_masked_stream(true);
       CPX_HIP(hipEventCreateWithFlags(&tab_.ev_start, hipEventDisableTiming));
       CPX_HIP(hipEventCreateWithFlags(&tab_.ev_m, hipEventDisableTiming));
       CPX_HIP(hipEventCreateWithFlags(&tab_.ev_done, hipEventDisableTiming));
@@ -968,9 +1023,9 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
         hd[nt + t] = j < 2 ? ~0u : slot_index(p, sm.TMP(j - 2));
       }
     });
-    CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, 3 * total * sizeof(Fr), hipMemcpyHostToDevice, side_.stream));
-    CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, side_.stream));
-    CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, 2 * nt * sizeof(uint32_t), hipMemcpyHostToDevice, side_.stream));
+    CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, 3 * total * sizeof(Fr), hipMemcpyHostToDevice, sside));
+    CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, sside));
+    CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, 2 * nt * sizeof(uint32_t), hipMemcpyHostToDevice, sside));
     side_.conv.ensure(2 * nt * ell);   // per task: points and images
     side_.ttasks.ensure(nt);
     side_.digits.ensure(9 * nt * ell);
@@ -978,10 +1033,10 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     side_.rawslot.ensure(nt * 32);
     side_.mid.ensure(nt * 32 * 16);
     side_.part.ensure(nt * 32);
-    launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
-    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nt * 32, side_.mid.p, side_.part.p, side_.stream);
-    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, side_.stream, nullptr, 0, 2);
-    launch_finalize(side_.res.p, (int)(2 * B), d_pp_.p, side_.dst.p, nullptr, side_.stream);
+    launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, sside);
+    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nt * 32, side_.mid.p, side_.part.p, sside);
+    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, sside, nullptr, 0, 2);
+    launch_finalize(side_.res.p, (int)(2 * B), d_pp_.p, side_.dst.p, nullptr, sside);
   }
 
   // -- table stream: B_t = msm(T_b, vec_r), B_u = msm(U_b, vec_r) (same_multiscalar_argument.rs:81-82) right behind the tables of T and U
@@ -1087,10 +1142,10 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
   //    phase 1 left in TMP0..3 (complete by now: the host has taken phase 1's results); needed only at the SameScalar transcript step.
   {
     const size_t nt = 6 * B;
-    launch_finalize(side_.res.p + 2 * B, (int)(4 * B), d_pp_.p, side_.dst.p + 2 * B, nullptr, side_.stream, side_.dst.p + nt + 2 * B);
-    launch_compress(d_pp_.p + 4 * ell + CW0, CWN, (int)pp_stride_, (int)B, side_.comp.p, side_.stream);
-    CPX_HIP(hipMemcpyAsync(side_.hcomp.p, side_.comp.p, B * (size_t)CWN * 48, hipMemcpyDeviceToHost, side_.stream));
-    CPX_HIP(hipEventRecord(side_.ev, side_.stream));
+    launch_finalize(side_.res.p + 2 * B, (int)(4 * B), d_pp_.p, side_.dst.p + 2 * B, nullptr, sside, side_.dst.p + nt + 2 * B);
+    launch_compress(d_pp_.p + 4 * ell + CW0, CWN, (int)pp_stride_, (int)B, side_.comp.p, sside);
+    CPX_HIP(hipMemcpyAsync(side_.hcomp.p, side_.comp.p, B * (size_t)CWN * 48, hipMemcpyDeviceToHost, sside));
+    CPX_HIP(hipEventRecord(side_.ev, sside));
   }
 
   // -- P2: B, A' = A + cm_T.T_1 + cm_U.T_1 (curdleproofs.rs:134) as a sum of three points of phase 1, and C = msm(G | Hvec, c)

@@ -191,6 +191,8 @@ class Engine {
   // second stream + private staging for work that is off the critical path of the phase sequence
   struct SideBufs {
     hipStream_t stream = nullptr;
+    hipStream_t lat_stream = nullptr, lat_main = nullptr;   // the host-driven prover's side / main stream: CU-masked (create_masked_stream)
+    hipEvent_t lat_ev = nullptr;
     hipEvent_t ev = nullptr, ev2 = nullptr;
     DevBuf<MsmTask> tasks;
     DevBuf<SmulTask> stasks;
@@ -226,6 +228,7 @@ class Engine {
   };
 
   void set_crs_impl(size_t ell, const uint8_t* points);
+  hipStream_t create_masked_stream(bool upper);
   const Aff& generator();
   void compress_affine(const Aff* pts, size_t n, uint8_t* out);
   bool unzip_trackers(const uint8_t* trackers, size_t n, std::vector<Aff>& vec_r, std::vector<Aff>& vec_s);

@@ -1545,32 +1545,19 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     if (o != psz || q != NPP) throw std::logic_error("proof layout");
   }
 
-  // -- V0: decompress proof points into their slots; M -> affine; compressed instance vectors
+  // -- V0: compressed instance vectors and M -> affine first (the transcript starts with their bytes: the side stream copies them
+  //    to the host), then the proof points are decompressed into their slots — the host hashes (V1a) while that kernel runs
   h_inst_comp_.ensure(B * 4 * ell * 48);
   h_mcomp_.ensure(B * 48);
   const uint8_t* inst_comp = h_inst_comp_.p;
   const uint8_t* mcomp = h_mcomp_.p;
+  const size_t npts = (size_t)B * NPP;
   {
-    const size_t npts = (size_t)B * NPP;
     h_pts_.ensure(npts * 48);
     h_u32_.ensure(npts + B);
     h_status_.ensure(npts);
     uint8_t* pts = h_pts_.p;
     uint32_t* dst = h_u32_.p;
-    parallel_for(B, [&](size_t p) {
-      for (int q = 0; q < NPP; q++) {
-        memcpy(&pts[(p * NPP + q) * 48], proofs + p * psz + pt_off[q], 48);
-        dst[p * NPP + q] = slot_index(p, SL_A + q);
-      }
-    });
-    d_vin_.ensure(npts * 48);
-    d_vdst_.ensure(npts);
-    d_status_.ensure(npts);
-      CPX_HIP(hipMemcpyAsync(d_vin_.p, pts, npts * 48, hipMemcpyHostToDevice, stream_));
-    CPX_HIP(hipMemcpyAsync(d_vdst_.p, dst, npts * 4, hipMemcpyHostToDevice, stream_));
-    tick("k_decompress", 0, (double)npts);
-    launch_decompress(d_vin_.p, (int)npts, d_pp_.p, d_vdst_.p, d_status_.p, 1, stream_);
-    tock();
     d_bytes_.ensure(B * 4 * ell * 48);
     tick("k_compress", 0, (double)(4 * ell * B));
     launch_compress(d_pp_.p, (int)(4 * ell), (int)pp_stride_, (int)B, d_bytes_.p, stream_);
@@ -1583,13 +1570,22 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_dst_.p, mdst, B * 4, hipMemcpyHostToDevice, stream_));
     launch_finalize(d_Mjac_.p, (int)B, d_pp_.p, d_dst_.p, d_mcomp_.p, stream_);
     transcript_prefix_async(B);   // side stream: copies of the compressed bytes for the host's transcripts
-    const uint8_t* status = h_status_.p;
+    parallel_for(B, [&](size_t p) {
+      for (int q = 0; q < NPP; q++) {
+        memcpy(&pts[(p * NPP + q) * 48], proofs + p * psz + pt_off[q], 48);
+        dst[p * NPP + q] = slot_index(p, SL_A + q);
+      }
+    });
+    d_vin_.ensure(npts * 48);
+    d_vdst_.ensure(npts);
+    d_status_.ensure(npts);
+    CPX_HIP(hipMemcpyAsync(d_vin_.p, pts, npts * 48, hipMemcpyHostToDevice, stream_));
+    CPX_HIP(hipMemcpyAsync(d_vdst_.p, dst, npts * 4, hipMemcpyHostToDevice, stream_));
+    tick("k_decompress", 0, (double)npts);
+    launch_decompress(d_vin_.p, (int)npts, d_pp_.p, d_vdst_.p, d_status_.p, 1, stream_);
+    tock();
     CPX_HIP(hipMemcpyAsync(h_status_.p, d_status_.p, npts, hipMemcpyDeviceToHost, stream_));
-    wait_stream();
     wait_side();
-    for (size_t p = 0; p < B; p++)
-      for (int q = 0; q < NPP; q++)
-        if (status[p * NPP + q]) st[p].bad = true;
   }
 
   const uint8_t ID0 = 0xc0;
@@ -1630,6 +1626,13 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     s.scal[0] = {S::one(), -s.beta_g_inv, s.alpha_g};    // D  (grand_product_argument.rs:223)
     s.scal[1] = {S::one(), S::one(), S::one()};          // A' (curdleproofs.rs:258)
   });
+  {   // the decompressed proof points (and their verdicts) are needed from here on
+    wait_stream();
+    const uint8_t* status = h_status_.p;
+    for (size_t p = 0; p < B; p++)
+      for (int q = 0; q < NPP; q++)
+        if (status[p * NPP + q]) st[p].bad = true;
+  }
 
   // -- V1b: D = B - beta^-1 sum(G) + alpha sum(H) (grand_product_argument.rs:223) and A' = A + cm_T.T_1 + cm_U.T_1
   //    (curdleproofs.rs:258) are hashed into the transcript, so they are needed as bytes: sums of decompressed proof

@@ -1189,6 +1189,85 @@ __global__ __launch_bounds__(64, 2) void k_decompress(const uint8_t* __restrict_
   status[g] = st;
 }
 
+// A few points (a lone proof's 45): one QUAD per point.  The four lanes parse the encoding and take the square root redundantly; the
+// subgroup test — [u^2] P by two chains of 63 doublings and 5 additions, what a lone verification waits for longest — runs on the
+// quad-cooperative XYZZ formulas (g1_28_quad.hpp: 4.4 us per doubling instead of 7.6 us).  Same verdicts as k_decompress.
+__device__ __forceinline__ bool g1_28_in_subgroup_quad(const Aff28& P, TAcc* slot /* [3]: scratch, P, [|u|] P */) {
+  const int sub = threadIdx.x & 3;
+  const bool idP = P.is_identity();
+  const uint64_t U = 0xd201000000010000ull;
+  TAcc acc = idP ? TAcc::identity() : TAcc{P.x, P.y, f28_one(), f28_one()};
+  if (sub == 0) slot[1] = acc;
+  for (int pass = 0; pass < 2; pass++) {      // [|u|] P, then [|u|] ([|u|] P)
+    if (sub == 0) slot[2] = acc;              // (pass 0: unused; pass 1: the addend [|u|] P)
+    __syncthreads();
+    for (int b = 62; b >= 0; b--) {
+      acc = xyzz28_dbl_quad(acc);
+      if ((U >> b) & 1) {
+        if (sub == 0) slot[0] = acc;
+        __syncthreads();
+        acc = xyzz28_add_quad_mem(slot, 0, 1 + pass);
+        __syncthreads();
+      }
+    }
+  }
+  if (idP) return true;
+  if (acc.is_identity()) return false;
+  // (beta x_P, y_P) == (X / ZZ, -Y / ZZZ)
+  const F28 lhs_x = f28_mul(f28_mul(f28_const(F28Cfg::BETA), P.x), acc.zz);
+  const F28 lhs_y = f28_mul(P.y, acc.zzz);
+  return f28_eq(lhs_x, acc.x) && f28_eq(lhs_y, f28_neg(acc.y));
+}
+__global__ __launch_bounds__(64) void k_decompress_quad(const uint8_t* __restrict__ in, int n, Aff* __restrict__ out, const uint32_t* __restrict__ dst_index,
+                                                         uint8_t* __restrict__ status, int check_subgroup, const uint32_t* __restrict__ src_offset) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [16][3]
+  const int quad = threadIdx.x >> 2, sub = threadIdx.x & 3;
+  const int g = blockIdx.x * 16 + quad;
+  const bool live = g < n;
+  Aff res = Aff::identity();
+  Aff28 chk = Aff28::identity();               // the point whose membership is tested (identity: nothing to test)
+  uint8_t st = 0;
+  if (live) {
+    const uint8_t* b = in + (src_offset ? (size_t)src_offset[g] : (size_t)g * 48);
+    Fp xc;
+    for (int l = 0; l < 12; l++) xc.v[11 - l] = ((uint32_t)b[4 * l] << 24) | ((uint32_t)b[4 * l + 1] << 16) | ((uint32_t)b[4 * l + 2] << 8) | b[4 * l + 3];
+    const uint8_t b0 = (uint8_t)(xc.v[11] >> 24);
+    xc.v[11] &= 0x1fffffffu;
+    const bool compressed = b0 & 0x80, infinity = b0 & 0x40, sort = b0 & 0x20;
+    if (!compressed) {
+      st = 1;
+    } else if (infinity) {
+      if (sort || !xc.is_zero()) st = 1;
+    } else {
+      Fp pm;   // x must be < p
+      for (int i = 0; i < 12; i++) pm.v[i] = FpCfg::P[i];
+      if (!fe_raw_gt(pm, xc)) {
+        st = 1;
+      } else {
+        const Fp x = fe_to_mont(xc);
+        const F28 x28 = f28_from_std(x);
+        const F28 rhs = f28_add(f28_mul(f28_sqr(x28), x28), f28_const(F28Cfg::FOUR));
+        const F28 y28 = f28_sqrt_device(rhs);
+        if (!f28_eq(f28_sqr(y28), rhs)) {
+          st = 1;
+        } else {
+          const Fp y = f28_to_std(y28), ny = fe_neg(y);
+          const bool y_larger = fe_raw_gt(fe_from_mont(y), fe_from_mont(ny));
+          const bool keep = (y_larger == sort);
+          res.x = x;
+          res.y = keep ? y : ny;
+          if (check_subgroup) chk = Aff28{x28, f28_cneg(y28, !keep)};
+        }
+      }
+    }
+  }
+  if (!g1_28_in_subgroup_quad(chk, buf + quad * 3)) st = 2;   // every lane of the wave takes part
+  if (!live || sub != 0) return;
+  out[dst_index ? dst_index[g] : g] = st ? Aff::identity() : res;
+  status[g] = st;
+}
+
 
 // sum of n Jacobian points (the partial sums of several engines / GPUs); flag[0] = 1 iff the sum is the identity
 __global__ __launch_bounds__(64) void k_sum_jac(const Jac* __restrict__ in, int n, Jac* __restrict__ out, int* __restrict__ flag) {
@@ -1585,6 +1664,14 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
 void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
                        const uint32_t* d_src_offset) {
   if (n <= 0) return;
+  static const long quad_max = [] {   // CPX_DECOMPRESS_QUAD_MAX moves the switch-over (tests reach both forms with small inputs)
+    const char* e = getenv("CPX_DECOMPRESS_QUAD_MAX");
+    return e ? atol(e) : 2048L;
+  }();
+  if (n <= quad_max && check_subgroup) {   // a few points: quad per point
+    CPX_LAUNCH(k_decompress_quad, dim3((n + 15) / 16), dim3(64), 16 * 3 * sizeof(TAcc), s, d_in, n, d_out, d_dst_index, d_status, check_subgroup, d_src_offset);
+    return;
+  }
   CPX_LAUNCH(k_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in, n, d_out, d_dst_index, d_status, check_subgroup, d_src_offset);
 }
 void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s) {

@@ -510,7 +510,7 @@ def test_fused_batch_verifier_many_points(ctx, orc, ell, nproofs):
 # a batch of a few proofs reaches.  THROUGHPUT_ENV moves every switch-over so that small batches run exactly those
 # instantiations (kernels.hip: msm_fix_windows_per_wave, msm_tblw_windows_per_wave, launch_reduce_sets,
 # launch_finalize_ranges, launch_msm_tail).
-THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAVE_MAX": "0", "CPX_FINALIZE_WAVE_MAX": "0", "CPX_TAIL_WAVE_MAX": "0", "CPX_TABLE_QUAD_MAX": "0"}
+THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAVE_MAX": "0", "CPX_FINALIZE_WAVE_MAX": "0", "CPX_TAIL_WAVE_MAX": "0", "CPX_TABLE_QUAD_MAX": "0", "CPX_DECOMPRESS_QUAD_MAX": "0"}
 
 
 @pytest.mark.parametrize("env", [{"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_MIN_BATCH": "1"}, {"CPX_DEVICE_MIN_BATCH": "1000000"}, THROUGHPUT_ENV,

@@ -348,7 +348,11 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   const int fix_wpw = fix ? msm_fix_windows_per_wave((int)nft_total, fix_bits_) : 16;
   const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / fix_wpw) : 0;
   const int tbl_wpw = msm_tblw_windows_per_wave((int)ntt_total);   // windows per wave of the shifted-table kernel
-  const uint32_t tbl_parts = (uint32_t)msm_tblw_parts(tbl_wpw);   // partial sums (waves) per task
+  uint32_t tbl_max_n = 0;
+  for (const TblReq& r : reqs)
+    if (needs_tbl(r)) tbl_max_n = std::max(tbl_max_n, (is_crs(r.seg0) ? 0u : r.seg0.n) + (is_crs(r.seg1) ? 0u : r.seg1.n));
+  const int tbl_slices = msm_tblw_slices((int)ntt_total, tbl_wpw, (int)tbl_max_n);   // a lone proof: several waves share a task's points
+  const uint32_t tbl_parts = (uint32_t)(msm_tblw_parts(tbl_wpw) * tbl_slices);   // partial sums (2 per wave) per task
   // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
   std::vector<size_t> soff(nt);
   std::vector<uint32_t> pfirst(nt), pcount(nt), tt_index(nt, ~0u), ft_index(nt * 2, ~0u);
@@ -447,7 +451,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   }
   if (ntt) {
     tick(tblw_kernel_name(tbl_wpw), 128.0 * pts_tbl, pts_tbl);
-    launch_msm_tblw(d_tt, (int)ntt, tbl_wpw, d_raw_.p + fix_sets * raw_set_words(), d_rawslot_.p + fix_sets, stream_);
+    launch_msm_tblw(d_tt, (int)ntt, tbl_wpw, d_raw_.p + fix_sets * raw_set_words(), d_rawslot_.p + fix_sets, stream_, tbl_slices);
     tock();
   }
   reduce_sets(fix_sets, tbl_sets);
@@ -613,15 +617,16 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
     DevBuf<TblTask> tt;
     DevBuf<TJac> part;
     DevBuf<uint32_t> dig;
+    const int slices = msm_tblw_slices(1, 2, (int)n);
     tt.ensure(1);
-    part.ensure(32);
+    part.ensure(32 * (size_t)slices);
     dig.ensure(9 * n);
-    ensure_raw_sets(32);
+    ensure_raw_sets(32 * (size_t)slices);
     tick("k_msm_tblw<2, true>", 128.0 * n, (double)n);
-    launch_msm_endo(dt.p, 1, (int)n, conv.p, dig.p, tt.p, d_raw_.p, d_rawslot_.p, stream_);
+    launch_msm_endo(dt.p, 1, (int)n, conv.p, dig.p, tt.p, d_raw_.p, d_rawslot_.p, stream_, slices);
     tock();
-    reduce_sets(0, 32, part.p);
-    launch_msm_tail(part.p, nullptr, res.p, 1, 16, 8, stream_, nullptr, 0, 2);
+    reduce_sets(0, 32 * (size_t)slices, part.p);
+    launch_msm_tail(part.p, nullptr, res.p, 1, 16, 8, stream_, nullptr, 0, 2 * slices);
     CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
     CPX_HIP(hipStreamSynchronize(stream_));   // before the scratch buffers above go out of scope
     flush_timers();
@@ -1026,24 +1031,25 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, 3 * total * sizeof(Fr), hipMemcpyHostToDevice, sside));
     CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, sside));
     CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, 2 * nt * sizeof(uint32_t), hipMemcpyHostToDevice, sside));
+    const size_t slices = (size_t)msm_tblw_slices((int)nt, 2, (int)ell), nsets = nt * 32 * slices;
     side_.conv.ensure(2 * nt * ell);   // per task: points and images
     side_.ttasks.ensure(nt);
     side_.digits.ensure(9 * nt * ell);
-    side_.raw.ensure(nt * 32 * raw_set_words());
-    side_.rawslot.ensure(nt * 32);
-    side_.mid.ensure(nt * 32 * 16);
-    side_.part.ensure(nt * 32);
-    launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, sside);
-    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nt * 32, side_.mid.p, side_.part.p, sside);
-    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, sside, nullptr, 0, 2);
+    side_.raw.ensure(nsets * raw_set_words());
+    side_.rawslot.ensure(nsets);
+    side_.mid.ensure(nsets * 16);
+    side_.part.ensure(nsets);
+    launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, sside, (int)slices);
+    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nsets, side_.mid.p, side_.part.p, sside);
+    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, sside, nullptr, 0, (int)(2 * slices));
     launch_finalize(side_.res.p, (int)(2 * B), d_pp_.p, side_.dst.p, nullptr, sside);
   }
 
   // -- table stream: B_t = msm(T_b, vec_r), B_u = msm(U_b, vec_r) (same_multiscalar_argument.rs:81-82) right behind the tables of T and U
   {
     const size_t nt = 2 * B;
-    const int wpw = msm_tblw_windows_per_wave((int)nt);
-    const uint32_t parts = (uint32_t)msm_tblw_parts(wpw);
+    const int wpw = msm_tblw_windows_per_wave((int)nt), tslices = msm_tblw_slices((int)nt, wpw, (int)n);
+    const uint32_t parts = (uint32_t)(msm_tblw_parts(wpw) * tslices);
     const size_t b_scal = B * n * sizeof(Fr), b_tt = nt * sizeof(TblTask), b_blob = b_scal + b_tt + 3 * nt * sizeof(uint32_t);
     tab_.blob.ensure(b_blob);
     tab_.stage.ensure(b_blob);
@@ -1076,7 +1082,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     }
     CPX_HIP(hipMemcpyAsync(tab_.blob.p, tab_.stage.p, b_blob, hipMemcpyHostToDevice, tab_.stream));
     const uint32_t* d_u32 = reinterpret_cast<const uint32_t*>(tab_.blob.p + b_scal + b_tt);
-    launch_msm_tblw(reinterpret_cast<const TblTask*>(tab_.blob.p + b_scal), (int)nt, wpw, tab_.raw.p, tab_.rawslot.p, tab_.stream);
+    launch_msm_tblw(reinterpret_cast<const TblTask*>(tab_.blob.p + b_scal), (int)nt, wpw, tab_.raw.p, tab_.rawslot.p, tab_.stream, tslices);
     launch_reduce_sets(tab_.raw.p, tab_.rawslot.p, 0, (int)(nt * parts), tab_.mid.p, tab_.part.p, tab_.stream);
     launch_finalize_ranges(tab_.part.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, tab_.comp.p, tab_.stream);
     CPX_HIP(hipMemcpyAsync(tab_.hcomp.p, tab_.comp.p, nt * 48, hipMemcpyDeviceToHost, tab_.stream));
@@ -1936,6 +1942,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     const uint32_t* d_all = idx_list(all_idx);
     const int fix_wpw = msm_fix_windows_per_wave((int)B, fix_bits_);
     const int fix_parts = 256 / fix_bits_ / fix_wpw;
+    const size_t slices = (size_t)msm_tblw_slices((int)B, 2, (int)NPT);   // a lone proof: several waves per window of the per-proof MSM
     const size_t total = B * (NPT + n);
     d_scal_.ensure(total);
     d_tasks_.ensure(B);
@@ -1943,11 +1950,11 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     d_conv_.ensure(2 * B * NPT);   // points and their endomorphism images
     d_digits_.ensure(9 * B * NPT);
     d_ttasks_.ensure(B);
-    d_part_.ensure(B * 32);
+    d_part_.ensure(B * 32 * slices);
     d_tpart_.ensure(B * (size_t)fix_parts);
     d_res_.ensure(B);
     d_comp_.ensure(B * 48);
-    ensure_raw_sets(B * std::max<size_t>(fix_parts, 32));
+    ensure_raw_sets(B * std::max<size_t>(fix_parts, 32 * slices));
     const size_t b_scal = total * sizeof(Fr), b_mt = B * sizeof(MsmTask), b_ft = B * sizeof(FixTask);
     h_stage_.ensure(b_scal + b_mt + b_ft);
     Fr* hs = reinterpret_cast<Fr*>(h_stage_.p);
@@ -1972,11 +1979,11 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     reduce_sets(B * fix_parts, 0);
     // per-proof points: used once, so no shifted tables — endomorphism split + radix-256 buckets per window
     tick("k_msm_tblw<2, true>", 128.0 * NPT * B, (double)(NPT * B));
-    launch_msm_endo(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_digits_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_);
+    launch_msm_endo(d_tasks_.p, (int)B, (int)NPT, d_conv_.p, d_digits_.p, d_ttasks_.p, d_raw_.p, d_rawslot_.p, stream_, (int)slices);
     tock();
-    reduce_sets(0, B * 32, d_part_.p);
+    reduce_sets(0, B * 32 * slices, d_part_.p);
     tick("k_msm_tail", 0, (double)B);
-    launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)B, 16, 8, stream_, d_tpart_.p, fix_parts, 2);
+    launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)B, 16, 8, stream_, d_tpart_.p, fix_parts, (int)(2 * slices));
     tock();
     tick("k_finalize", 0, (double)B);
     launch_finalize(d_res_.p, (int)B, nullptr, nullptr, d_comp_.p, stream_);

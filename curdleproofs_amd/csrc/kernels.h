@@ -61,7 +61,9 @@ struct TblTmp {   // table-build scratch: a Jacobian copy and the running produc
 // -> partial sums d_part[task.pad + j], j < 64 / wpw
 int msm_tblw_windows_per_wave(int ntasks);
 int msm_tblw_parts(int wpw);   // waves (= partial sums) per task
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
+// slices > 1 (a few tasks in flight): that many waves share a task's points; a task then leaves slices * msm_tblw_parts(wpw) partial sums
+int msm_tblw_slices(int ntasks, int wpw, int max_n);   // max_n: points of the largest task
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s, int slices = 1);
 // The MSM waves of k_msm_tblw / k_msm_fix leave their 64 lane accumulators as "raw sets" (raw_set_words() 32-bit words
 // each; tblw: 2 sets per wave, fix: 1) plus the partial-sum slot every set belongs to; launch_reduce_sets turns them
 // into d_part[slot] (bucket sets of k_msm_tblw: weighted sums; k_msm_fix: plain sums).
@@ -71,8 +73,10 @@ size_t raw_set_words();
 // weight 2^(8w): launch_msm_tail(part, ..., group 16, shift 8, dup 2) finishes.  d_conv: 2 x (sum of n) TAff scratch
 // (task.conv_off in units of points, as for launch_msm_accum), d_digits: 9 words per point (the split scalars' digits,
 // recoded once per task instead of once per wave), d_ttasks: ntasks TblTask scratch.
+// slices > 1 (msm_tblw_slices): that many waves per window share the task's points; 32 * slices raw sets and partial sums per task,
+// part[(task*16 + w) * 2 * slices + d] carry the weight 2^(8w) (tail: dup = 2 * slices).
 void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
-                     hipStream_t s);
+                     hipStream_t s, int slices = 1);
 // The first nplain sets are plain sums, the following nweighted ones bucket sets (lower / upper half alternating).
 void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s);   // d_mid: 16 TJac per set
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void k_to_table(const MsmTask* __restrict__ tas
 // bases of the endomorphism MSM (k_msm_tblw<2, true>): per task the table-form points followed by their images
 // -phi(P) = (beta x, -y), and the table task describing them (two "copies", stride n; 32 partial sums from task * 32)
 __global__ __launch_bounds__(64) void k_to_table_endo(const MsmTask* __restrict__ tasks, TAff* __restrict__ conv, uint32_t* __restrict__ digits,
-                                                      TblTask* __restrict__ ttasks) {
+                                                      TblTask* __restrict__ ttasks, int slices) {
   const MsmTask task = tasks[blockIdx.y];
   const uint32_t j = blockIdx.x * 64 + threadIdx.x;
   TAff* dst = conv + 2 * (size_t)task.conv_off;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_to_table_endo(const MsmTask* __restrict_
     t.seg[1] = TblSeg{nullptr, nullptr, 0, 0};
     t.scalars = task.scalars;
     t.flags = task.flags;
-    t.pad = blockIdx.y * 32;
+    t.pad = blockIdx.y * 32 * slices;
     t.digits = dgs;
     ttasks[blockIdx.y] = t;
   }
@@ -521,7 +521,7 @@ __device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, uint32_t& n
 // the "table" has two copies, P and -phi(P) (k_to_table_endo), wave w of a task takes digit w of |t| and of q, and the
 // 16 window results carry the weights 2^(8w) (Horner tail, k_msm_tail).
 template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
-                                                                                            uint32_t* __restrict__ raw_slot) {
+                                                                                            uint32_t* __restrict__ raw_slot, int slices) {
   static_assert(!PERWIN || WPW == 2, "one window of each half per wave");
   constexpr int WV = PERWIN ? 16 : TBW_WINDOWS / WPW;   // waves per task
   constexpr int NW = (WPW + 3) / 4;
@@ -531,14 +531,17 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
   uint32_t* cur = cnt + 128;                                          // [128] scatter cursors
   uint32_t* start = cur + 128;                                        // [128] list offsets
   uint8_t* order = reinterpret_cast<uint8_t*>(start + 128);           // [128] buckets by size
-  const TblTask task = tasks[blockIdx.x / WV];
-  const int wv = blockIdx.x % WV, w0 = PERWIN ? wv : wv * WPW;
+  // a few tasks in flight (latency matters): `slices` waves share a task's points (each its own 64-aligned range and raw sets), so
+  // that a lane's chain of additions is a quarter as long; slices = 1 otherwise
+  const TblTask task = tasks[blockIdx.x / (WV * slices)];
+  const int wv = (blockIdx.x / slices) % WV, w0 = PERWIN ? wv : wv * WPW, slice = blockIdx.x % slices;
   const int lane = threadIdx.x;
-  const uint32_t ntot = task.seg[0].n + task.seg[1].n;
+  const uint32_t nall = task.seg[0].n + task.seg[1].n, per = ((nall + slices - 1) / slices + 63) & ~63u;
+  const uint32_t first = min(nall, (uint32_t)slice * per), ntot = min(nall, first + per);
   uint32_t* raw0 = raw + (size_t)blockIdx.x * 2 * RAW_SET_WORDS;
-  if (lane < 2) raw_slot[blockIdx.x * 2 + lane] = task.pad + 2 * wv + lane;   // task.pad = first partial slot of the task
+  if (lane < 2) raw_slot[blockIdx.x * 2 + lane] = task.pad + 2 * (wv * slices + slice) + lane;   // task.pad = first partial slot of the task
 
-  uint32_t next = 0;
+  uint32_t next = first;
   bool later = false;   // a later round: the accumulators are parked in raw0 / raw1
   do {
     cnt[lane] = 0;
@@ -784,20 +787,23 @@ __global__ __launch_bounds__(64) void k_finalize_ranges_wave(const TJac* __restr
                                                              int n, Aff* __restrict__ out_aff, const uint32_t* __restrict__ dst_index, uint8_t* __restrict__ out_comp,
                                                              const uint32_t* __restrict__ addends, const uint32_t* __restrict__ comp_index) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [65]: 64 sums + the identity for idle quads
+  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [256]: up to 255 sums + the identity (entry 255) for idle quads
   const int lane = threadIdx.x, g = blockIdx.x;
   const TJac* src = part + first[g];
   const uint32_t c = count[g];
-  {
-    TJac p = TJac::identity();
-    if ((uint32_t)lane < c) p = src[lane];                                  // (no addition to the identity first)
-    for (uint32_t j = lane + 64; j < c; j += 64) p = t_add(p, src[j]);
-    buf[lane] = xyzz28_from_jac(p);
-    if (lane == 0) buf[64] = TAcc::identity();
+  int m = c < 255 ? (int)c : 255;
+  for (int i = lane; i < m; i += 64) {
+    TJac p = src[i];
+    for (uint32_t j = i + 255; j < c; j += 255) p = t_add(p, src[j]);   // (more partial sums than entries: never in the shipped configurations)
+    buf[i] = xyzz28_from_jac(p);
+  }
+  if (lane == 0) {
+    buf[255] = TAcc::identity();
+    if (m == 0) buf[0] = TAcc::identity();
   }
   __syncthreads();
   // level by level: live entries [0, m); top = the largest power of two below m; entries [top, m) fold onto [0, m - top)
-  int m = c < 64 ? (int)c : 64, nrounds = 0;
+  int nrounds = 0;
   for (int mm = m; mm > 1;) {
     int top = 1;
     while (top * 2 < mm) top *= 2;
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(64) void k_finalize_ranges_wave(const TJac* __restr
   if (m > 1) while (top * 2 < m) top *= 2;
   quad_exec(buf, nrounds, [&](int, int quad, bool&) {
     const int j = done + quad, njobs = m - top;
-    const QuadJob jb = j < njobs ? QuadJob{(uint8_t)j, (uint8_t)(j + top), (uint8_t)j, 1} : QuadJob{64, 64, 64, 0};
+    const QuadJob jb = j < njobs ? QuadJob{(uint8_t)j, (uint8_t)(j + top), (uint8_t)j, 1} : QuadJob{255, 255, 255, 0};
     done += 16;
     if (done >= njobs) {   // next level
       m = top;
@@ -989,31 +995,39 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail(const T
 }
 
 // A few outputs (a lone proof's verification, tier-0 MSMs, R and S of a lone prover): one wave per output and one QUAD per window.
-// Quad j adds the `dup` inputs of weight 2^(shift j) and shifts the sum by shift * j doublings — the doublings of the 16 windows run
-// side by side instead of one after the other in a Horner chain, each spread over the four lanes (g1_28_quad.hpp: 4.4 us instead of
-// 7.6 us) — then the window sums and the extra partial sums are added in a tree of quad additions: shift * (group - 1) doublings
-// and ~6 additions deep (0.6 ms for the verifier's 16 x 2 + 8 partial sums; the one-lane Horner chain took 1.6 ms).
-// Needs group <= 16 and group * dup + extra_per_out <= 64.
+// The `dup` inputs of a window are added in a tree, quad j then shifts the sum of window j by shift * j doublings — the doublings
+// of the 16 windows run side by side instead of one after the other in a Horner chain, each spread over the four lanes
+// (g1_28_quad.hpp: 4.4 us instead of 7.6 us) — and the window sums and the extra partial sums are added in a tree of quad
+// additions: shift * (group - 1) doublings and ~6 additions deep (0.6 ms for the verifier's 16 x 2 + 8 partial sums; the one-lane
+// Horner chain took 1.6 ms).  Needs group <= 16, dup a power of two, extra_per_out <= 64 and group * dup + extra_per_out <= 255.
 template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail_wave(const TJac* __restrict__ in, TJac* __restrict__ out, Jac* __restrict__ out_std,
                                                                               int group, int shift, const TJac* __restrict__ extra, int extra_per_out, int dup) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [65]: the inputs, then the window sums and extras; [64] = identity
+  TAcc* buf = reinterpret_cast<TAcc*>(smem);   // [nin + extra + 1]: the inputs, then the window sums and extras; the last = identity
   const int t = blockIdx.x, lane = threadIdx.x, quad = lane >> 2, sub = lane & 3;
-  const int nin = group * dup;
-  {
-    TJac p = TJac::identity();
-    if (lane < nin) p = in[(size_t)t * nin + lane];
-    else if (lane < nin + extra_per_out) p = extra[(size_t)t * extra_per_out + (lane - nin)];
-    buf[lane] = xyzz28_from_jac(p);
-    if (lane == 0) buf[64] = TAcc::identity();
-  }
+  const int nin = group * dup, nall = nin + extra_per_out;
+  const uint8_t ident = (uint8_t)nall;
+  for (int i = lane; i < nall; i += 64) buf[i] = xyzz28_from_jac(i < nin ? in[(size_t)t * nin + i] : extra[(size_t)t * extra_per_out + (i - nin)]);
+  if (lane == 0) buf[nall] = TAcc::identity();
   __syncthreads();
-  // the inputs of a window: dup - 1 rounds, quad j adds input d of window j to input 0
-  quad_exec(buf, dup - 1, [&](int r, int q, bool&) {
-    return q < group ? QuadJob{(uint8_t)(q * dup), (uint8_t)(q * dup + r + 1), (uint8_t)(q * dup), 1} : QuadJob{64, 64, 64, 0};
-  });
-  TAcc acc = buf[quad < group ? quad * dup : 64];
-  TAcc ex = buf[64];
+  {   // the inputs of a window: halving tree, level h adds entry i + h to entry i (i < h) of every window
+    int nrounds = 0;
+    for (int h = dup / 2; h >= 1; h >>= 1) nrounds += (group * h + 15) / 16;
+    int h = dup / 2, done = 0;
+    quad_exec(buf, nrounds, [&](int, int q, bool&) {
+      const int j = done + q, njobs = group * h;
+      const int w = j / h, i = j % h;
+      const QuadJob jb = j < njobs ? QuadJob{(uint8_t)(w * dup + i), (uint8_t)(w * dup + i + h), (uint8_t)(w * dup + i), 1} : QuadJob{ident, ident, ident, 0};
+      done += 16;
+      if (done >= njobs) {
+        h >>= 1;
+        done = 0;
+      }
+      return jb;
+    });
+  }
+  TAcc acc = buf[quad < group ? quad * dup : nall];
+  TAcc ex = buf[nall];
   if (lane < extra_per_out) ex = buf[nin + lane];
   const int nd = shift * (group - 1), mine = quad < group ? shift * quad : 0;
   for (int s = 0; s < nd; s++) {
@@ -1023,7 +1037,9 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail_wave(co
   __syncthreads();                              // every quad holds its window sum: the inputs may go
   if (quad < group && sub == 0) buf[quad] = acc;
   if (lane < extra_per_out) buf[group + lane] = ex;
+  if (lane == 0) buf[group + extra_per_out] = TAcc::identity();
   __syncthreads();
+  const uint8_t ident2 = (uint8_t)(group + extra_per_out);
   int m = group + extra_per_out, nrounds = 0;
   for (int mm = m; mm > 1;) {
     int top = 1;
@@ -1035,7 +1051,7 @@ template <bool STD_OUT> __global__ __launch_bounds__(64) void k_msm_tail_wave(co
   while (top * 2 < m) top *= 2;
   quad_exec(buf, nrounds, [&](int, int q, bool&) {
     const int j = done + q, njobs = m - top;
-    const QuadJob jb = j < njobs ? QuadJob{(uint8_t)j, (uint8_t)(j + top), (uint8_t)j, 1} : QuadJob{64, 64, 64, 0};
+    const QuadJob jb = j < njobs ? QuadJob{(uint8_t)j, (uint8_t)(j + top), (uint8_t)j, 1} : QuadJob{ident2, ident2, ident2, 0};
     done += 16;
     if (done >= njobs) {   // next level
       m = top;
@@ -1500,8 +1516,9 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
     const char* e = getenv("CPX_TAIL_WAVE_MAX");
     return e ? atol(e) : 256L;
   }();
-  if (nout <= wave_max && shift > 0 && group <= 16 && group * dup + extra_per_out <= 64) {   // a few outputs: wave per output, windows shifted side by side
-    const size_t lds = 65 * sizeof(TAcc);
+  if (nout <= wave_max && shift > 0 && group <= 16 && dup >= 1 && (dup & (dup - 1)) == 0 && extra_per_out <= 64 &&
+      group * dup + extra_per_out <= 255) {   // a few outputs: wave per output, windows shifted side by side
+    const size_t lds = (size_t)(group * dup + extra_per_out + 1) * sizeof(TAcc);
     if (d_out_std) CPX_LAUNCH(k_msm_tail_wave<true>, dim3(nout), dim3(64), lds, s, d_in, d_out, d_out_std, group, shift, d_extra, extra_per_out, dup);
     else CPX_LAUNCH(k_msm_tail_wave<false>, dim3(nout), dim3(64), lds, s, d_in, d_out, d_out_std, group, shift, d_extra, extra_per_out, dup);
     return;
@@ -1510,16 +1527,16 @@ void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, in
   else CPX_LAUNCH(k_msm_tail<false>, dim3((nout + 63) / 64), dim3(64), 0, s, d_in, d_out, d_out_std, nout, group, shift, d_extra, extra_per_out, dup);
 }
 void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
-                     hipStream_t s) {
+                     hipStream_t s, int slices) {
   if (ntasks <= 0) return;
   {
     hipEvent_t ea = tl_ev_start, eb = tl_ev_stop;   // the profiling events belong to the accumulation kernel
     tl_ev_start = tl_ev_stop = nullptr;
-    CPX_LAUNCH(k_to_table_endo, dim3((std::max(max_n, 1) + 63) / 64, ntasks), dim3(64), 0, s, d_tasks, d_conv, d_digits, d_ttasks);
+    CPX_LAUNCH(k_to_table_endo, dim3((std::max(max_n, 1) + 63) / 64, ntasks), dim3(64), 0, s, d_tasks, d_conv, d_digits, d_ttasks, slices);
     tl_ev_start = ea;
     tl_ev_stop = eb;
   }
-  CPX_LAUNCH((k_msm_tblw<2, true>), dim3(ntasks * 16), dim3(64), TBW_LDS, s, d_ttasks, d_raw, d_raw_slot);
+  CPX_LAUNCH((k_msm_tblw<2, true>), dim3(ntasks * 16 * slices), dim3(64), TBW_LDS, s, d_ttasks, d_raw, d_raw_slot, slices);
 }
 int msm_tblw_windows_per_wave(int ntasks) {
   // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2);
@@ -1542,15 +1559,31 @@ int msm_tblw_windows_per_wave(int ntasks) {
   return 8;
 }
 int msm_tblw_parts(int wpw) { return 64 / wpw; }
-void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
+int msm_tblw_slices(int ntasks, int wpw, int max_n) {
+  // waves per task over its points: only when the GPU would otherwise stand almost empty (a lone proof: 16 waves per task) and a
+  // slice keeps >= 256 points — below that the longest of a wave's 128 bucket lists no longer shrinks with the slice (a lane adds
+  // max, not mean, and 64 points leave lists of 0..6), while every slice costs two more sets to reduce
+  static const int forced = [] {   // CPX_TBW_SLICES=1|2|4 pins it
+    const char* e = getenv("CPX_TBW_SLICES");
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4) ? v : 0;
+  }();
+  if (forced) return forced;
+  if (wpw != 2) return 1;
+  const long waves = (long)ntasks * 16;
+  int s = waves * 4 <= 1024 ? 4 : waves * 2 <= 1024 ? 2 : 1;
+  while (s > 1 && max_n / s < 256) s >>= 1;
+  return s;
+}
+void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s, int slices) {
   if (ntasks <= 0) return;
-  const dim3 grid(ntasks * (TBW_WINDOWS / wpw)), block(64);
+  const dim3 grid(ntasks * (TBW_WINDOWS / wpw) * slices), block(64);
   switch (wpw) {
-    case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
-    case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
-    case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
-    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
-    default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot); break;
+    case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
+    case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
+    case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
+    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
+    default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
   }
 }
 size_t raw_set_words() { return RAW_SET_WORDS; }
@@ -1617,7 +1650,7 @@ void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const u
     return e ? atol(e) : 512L;
   }();
   if (n <= wave_max) {   // a few proofs: wave per request (tree over the partial sums)
-    CPX_LAUNCH(k_finalize_ranges_wave, dim3(n), dim3(64), 65 * sizeof(TAcc), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
+    CPX_LAUNCH(k_finalize_ranges_wave, dim3(n), dim3(64), 256 * sizeof(TAcc), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
     return;
   }
   CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);

@@ -1554,8 +1554,12 @@ int msm_tblw_windows_per_wave(int ntasks) {
   for (int wpw = 32; wpw > 8; wpw >>= 1)
     if ((long)ntasks * (TBW_WINDOWS / wpw) >= min_waves) return wpw;
   // a few proofs in flight: latency matters, so spread a task over as many (short) waves as the GPU can hold at once
-  if ((long)ntasks * 16 <= 2048) return 2;
-  if ((long)ntasks * 8 <= 2048) return 4;
+  static const long lat_waves = [] {   // CPX_TBW_LAT_WAVES
+    const char* e = getenv("CPX_TBW_LAT_WAVES");
+    return e ? atol(e) : 2048L;
+  }();
+  if ((long)ntasks * 16 <= lat_waves) return 2;
+  if ((long)ntasks * 8 <= lat_waves) return 4;
   return 8;
 }
 int msm_tblw_parts(int wpw) { return 64 / wpw; }
@@ -1594,7 +1598,7 @@ void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int n
   // throughput instantiations, so that tests reach the throughput kernels with small batches
   static const long wave_max = [] {
     const char* e = getenv("CPX_REDUCE_WAVE_MAX");
-    return e ? atol(e) : 2048L;
+    return e ? atol(e) : 16384L;   // (measured: 64 ... 512 proofs per pass gain 5-9 % over the switch at 2048 sets; beyond, the work-efficient form wins)
   }();
   if (nsets <= wave_max) {   // a few proofs: wave per set, both kinds in one launch
     CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), QP_ENTRIES * sizeof(TAcc), s, d_raw, d_raw_slot, nplain, d_part);
@@ -1619,9 +1623,13 @@ int msm_fix_windows_per_wave(int ntasks, int cbits) {
     return e ? atol(e) : 4096L;   // two waves per SIMD
   }();
   if ((long)ntasks * (w / 16) >= min_waves) return 16;
+  static const long lat_waves = [] {   // CPX_FIX_LAT_WAVES: up to how many waves the short-wave forms may launch
+    const char* e = getenv("CPX_FIX_LAT_WAVES");
+    return e ? atol(e) : 2048L;
+  }();
   if (cbits == 16) {   // a few proofs in flight: more, shorter waves per task
-    if ((long)ntasks * 8 <= 2048) return 2;
-    if ((long)ntasks * 4 <= 2048) return 4;
+    if ((long)ntasks * 8 <= lat_waves) return 2;
+    if ((long)ntasks * 4 <= lat_waves) return 4;
   }
   return 8;
 }

@@ -39,3 +39,9 @@ dt = time.perf_counter() - t0
 print("B=%d ell=%d: %.0f proofs/s, %.1f ms per pass (prove %.1f + verify %.1f), ok=%s  [%s]" % (
     B, ell, B * reps / dt, 1e3 * dt / reps, 1e3 * tp / reps, 1e3 * tv / reps, ok,
     " ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith("CPX_"))))
+if os.environ.get("SWEEP_STATS"):   # per-kernel times of one more pass (event timing serialises the kernels: shares, not wall time)
+    c.set_profiling(True); c.reset_stats()
+    pr = c.prove_batch(a[0], a[1], a[2], a[3], raw=True)
+    c.verify_batch(pr, a[4])
+    for k, v in sorted(c.stats().items(), key=lambda kv: -kv[1]["ms"]):
+        if v["launches"]: print("  %-24s %8.2f ms x%d" % (k, v["ms"], v["launches"]))

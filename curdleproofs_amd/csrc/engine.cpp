@@ -325,7 +325,7 @@ void Engine::ensure_raw_sets(size_t nsets) {
 }
 void Engine::reduce_sets(size_t nplain, size_t nweighted, TJac* part) {
   tick("k_reduce_sets", 0, (double)(nplain + nweighted), true);   // up to four launches (groups of 8 lanes, then the groups of a set; plain / bucket sets)
-  launch_reduce_sets(d_raw_.p, d_rawslot_.p, (int)nplain, (int)nweighted, d_rawmid_.p, part ? part : d_tpart_.p, stream_);
+  launch_reduce_sets(d_raw_.p, d_rawslot_.p, (int)nplain, (int)nweighted, d_rawmid_.p, part ? part : d_tpart_.p, stream_, (int)B_);
   tock();
 }
 
@@ -1040,7 +1040,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     side_.mid.ensure(nsets * 16);
     side_.part.ensure(nsets);
     launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, sside, (int)slices);
-    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nsets, side_.mid.p, side_.part.p, sside);
+    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nsets, side_.mid.p, side_.part.p, sside, (int)B);
     launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, sside, nullptr, 0, (int)(2 * slices));
     launch_finalize(side_.res.p, (int)(2 * B), d_pp_.p, side_.dst.p, nullptr, sside);
   }
@@ -1083,7 +1083,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(tab_.blob.p, tab_.stage.p, b_blob, hipMemcpyHostToDevice, tab_.stream));
     const uint32_t* d_u32 = reinterpret_cast<const uint32_t*>(tab_.blob.p + b_scal + b_tt);
     launch_msm_tblw(reinterpret_cast<const TblTask*>(tab_.blob.p + b_scal), (int)nt, wpw, tab_.raw.p, tab_.rawslot.p, tab_.stream, tslices);
-    launch_reduce_sets(tab_.raw.p, tab_.rawslot.p, 0, (int)(nt * parts), tab_.mid.p, tab_.part.p, tab_.stream);
+    launch_reduce_sets(tab_.raw.p, tab_.rawslot.p, 0, (int)(nt * parts), tab_.mid.p, tab_.part.p, tab_.stream, (int)B);
     launch_finalize_ranges(tab_.part.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, tab_.comp.p, tab_.stream);
     CPX_HIP(hipMemcpyAsync(tab_.hcomp.p, tab_.comp.p, nt * 48, hipMemcpyDeviceToHost, tab_.stream));
     CPX_HIP(hipEventRecord(tab_.ev_done, tab_.stream));

@@ -78,7 +78,9 @@ size_t raw_set_words();
 void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
                      hipStream_t s, int slices = 1);
 // The first nplain sets are plain sums, the following nweighted ones bucket sets (lower / upper half alternating).
-void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s);   // d_mid: 16 TJac per set
+// nproofs: how many proofs the batch in flight holds (0: unknown) — picks between the wave-per-set and the work-efficient kernels
+void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s,
+                        int nproofs = 0);   // d_mid: 16 TJac per set
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
 // endo = false: copy c = 2^(256 c / C) P.   endo = true (the tables k_msm_tblw reads): copies 0..C/2-1 = 2^(8c) P and

@@ -1591,15 +1591,19 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_ra
   }
 }
 size_t raw_set_words() { return RAW_SET_WORDS; }
-void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s) {
+void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s, int nproofs) {
   const int nsets = nplain + nweighted;
   if (nsets <= 0) return;
   // CPX_REDUCE_WAVE_MAX / CPX_FINALIZE_WAVE_MAX move the switch-over between the latency (wave per item) and the
-  // throughput instantiations, so that tests reach the throughput kernels with small batches
-  static const long wave_max = [] {
+  // throughput instantiations, so that tests reach the throughput kernels with small batches.
+  // The wave form spends ~4x the lane time of the work-efficient form: it pays while the GPU is not full — up to 16384 sets when
+  // at most 512 proofs are in flight (64 ... 512 proofs per pass: +5-9 %); a large batch (several contexts keep the GPU busy) keeps
+  // it for launches of at most 2048 sets (at 16384 for every batch size the bench lost 3 %)
+  static const long forced = [] {
     const char* e = getenv("CPX_REDUCE_WAVE_MAX");
-    return e ? atol(e) : 16384L;   // (measured: 64 ... 512 proofs per pass gain 5-9 % over the switch at 2048 sets; beyond, the work-efficient form wins)
+    return e ? atol(e) : -1L;
   }();
+  const long wave_max = forced >= 0 ? forced : (nproofs > 0 && nproofs <= 512 ? 16384L : 2048L);
   if (nsets <= wave_max) {   // a few proofs: wave per set, both kinds in one launch
     CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), QP_ENTRIES * sizeof(TAcc), s, d_raw, d_raw_slot, nplain, d_part);
     return;

@@ -514,12 +514,17 @@ THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAV
 
 
 @pytest.mark.parametrize("env", [{"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_MIN_BATCH": "1"}, {"CPX_DEVICE_MIN_BATCH": "1000000"}, THROUGHPUT_ENV,
-                                 dict(THROUGHPUT_ENV, CPX_DEVICE_MIN_BATCH="1")],
-                         ids=["fix8", "device_resident", "host_driven", "throughput_kernels", "throughput_kernels_device_resident"])
+                                 dict(THROUGHPUT_ENV, CPX_DEVICE_MIN_BATCH="1"),
+                                 {"CPX_TBW_SLICES": "4", "CPX_DEVICE_MIN_BATCH": "1000000"}, {"CPX_TBW_SLICES": "2", "CPX_TAIL_WAVE_MAX": "0"},
+                                 {"CPX_CU_MASK": "0", "CPX_REDUCE_WAVE_MAX": "1000000", "CPX_FINALIZE_WAVE_MAX": "1000000"}],
+                         ids=["fix8", "device_resident", "host_driven", "throughput_kernels", "throughput_kernels_device_resident",
+                              "four_point_slices_host_driven", "two_point_slices_thread_tail", "plain_streams_wave_kernels_everywhere"])
 def test_engine_variants_stay_bit_exact(env):
     # the 8-bit fixed-base table, the device-resident protocol (step kernels of protocol.hip; normally used from 32 proofs per
     # batch on) forced on single proofs, the host-driven protocol forced on a batch of 40, and the throughput instantiations
-    # of the MSM / reduction / finalisation kernels are alternative engine configurations; all must reproduce the reference
+    # of the MSM / reduction / finalisation kernels, the point slices of the bucket-list MSM (msm_tblw_slices: by default only
+    # tasks of >= 512 points of a lone proof are sliced) and the latency kernels forced onto every batch size
+    # are alternative engine configurations; all must reproduce the reference
     # KAT (whisk.rs:416-456), the oracle's bytes at ell = 28 / 252 and the oracle's verdicts
     import subprocess
     import sys

@@ -444,6 +444,12 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   CPX_HIP(hipMemcpyAsync(d_blob_.p, h_stage_.p, b_blob, hipMemcpyHostToDevice, stream_));
   const size_t fix_sets = nft * fix_parts, tbl_sets = ntt * tbl_parts;   // raw sets: [fixed-base waves | bucket sets of the table waves]
   ensure_raw_sets(fix_sets + tbl_sets);
+  if (nft && ntt && fix_bits_ == 16 && fix_wpw == 2 && tbl_wpw == 2) {   // a lone proof: both MSM kernels of the phase in one launch
+    tick("k_msm_fix_tblw", 128.0 * (pts_fix + pts_tbl), pts_fix + pts_tbl);
+    launch_msm_fix_tblw(d_ft, (int)nft, fixtab(), (int)nc(), d_raw_.p, d_rawslot_.p, d_tt, (int)ntt, tbl_slices, d_raw_.p + fix_sets * raw_set_words(),
+                        d_rawslot_.p + fix_sets, stream_);
+    tock();
+  } else {
   if (nft) {
     tick(fix_kernel_name(fix_bits_, fix_wpw), 128.0 * pts_fix, pts_fix);
     launch_msm_fix(d_ft, (int)nft, fixtab(), fix_bits_, fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
@@ -453,6 +459,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     tick(tblw_kernel_name(tbl_wpw), 128.0 * pts_tbl, pts_tbl);
     launch_msm_tblw(d_tt, (int)ntt, tbl_wpw, d_raw_.p + fix_sets * raw_set_words(), d_rawslot_.p + fix_sets, stream_, tbl_slices);
     tock();
+  }
   }
   reduce_sets(fix_sets, tbl_sets);
   tick("k_finalize_ranges", 0, (double)nt);

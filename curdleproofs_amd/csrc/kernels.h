@@ -103,6 +103,9 @@ struct FixTask {
 };
 int msm_fix_windows_per_wave(int ntasks, int cbits);
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TFix* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
+// k_msm_fix<16, 2> and k_msm_tblw<2, false> of one phase in ONE launch (a lone proof: neither fills the GPU)
+void launch_msm_fix_tblw(const FixTask* d_ftasks, int nftasks, const TFix* d_fix_tab, int nc, uint32_t* d_fraw, uint32_t* d_fraw_slot, const TblTask* d_ttasks,
+                         int nttasks, int slices, uint32_t* d_traw, uint32_t* d_traw_slot, hipStream_t s);
 // shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
 // output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)

@@ -520,8 +520,8 @@ __device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, uint32_t& n
 // PERWIN (k_msm_tblw<2, true>): the same wave over bases WITHOUT shifted copies (the verifier's per-proof points, used once):
 // the "table" has two copies, P and -phi(P) (k_to_table_endo), wave w of a task takes digit w of |t| and of q, and the
 // 16 window results carry the weights 2^(8w) (Horner tail, k_msm_tail).
-template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
-                                                                                            uint32_t* __restrict__ raw_slot, int slices) {
+template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
+                                                                            uint32_t* __restrict__ raw_slot, int slices, const uint32_t bid) {
   static_assert(!PERWIN || WPW == 2, "one window of each half per wave");
   constexpr int WV = PERWIN ? 16 : TBW_WINDOWS / WPW;   // waves per task
   constexpr int NW = (WPW + 3) / 4;
@@ -533,13 +533,13 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
   uint8_t* order = reinterpret_cast<uint8_t*>(start + 128);           // [128] buckets by size
   // a few tasks in flight (latency matters): `slices` waves share a task's points (each its own 64-aligned range and raw sets), so
   // that a lane's chain of additions is a quarter as long; slices = 1 otherwise
-  const TblTask task = tasks[blockIdx.x / (WV * slices)];
-  const int wv = (blockIdx.x / slices) % WV, w0 = PERWIN ? wv : wv * WPW, slice = blockIdx.x % slices;
+  const TblTask task = tasks[bid / (WV * slices)];
+  const int wv = (bid / slices) % WV, w0 = PERWIN ? wv : wv * WPW, slice = bid % slices;
   const int lane = threadIdx.x;
   const uint32_t nall = task.seg[0].n + task.seg[1].n, per = ((nall + slices - 1) / slices + 63) & ~63u;
   const uint32_t first = min(nall, (uint32_t)slice * per), ntot = min(nall, first + per);
-  uint32_t* raw0 = raw + (size_t)blockIdx.x * 2 * RAW_SET_WORDS;
-  if (lane < 2) raw_slot[blockIdx.x * 2 + lane] = task.pad + 2 * (wv * slices + slice) + lane;   // task.pad = first partial slot of the task
+  uint32_t* raw0 = raw + (size_t)bid * 2 * RAW_SET_WORDS;
+  if (lane < 2) raw_slot[bid * 2 + lane] = task.pad + 2 * (wv * slices + slice) + lane;   // task.pad = first partial slot of the task
 
   uint32_t next = first;
   bool later = false;   // a later round: the accumulators are parked in raw0 / raw1
@@ -638,6 +638,10 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
     later = true;
   } while (next < ntot);
 }
+template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
+                                                                                            uint32_t* __restrict__ raw_slot, int slices) {
+  msm_tblw_body<WPW, PERWIN>(tasks, raw, raw_slot, slices, blockIdx.x);
+}
 
 // ------------------------------------------------------------------ fixed-base MSM over multiples tables
 constexpr int FIX_CHUNK = 256;
@@ -661,15 +665,15 @@ template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint3
 // One wave = FIX_WPW windows x (64 / FIX_WPW) point slices of one task.  16 windows per wave (a whole radix-2^16
 // task) keeps the fixed 6-step tree reduction small against the per-lane additions (n/4 per lane); 8 windows
 // per wave double the number of waves when the launch would not fill the GPU otherwise.
-template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TFix* __restrict__ tab, int nc,
-                                                                     uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot) {
+template <int CB, int FIX_WPW> __device__ __forceinline__ void msm_fix_body(const FixTask* __restrict__ tasks, const TFix* __restrict__ tab, int nc,
+                                                                          uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot, const uint32_t bid) {
   constexpr int W = 256 / CB, WG = W / FIX_WPW;    // waves per task
   constexpr int LPW = 64 / FIX_WPW;                // lanes (point slices) per window
   constexpr uint32_t M = 1u << (CB - 1);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int16_t* digits = reinterpret_cast<int16_t*>(smem);   // [FIX_WPW][FIX_CHUNK]
-  const FixTask task = tasks[blockIdx.x / WG];
-  const int wg = blockIdx.x % WG;
+  const FixTask task = tasks[bid / WG];
+  const int wg = bid % WG;
   const int lane = threadIdx.x;
   const int wl = lane / LPW, sl = lane % LPW;
   const uint32_t w = (uint32_t)(wg * FIX_WPW + wl);
@@ -703,8 +707,21 @@ template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fi
     }
   }
   // all entries carry weight 1: the wave's 64 accumulators form one plain raw set (k_reduce_sets adds them up)
-  raw_store(raw + (size_t)blockIdx.x * RAW_SET_WORDS, lane, xacc);
-  if (lane == 0) raw_slot[blockIdx.x] = task.out_first + wg;
+  raw_store(raw + (size_t)bid * RAW_SET_WORDS, lane, xacc);
+  if (lane == 0) raw_slot[bid] = task.out_first + wg;
+}
+template <int CB, int FIX_WPW> __global__ __launch_bounds__(64, 2) void k_msm_fix(const FixTask* __restrict__ tasks, const TFix* __restrict__ tab, int nc,
+                                                                     uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot) {
+  msm_fix_body<CB, FIX_WPW>(tasks, tab, nc, raw, raw_slot, blockIdx.x);
+}
+// A lone proof's phase: the fixed-base waves and the shifted-table waves of a phase do not depend on each other, and each of the two
+// launches leaves most of the GPU empty (8 waves per fixed-base task, 16 per table task).  One launch for both: the first
+// nfix_blocks work-groups run the fixed-base body, the rest the table body (39 + 95 us one after the other -> the longer of the two).
+__global__ __launch_bounds__(64, 2) void k_msm_fix_tblw(const FixTask* __restrict__ ftasks, const TFix* __restrict__ tab, int nc, uint32_t* __restrict__ fraw,
+                                                        uint32_t* __restrict__ fraw_slot, uint32_t nfix_blocks, const TblTask* __restrict__ ttasks,
+                                                        uint32_t* __restrict__ traw, uint32_t* __restrict__ traw_slot, int slices) {
+  if (blockIdx.x < nfix_blocks) msm_fix_body<16, 2>(ftasks, tab, nc, fraw, fraw_slot, blockIdx.x);
+  else msm_tblw_body<2, false>(ttasks, traw, traw_slot, slices, blockIdx.x - nfix_blocks);
 }
 
 // Table of multiples from the shifted copies: thread per (window, base) walks m = 1..M with mixed additions and
@@ -1647,6 +1664,13 @@ void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TFix* d_fix_tab, i
   else if (cbits == 16) CPX_LAUNCH((k_msm_fix<16, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
   else if (wpw == 16) CPX_LAUNCH((k_msm_fix<8, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
   else CPX_LAUNCH((k_msm_fix<8, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+}
+void launch_msm_fix_tblw(const FixTask* d_ftasks, int nftasks, const TFix* d_fix_tab, int nc, uint32_t* d_fraw, uint32_t* d_fraw_slot, const TblTask* d_ttasks,
+                         int nttasks, int slices, uint32_t* d_traw, uint32_t* d_traw_slot, hipStream_t s) {
+  const uint32_t nfix_blocks = (uint32_t)nftasks * 8, ntbl_blocks = (uint32_t)nttasks * 16 * (uint32_t)slices;
+  const size_t lds = std::max<size_t>(16 * FIX_CHUNK * 2, TBW_LDS);
+  CPX_LAUNCH(k_msm_fix_tblw, dim3(nfix_blocks + ntbl_blocks), dim3(64), lds, s, d_ftasks, d_fix_tab, nc, d_fraw, d_fraw_slot, nfix_blocks, d_ttasks, d_traw,
+             d_traw_slot, slices);
 }
 void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
   const int W = 256 / cbits, total = W * nc;

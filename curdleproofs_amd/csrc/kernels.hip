@@ -462,6 +462,7 @@ constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
 constexpr int TBW_CAP = 8704;         // list entries per round
 constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index
 constexpr int TBW_LDS = TBW_CAP * 2 + 3 * 128 * 4 + 128;
+constexpr int TBW_LDS_CACHE = TBW_LDS + TBW_ROUND_PTS * 4;   // k_msm_tblw<2, false> keeps a round's recoded digits (below)
 static_assert(TBW_CAP >= 64 * TBW_WINDOWS, "one slab always fits");
 
 __device__ __forceinline__ const TAff* tbl_point(const TblTask& t, uint32_t g, uint32_t copy) {
@@ -531,6 +532,11 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
   uint32_t* cur = cnt + 128;                                          // [128] scatter cursors
   uint32_t* start = cur + 128;                                        // [128] list offsets
   uint8_t* order = reinterpret_cast<uint8_t*>(start + 128);           // [128] buckets by size
+  // the latency form (two windows per wave, a lone proof): the split + recoding of a scalar (~700 instructions) is done in the
+  // histogram pass and kept for the scatter pass (one word per point); the other forms recompute it (2 x per 4-32 windows: < 1 %
+  // of their additions, and 4 KB more LDS per wave would cost them the second wave per SIMD)
+  constexpr bool CACHE = WPW == 2 && !PERWIN;
+  uint32_t* dcache = reinterpret_cast<uint32_t*>(smem + TBW_LDS);      // [TBW_ROUND_PTS], CACHE only
   // a few tasks in flight (latency matters): `slices` waves share a task's points (each its own 64-aligned range and raw sets), so
   // that a lane's chain of additions is a quarter as long; slices = 1 otherwise
   const TblTask task = tasks[bid / (WV * slices)];
@@ -555,6 +561,7 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
       int mine = 0;
       if (i < ntot) {
         tbw_digits<WPW, PERWIN>(task, i, w0, dg, sg_lo, sg_hi);
+        if (CACHE) dcache[i - next] = (dg[0] & 0xffffu) | (sg_lo << 16) | (sg_hi << 17);
         CPX_UNROLL for (int j = 0; j < WPW; j++) {
           uint32_t neg;
           mine += tbw_bucket(dg[j >> 2], j, neg) < 128u ? 1 : 0;
@@ -607,7 +614,14 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
       const uint32_t i = s0 + lane;
       if (i < end) {
         uint32_t dg[NW], sg_lo, sg_hi;
-        tbw_digits<WPW, PERWIN>(task, i, w0, dg, sg_lo, sg_hi);
+        if (CACHE) {
+          const uint32_t v = dcache[i - next];
+          dg[0] = v & 0xffffu;
+          sg_lo = (v >> 16) & 1u;
+          sg_hi = (v >> 17) & 1u;
+        } else {
+          tbw_digits<WPW, PERWIN>(task, i, w0, dg, sg_lo, sg_hi);
+        }
         CPX_UNROLL for (int j = 0; j < WPW; j++) {
           uint32_t neg;
           const uint32_t b = tbw_bucket(dg[j >> 2], j, neg);
@@ -1603,7 +1617,7 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_ra
     case 32: CPX_LAUNCH(k_msm_tblw<32>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
     case 16: CPX_LAUNCH(k_msm_tblw<16>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
     case 4: CPX_LAUNCH(k_msm_tblw<4>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
-    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
+    case 2: CPX_LAUNCH(k_msm_tblw<2>, grid, block, TBW_LDS_CACHE, s, d_tasks, d_raw, d_raw_slot, slices); break;
     default: CPX_LAUNCH(k_msm_tblw<8>, grid, block, TBW_LDS, s, d_tasks, d_raw, d_raw_slot, slices); break;
   }
 }
@@ -1668,7 +1682,7 @@ void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TFix* d_fix_tab, i
 void launch_msm_fix_tblw(const FixTask* d_ftasks, int nftasks, const TFix* d_fix_tab, int nc, uint32_t* d_fraw, uint32_t* d_fraw_slot, const TblTask* d_ttasks,
                          int nttasks, int slices, uint32_t* d_traw, uint32_t* d_traw_slot, hipStream_t s) {
   const uint32_t nfix_blocks = (uint32_t)nftasks * 8, ntbl_blocks = (uint32_t)nttasks * 16 * (uint32_t)slices;
-  const size_t lds = std::max<size_t>(16 * FIX_CHUNK * 2, TBW_LDS);
+  const size_t lds = std::max<size_t>(16 * FIX_CHUNK * 2, TBW_LDS_CACHE);
   CPX_LAUNCH(k_msm_fix_tblw, dim3(nfix_blocks + ntbl_blocks), dim3(64), lds, s, d_ftasks, d_fix_tab, nc, d_fraw, d_fraw_slot, nfix_blocks, d_ttasks, d_traw,
              d_traw_slot, slices);
 }

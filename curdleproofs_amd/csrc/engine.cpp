@@ -166,7 +166,11 @@ void WorkerPool::run(size_t n, const std::function<void(size_t)>& f) {
 }
 
 template <class F> void Engine::parallel_for(size_t n, F&& f) {
-  if (n < 16) {   // a handful of items: waking the pool (tens of sleeping threads) costs more than the work
+  static const size_t inline_below = [] {
+    const char* e = getenv("CPX_INLINE_BELOW");
+    return e ? (size_t)atol(e) : (size_t)16;
+  }();
+  if (n < inline_below) {   // a handful of items: waking the pool (tens of sleeping threads) costs more than the work
     for (size_t i = 0; i < n; i++) f(i);
     return;
   }

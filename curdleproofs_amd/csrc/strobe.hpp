@@ -73,8 +73,17 @@ struct Strobe {
     pos = pos_begin = 0;
   }
   CPX_HD void absorb(const uint8_t* d, size_t n) {
-    for (size_t i = 0; i < n; i++) {
-      xor_byte(pos, d[i]);
+    size_t i = 0;
+    while (i < n) {
+      if ((pos & 7) == 0 && n - i >= 8 && pos + 8 <= RATE) {   // a whole lane of the state at once (the instance prefix is 48 KB)
+        uint64_t v = 0;
+        CPX_UNROLL for (int j = 0; j < 8; j++) v |= (uint64_t)d[i + j] << (8 * j);
+        st[pos >> 3] ^= v;
+        pos += 8;   // (RATE is not a multiple of 8: the boundary is always reached byte by byte)
+        i += 8;
+        continue;
+      }
+      xor_byte(pos, d[i++]);
       if (++pos == RATE) run_f();
     }
   }

@@ -165,7 +165,99 @@ void WorkerPool::run(size_t n, const std::function<void(size_t)>& f) {
   if (err_) std::rethrow_exception(err_);
 }
 
+SpinTeam::SpinTeam(size_t helpers) {
+  for (size_t i = 0; i < helpers; i++) threads_.emplace_back([this] { worker(); });
+}
+SpinTeam::~SpinTeam() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+    spinning_.store(false, std::memory_order_release);
+  }
+  cv_.notify_all();
+  for (auto& t : threads_) t.join();
+}
+void SpinTeam::engage() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    spinning_.store(true, std::memory_order_release);
+  }
+  cv_.notify_all();
+}
+void SpinTeam::release() { spinning_.store(false, std::memory_order_release); }
+void SpinTeam::drain() {
+  const std::function<void(size_t)>* job = job_.load(std::memory_order_acquire);
+  const size_t n = n_.load(std::memory_order_acquire);
+  if (!job) return;
+  for (;;) {
+    const size_t i = next_.fetch_add(1, std::memory_order_acq_rel);
+    if (i >= n) break;
+    try {
+      (*job)(i);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(err_mu_);
+      if (!err_) err_ = std::current_exception();
+    }
+    done_.fetch_add(1, std::memory_order_acq_rel);
+  }
+}
+void SpinTeam::worker() {
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return stop_ || spinning_.load(std::memory_order_acquire); });
+      if (stop_) return;
+    }
+    uint64_t seen = 0;   // (a job of an earlier engagement is complete: draining it again finds no items)
+    while (spinning_.load(std::memory_order_acquire)) {
+      const uint64_t e = epoch_.load(std::memory_order_acquire);
+      if (e != seen) {
+        seen = e;
+        in_drain_.fetch_add(1, std::memory_order_acq_rel);
+        if (epoch_.load(std::memory_order_acquire) == e) drain();   // (the job may have completed and gone in between)
+        in_drain_.fetch_sub(1, std::memory_order_acq_rel);
+      } else {
+        __builtin_ia32_pause();
+      }
+    }
+  }
+}
+void SpinTeam::run(size_t n, const std::function<void(size_t)>& f) {
+  if (!n) return;
+  err_ = nullptr;
+  n_.store(n, std::memory_order_relaxed);
+  done_.store(0, std::memory_order_relaxed);
+  next_.store(0, std::memory_order_relaxed);
+  job_.store(&f, std::memory_order_release);
+  epoch_.fetch_add(1, std::memory_order_acq_rel);
+  drain();
+  while (done_.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+  // no helper may still be inside this job's drain() when the next job resets the counters (or f goes out of scope)
+  job_.store(nullptr, std::memory_order_release);
+  epoch_.fetch_add(1, std::memory_order_acq_rel);
+  while (in_drain_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  if (err_) std::rethrow_exception(err_);
+}
+Engine::TeamScope::TeamScope(Engine* e, size_t batch) {
+  static const bool off = [] {
+    const char* v = getenv("CPX_SPIN_TEAM");
+    return v && atoi(v) == 0;
+  }();
+  if (off || batch < 2) return;
+  const size_t want = std::min<size_t>(batch, e->host_threads_ > 0 ? (size_t)e->host_threads_ : 8);
+  if (want < 2) return;
+  if (!e->team_ || e->team_->size() < want) e->team_.reset(new SpinTeam(want - 1));
+  t = e->team_.get();
+  t->engage();
+}
+
 template <class F> void Engine::parallel_for(size_t n, F&& f) {
+  if (team_ && team_->engaged() && n >= 2) {   // a small batch's call: spinning helpers (TeamScope)
+    const std::function<void(size_t)> fn = [&](size_t i) { f(i); };
+    HostSpan w(this, "host_parallel_for");
+    team_->run(n, fn);
+    return;
+  }
   static const size_t inline_below = [] {
     const char* e = getenv("CPX_INLINE_BELOW");
     return e ? (size_t)atol(e) : (size_t)16;
@@ -912,6 +1004,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipEventCreateWithFlags(&side_.lat_ev, hipEventDisableTiming));
   }
   const hipStream_t sside = side_.lat_stream;
+  TeamScope team(this, B);   // 2 ... 31 proofs: the host loops between the phases on spinning helper threads
   StreamSwap lat_main(stream_, B <= 8 ? side_.lat_main : nullptr, side_.lat_ev);   // a few proofs: the phases on the lower half of the CUs
   const SlotMap sm(L);
   const size_t nrand = 3 * n + 9;
@@ -1520,6 +1613,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     return;
   }
 
+  TeamScope team(this, B);   // 2 ... 31 proofs: the host loops on spinning helper threads
   struct VState {
     Transcript tr{"curdleproofs"};
     bool bad = false;           // deserialisation failure

@@ -100,6 +100,36 @@ class WorkerPool {
   std::exception_ptr err_;
 };
 
+// A few helper threads that SPIN between jobs while engaged.  The host-driven path of a small batch (2 ... 31 proofs) runs a loop
+// over the proofs between every two MSM phases — 20-100 us of transcript and scalar work per proof, every ~0.3 ms, 40 times per
+// call: a sleeping pool wakes too slowly for that (tens of us per wake-up) and the loop run inline makes the call scale with the
+// batch (12.7 ms at 4 proofs against 6.8 ms at 1).  engage() at the start of the call, release() at its end; in between the
+// helpers poll an epoch counter.
+class SpinTeam {
+ public:
+  explicit SpinTeam(size_t helpers);
+  ~SpinTeam();
+  size_t size() const { return threads_.size() + 1; }
+  void engage();
+  void release();
+  bool engaged() const { return spinning_.load(std::memory_order_relaxed); }
+  void run(size_t n, const std::function<void(size_t)>& f);   // the caller takes part; exceptions are rethrown
+
+ private:
+  void worker();
+  void drain();
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool stop_ = false;                       // guarded by mu_
+  std::atomic<bool> spinning_{false};
+  std::atomic<uint64_t> epoch_{0};
+  std::atomic<size_t> next_{0}, done_{0}, n_{0}, in_drain_{0};
+  std::atomic<const std::function<void(size_t)>*> job_{nullptr};
+  std::mutex err_mu_;
+  std::exception_ptr err_;
+};
+
 // kernel names as rocprofv3 reports the template instantiations (statistics keys)
 inline const char* fix_kernel_name(int bits, int wpw) {
   if (bits == 16) return wpw == 16 ? "k_msm_fix<16, 16>" : wpw == 8 ? "k_msm_fix<16, 8>" : wpw == 4 ? "k_msm_fix<16, 4>" : "k_msm_fix<16, 2>";
@@ -292,6 +322,14 @@ class Engine {
   void tock();
   void flush_timers();
   template <class F> void parallel_for(size_t n, F&& f);
+  std::unique_ptr<SpinTeam> team_;
+  struct TeamScope {   // engages the spin team for a small batch's call
+    SpinTeam* t = nullptr;
+    TeamScope(Engine* e, size_t batch);
+    ~TeamScope() {
+      if (t) t->release();
+    }
+  };
   struct HostSpan {
     HostSpan(Engine* e, const char* name);
     ~HostSpan();

@@ -288,7 +288,8 @@ void Engine::wait_stream() {
   CPX_HIP(hipStreamSynchronize(stream_));
 }
 
-// Batches of at least CPX_DEVICE_MIN_BATCH proofs (default 32) run the whole protocol on the GPU (engine_device.cpp).  Smaller
+// Batches of at least CPX_DEVICE_MIN_BATCH proofs (default 96: measured cross-over with the spin team of the host-driven path,
+// 21.9 against 35.1 ms per prove + verify pass at 32 proofs, 36.3 against 43.6 ms at 96, 59 against 54 ms at 192) run the whole protocol on the GPU (engine_device.cpp).  Smaller
 // batches are driven from the host: a lone transcript is latency-bound on a GPU wave (~4 us per Keccak permutation against
 // ~0.25 us on a host core, ~1000 permutations per proof), and the host has idle cores.  In the host-driven mode the
 // transcript prefix of every loaded proof is hashed on the host as well.
@@ -296,7 +297,7 @@ bool Engine::device_prefix(size_t B) const {
   static const size_t min_batch = [] {
     const char* e = getenv("CPX_DEVICE_MIN_BATCH");
     if (!e) e = getenv("CPX_DEVICE_TRANSCRIPT_MIN_BATCH");   // former name
-    return e ? (size_t)atol(e) : (size_t)32;
+    return e ? (size_t)atol(e) : (size_t)96;
   }();
   return B >= min_batch;
 }

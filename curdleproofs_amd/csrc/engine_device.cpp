@@ -1,6 +1,6 @@
 // Device-resident batch prover / verifier of the engine — product code (see engine.hpp, protocol.h).
 //
-// For batches of >= 32 proofs (CPX_DEVICE_TRANSCRIPT_MIN_BATCH) the whole protocol runs on the GPU: the MSM phases read their
+// For batches of >= 96 proofs (CPX_DEVICE_MIN_BATCH) the whole protocol runs on the GPU: the MSM phases read their
 // scalars from device memory through task descriptors that are built ONCE per loaded batch shape ("plans"), the
 // finalisation kernels leave the compressed results in a per-proof slot registry, and one-wave-per-proof step kernels
 // (protocol.hip) hash them into the transcripts and derive the next phase's scalars.  The host only enqueues: no

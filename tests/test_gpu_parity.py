@@ -368,7 +368,8 @@ def test_prove_verify_ell60(ctx, orc):
 
 def test_prove_verify_batch40_ell28(ctx, orc):
     # 40 independent instances (BASELINE config 4 recipe: instance i from StdRng(i)): large enough for the engine's
-    # batch paths (transcript prefix on the device from 32 proofs on, multi-chunk host loops); every proof must equal
+    # batch paths (host-driven protocol on the spin team below 96 proofs, multi-chunk host loops; the device-resident form of this
+    # test runs in test_engine_variants_stay_bit_exact); every proof must equal
     # the oracle's bytes and verify
     _prove_and_check(ctx, orc, 28, list(range(100, 140)))
 
@@ -520,7 +521,7 @@ THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAV
                          ids=["fix8", "device_resident", "host_driven", "throughput_kernels", "throughput_kernels_device_resident",
                               "four_point_slices_host_driven", "two_point_slices_thread_tail", "plain_streams_wave_kernels_everywhere"])
 def test_engine_variants_stay_bit_exact(env):
-    # the 8-bit fixed-base table, the device-resident protocol (step kernels of protocol.hip; normally used from 32 proofs per
+    # the 8-bit fixed-base table, the device-resident protocol (step kernels of protocol.hip; normally used from 96 proofs per
     # batch on) forced on single proofs, the host-driven protocol forced on a batch of 40, and the throughput instantiations
     # of the MSM / reduction / finalisation kernels, the point slices of the bucket-list MSM (msm_tblw_slices: by default only
     # tasks of >= 512 points of a lone proof are sliced) and the latency kernels forced onto every batch size
@@ -715,12 +716,12 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(d["value"] - 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
 
 
-@pytest.mark.parametrize("copies", [1, 33], ids=["host_driven", "device_resident"])
+@pytest.mark.parametrize("copies", [1, 97], ids=["host_driven", "device_resident"])
 def test_instances_with_identity_points_and_repeated_points(ctx, orc, copies):
     """Edge instances the reference accepts as inputs: a ciphertext whose components are the point at infinity (R_i = S_i = O, hence an
     identity column in the per-proof tables of T and U, an identity base in the R / S MSMs and a 0xc0 encoding in the hashed instance)
     and two identical ciphertexts (equal bases next to each other in every bucket list).  Proof bytes and verdicts must equal the
-    oracle's, on the host-driven path (one proof) and on the device-resident path (33 copies of the instance)."""
+    oracle's, on the host-driven path (one proof) and on the device-resident path (97 copies of the instance)."""
     import curdleproofs_amd as cpx
     ell = 28
     crs = orc.generate_crs_points(ell)

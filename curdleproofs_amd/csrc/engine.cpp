@@ -98,146 +98,6 @@ void Engine::flush_timers() {
   pending_.clear();
 }
 
-WorkerPool::WorkerPool(size_t threads) {
-  for (size_t i = 1; i < threads; i++) threads_.emplace_back([this] { worker(); });
-}
-WorkerPool::~WorkerPool() {
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    stop_ = true;
-  }
-  cv_.notify_all();
-  for (auto& t : threads_) t.join();
-}
-// Items are claimed through an atomic counter in small chunks (no lock on the hot path); the mutex only
-// guards job hand-off and completion.
-void WorkerPool::drain() {
-  const size_t n = n_, chunk = chunk_;
-  for (;;) {
-    const size_t b = next_.fetch_add(chunk, std::memory_order_relaxed);
-    if (b >= n) break;
-    const size_t e = std::min(n, b + chunk);
-    try {
-      for (size_t i = b; i < e; i++) (*job_)(i);
-    } catch (...) {
-      std::lock_guard<std::mutex> lk(mu_);
-      if (!err_) err_ = std::current_exception();
-      next_.store(n, std::memory_order_relaxed);
-    }
-  }
-}
-void WorkerPool::worker() {
-  uint64_t seen = 0;
-  for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && job_); });
-      if (stop_) return;
-      seen = epoch_;
-      active_++;
-    }
-    drain();
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      active_--;
-      if (active_ == 0) done_cv_.notify_all();
-    }
-  }
-}
-void WorkerPool::run(size_t n, const std::function<void(size_t)>& f) {
-  if (!n) return;
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    job_ = &f;
-    n_ = n;
-    chunk_ = std::max<size_t>(1, n / (8 * size()));
-    next_.store(0, std::memory_order_relaxed);
-    err_ = nullptr;
-    epoch_++;
-    active_++;
-  }
-  cv_.notify_all();
-  drain();
-  std::unique_lock<std::mutex> lk(mu_);
-  active_--;
-  done_cv_.wait(lk, [&] { return active_ == 0; });
-  job_ = nullptr;
-  if (err_) std::rethrow_exception(err_);
-}
-
-SpinTeam::SpinTeam(size_t helpers) {
-  for (size_t i = 0; i < helpers; i++) threads_.emplace_back([this] { worker(); });
-}
-SpinTeam::~SpinTeam() {
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    stop_ = true;
-    spinning_.store(false, std::memory_order_release);
-  }
-  cv_.notify_all();
-  for (auto& t : threads_) t.join();
-}
-void SpinTeam::engage() {
-  {
-    std::lock_guard<std::mutex> lk(mu_);
-    spinning_.store(true, std::memory_order_release);
-  }
-  cv_.notify_all();
-}
-void SpinTeam::release() { spinning_.store(false, std::memory_order_release); }
-void SpinTeam::drain() {
-  const std::function<void(size_t)>* job = job_.load(std::memory_order_acquire);
-  const size_t n = n_.load(std::memory_order_acquire);
-  if (!job) return;
-  for (;;) {
-    const size_t i = next_.fetch_add(1, std::memory_order_acq_rel);
-    if (i >= n) break;
-    try {
-      (*job)(i);
-    } catch (...) {
-      std::lock_guard<std::mutex> lk(err_mu_);
-      if (!err_) err_ = std::current_exception();
-    }
-    done_.fetch_add(1, std::memory_order_acq_rel);
-  }
-}
-void SpinTeam::worker() {
-  for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [&] { return stop_ || spinning_.load(std::memory_order_acquire); });
-      if (stop_) return;
-    }
-    uint64_t seen = 0;   // (a job of an earlier engagement is complete: draining it again finds no items)
-    while (spinning_.load(std::memory_order_acquire)) {
-      const uint64_t e = epoch_.load(std::memory_order_acquire);
-      if (e != seen) {
-        seen = e;
-        in_drain_.fetch_add(1, std::memory_order_acq_rel);
-        if (epoch_.load(std::memory_order_acquire) == e) drain();   // (the job may have completed and gone in between)
-        in_drain_.fetch_sub(1, std::memory_order_acq_rel);
-      } else {
-        __builtin_ia32_pause();
-      }
-    }
-  }
-}
-void SpinTeam::run(size_t n, const std::function<void(size_t)>& f) {
-  if (!n) return;
-  err_ = nullptr;
-  n_.store(n, std::memory_order_relaxed);
-  done_.store(0, std::memory_order_relaxed);
-  next_.store(0, std::memory_order_relaxed);
-  job_.store(&f, std::memory_order_release);
-  epoch_.fetch_add(1, std::memory_order_acq_rel);
-  drain();
-  while (done_.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
-  // no helper may still be inside this job's drain() when the next job resets the counters (or f goes out of scope)
-  job_.store(nullptr, std::memory_order_release);
-  epoch_.fetch_add(1, std::memory_order_acq_rel);
-  while (in_drain_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
-  if (err_) std::rethrow_exception(err_);
-}
 Engine::TeamScope::TeamScope(Engine* e, size_t batch) {
   static const bool off = [] {
     const char* v = getenv("CPX_SPIN_TEAM");

@@ -20,6 +20,7 @@
 #include <vector>
 #include "../../include/cpx.h"   // public error codes
 #include "host_math.hpp"
+#include "host_threads.hpp"
 #include "kernels.h"
 #include "protocol.h"
 
@@ -75,60 +76,6 @@ struct KernelStat {
   double units = 0;       // MSM points / scalar-mul elements / points processed
 };
 
-
-// Persistent host worker pool: the per-phase Fiat-Shamir / Fr work of a batch is spread over these threads
-// (spawning threads per phase cost ~100 ms per step at 50 phases x 64 threads).
-class WorkerPool {
- public:
-  explicit WorkerPool(size_t threads);
-  ~WorkerPool();
-  size_t size() const { return threads_.size() + 1; }
-  // runs f(i) for i in [0, n); the calling thread participates; exceptions are rethrown
-  void run(size_t n, const std::function<void(size_t)>& f);
-
- private:
-  void worker();
-  void drain();
-  std::vector<std::thread> threads_;
-  std::mutex mu_;
-  std::condition_variable cv_, done_cv_;
-  const std::function<void(size_t)>* job_ = nullptr;
-  size_t n_ = 0, chunk_ = 1, active_ = 0;
-  std::atomic<size_t> next_{0};
-  uint64_t epoch_ = 0;
-  bool stop_ = false;
-  std::exception_ptr err_;
-};
-
-// A few helper threads that SPIN between jobs while engaged.  The host-driven path of a small batch (2 ... 31 proofs) runs a loop
-// over the proofs between every two MSM phases — 20-100 us of transcript and scalar work per proof, every ~0.3 ms, 40 times per
-// call: a sleeping pool wakes too slowly for that (tens of us per wake-up) and the loop run inline makes the call scale with the
-// batch (12.7 ms at 4 proofs against 6.8 ms at 1).  engage() at the start of the call, release() at its end; in between the
-// helpers poll an epoch counter.
-class SpinTeam {
- public:
-  explicit SpinTeam(size_t helpers);
-  ~SpinTeam();
-  size_t size() const { return threads_.size() + 1; }
-  void engage();
-  void release();
-  bool engaged() const { return spinning_.load(std::memory_order_relaxed); }
-  void run(size_t n, const std::function<void(size_t)>& f);   // the caller takes part; exceptions are rethrown
-
- private:
-  void worker();
-  void drain();
-  std::vector<std::thread> threads_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  bool stop_ = false;                       // guarded by mu_
-  std::atomic<bool> spinning_{false};
-  std::atomic<uint64_t> epoch_{0};
-  std::atomic<size_t> next_{0}, done_{0}, n_{0}, in_drain_{0};
-  std::atomic<const std::function<void(size_t)>*> job_{nullptr};
-  std::mutex err_mu_;
-  std::exception_ptr err_;
-};
 
 // kernel names as rocprofv3 reports the template instantiations (statistics keys)
 inline const char* fix_kernel_name(int bits, int wpw) {

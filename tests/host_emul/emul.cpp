@@ -11,6 +11,9 @@
 #include "../../curdleproofs_amd/csrc/glv.hpp"
 #include "../../curdleproofs_amd/csrc/recode.hpp"
 #include "../../curdleproofs_amd/csrc/host_math.hpp"
+#include "../../curdleproofs_amd/csrc/quad_program.hpp"
+#include "../../curdleproofs_amd/csrc/host_threads.hpp"
+#include <stdexcept>
 
 using namespace cpx;
 
@@ -421,6 +424,95 @@ void emul_msm_endo(const uint8_t* bases, const uint8_t* scalars, size_t n, int p
   }
   const Jac r = t_jac_to_std(res);
   memcpy(out, &r, sizeof r);
+}
+
+// The reduction programs of k_reduce_sets_wave (quad_program.hpp: the tables the GPU runs) interpreted over integers: a point is
+// a number, an addition a sum, a doubling a product by two.  kind 0 = plain, 1 = bucket set (lower half), 2 = upper half.
+// out[0] = the result, out[1] = rounds, out[2] = addition rounds, out[3] = hazards (a job reading an entry another job of the
+// same round writes, two jobs writing one entry, an index outside the array).
+void emul_quad_program(int kind, const int64_t* in /* 64 */, int64_t* out /* 4 */) {
+  static constexpr QuadProgram progs[3] = {qp_plain(), qp_weighted(false), qp_weighted(true)};
+  const QuadProgram& p = progs[kind];
+  int64_t buf[QP_ENTRIES];
+  for (int i = 0; i < QP_ENTRIES; i++) buf[i] = i < 64 ? in[i] : 0x5555555555ll;   // scratch entries start as garbage
+  buf[QP_IDENT] = 0;
+  int64_t hazards = 0, add_rounds = 0;
+  for (int r = 0; r < p.nrounds; r++) {
+    int64_t res[16];
+    bool written[QP_ENTRIES] = {};
+    for (int q = 0; q < 16; q++) {
+      const QuadJob j = p.job[r][q];
+      if (j.a >= QP_ENTRIES || j.b >= QP_ENTRIES || j.dst >= QP_ENTRIES) hazards++;
+      res[q] = p.dbl[r] ? 2 * buf[j.a] : buf[j.a] + buf[j.b];
+      if (j.on) {
+        if (written[j.dst]) hazards++;
+        written[j.dst] = true;
+      }
+    }
+    for (int q = 0; q < 16; q++) {   // a read of an entry that ANOTHER job of the round writes depends on the quads' order
+      const QuadJob j = p.job[r][q];
+      if (written[j.a] && !(j.on && j.dst == j.a)) hazards++;
+      if (!p.dbl[r] && written[j.b] && !(j.on && j.dst == j.b)) hazards++;
+    }
+    for (int q = 0; q < 16; q++)
+      if (p.job[r][q].on) buf[p.job[r][q].dst] = res[q];
+    add_rounds += p.dbl[r] ? 0 : 1;
+  }
+  out[0] = buf[p.result];
+  out[1] = p.nrounds;
+  out[2] = add_rounds;
+  out[3] = hazards;
+}
+
+// The engine's thread helpers (host_threads.hpp).  kind 0 = WorkerPool, 1 = SpinTeam engaged, 2 = SpinTeam engaged / released
+// between jobs.  `jobs` parallel loops over n items each; every item adds its index + job number to a per-item cell and must be
+// visited exactly once; job number `throw_at` (if >= 0) throws from item 0 and the exception must reach the caller while the
+// other jobs stay intact.  Returns 0 if everything added up, a positive code otherwise.
+int emul_thread_helpers(int kind, size_t threads, size_t n, size_t jobs, long throw_at) {
+  std::vector<std::atomic<uint64_t>> cell(n);
+  for (auto& c : cell) c.store(0);
+  uint64_t expect = 0;
+  int caught = 0;
+  auto body = [&](size_t job) {
+    const std::function<void(size_t)> f = [&, job](size_t i) {
+      if ((long)job == throw_at && i == 0) throw std::runtime_error("item failed");
+      cell[i].fetch_add(i + job + 1);
+    };
+    return f;
+  };
+  if (kind == 0) {
+    WorkerPool pool(threads);
+    for (size_t j = 0; j < jobs; j++) {
+      try {
+        pool.run(n, body(j));
+      } catch (const std::runtime_error&) {
+        caught++;
+      }
+    }
+  } else {
+    SpinTeam team(threads - 1);
+    if (kind == 1) team.engage();
+    for (size_t j = 0; j < jobs; j++) {
+      if (kind == 2) team.engage();
+      try {
+        team.run(n, body(j));
+      } catch (const std::runtime_error&) {
+        caught++;
+      }
+      if (kind == 2) team.release();
+    }
+    team.release();
+  }
+  if (caught != (throw_at >= 0 && (size_t)throw_at < jobs ? 1 : 0)) return 1;
+  for (size_t i = 0; i < n; i++) {
+    expect = 0;
+    for (size_t j = 0; j < jobs; j++)
+      if (!((long)j == throw_at && i == 0)) expect += i + j + 1;
+    // (a WorkerPool job that throws stops handing out further items: only check the failed job's cells loosely)
+    const uint64_t got = cell[i].load();
+    if (throw_at < 0 ? got != expect : (got > expect || got + (i + (uint64_t)throw_at + 1) < expect)) return 2;
+  }
+  return 0;
 }
 
 }  // extern "C"

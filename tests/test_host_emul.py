@@ -18,9 +18,9 @@ FR, AFF, JAC = 32, 96, 144
 
 @pytest.fixture(scope="module")
 def emul():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.hpp", "g1.hpp", "recode.hpp", "host_math.hpp", "fp28.hpp", "g1_28.hpp", "modinv30.hpp", "strobe.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("mont32.hpp", "g1.hpp", "recode.hpp", "host_math.hpp", "fp28.hpp", "g1_28.hpp", "modinv30.hpp", "strobe.hpp", "quad_program.hpp", "host_threads.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", LIB, SRC])
     L = ctypes.CDLL(LIB)
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     L.emul_fp_mul.argtypes = [vp, vp, vp, sz]
@@ -40,6 +40,10 @@ def emul():
     L.emul_f28_mul.argtypes = [vp, vp, vp, sz]
     L.emul_f28_msm.argtypes = [vp, vp, sz, vp, vp]
     L.emul_f28_xyzz_sum.argtypes = [vp, sz, vp, vp, vp]
+    L.emul_quad_program.argtypes = [ctypes.c_int, vp, vp]
+    L.emul_quad_program.restype = None
+    L.emul_thread_helpers.argtypes = [ctypes.c_int, sz, sz, sz, ctypes.c_long]
+    L.emul_thread_helpers.restype = ctypes.c_int
     return L
 
 
@@ -337,3 +341,35 @@ def test_table_msm_kernel_algorithm(emul, orc, perwin):
     o = _o(JAC)
     emul.emul_msm_endo(_b(bytes(bases)), _b(bytes(scalars)), n, perwin, o)
     assert orc.g1_compress_jac(bytes(o)) == orc.g1_compress_jac(orc.g1_msm(bytes(bases), bytes(scalars), naive=True))
+
+
+def test_quad_reduction_programs(emul):
+    """k_reduce_sets_wave (kernels.hip) runs fixed programs of (operand, operand, destination) jobs, 16 per round, over an
+    array of points: quad_program.hpp.  Interpreted over integers (point = number) the plain program must return the sum of
+    its 64 inputs, the bucket-set programs sum (l + 1) A_l and sum (64 + l + 1) A_l — the weights k_msm_tblw's lane
+    accumulators carry (kernels.hip: lane l of set 2k + h holds bucket |d| = 64 h + l + 1) — and no job of a round may read
+    what another job of the same round writes."""
+    import random
+    rng = random.Random(5)
+    cases = [[rng.randrange(1, 1 << 40) for _ in range(64)] for _ in range(8)]
+    cases += [[1 if i == k else 0 for i in range(64)] for k in range(64)]          # every single weight
+    cases += [[0] * 64, [1] * 64]
+    for kind, weight in ((0, lambda l: 1), (1, lambda l: l + 1), (2, lambda l: 64 + l + 1)):
+        for vals in cases:
+            inp = (ctypes.c_int64 * 64)(*vals)
+            out = (ctypes.c_int64 * 4)()
+            emul.emul_quad_program(kind, inp, out)
+            assert out[0] == sum(weight(l) * v for l, v in enumerate(vals)), (kind, vals[:8])
+            assert out[3] == 0, "hazard inside a round"
+            assert out[1] <= 20 and out[2] == (7 if kind == 0 else 13)               # DESIGN.md section 4b: 7 / 13 addition rounds
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2], ids=["worker_pool", "spin_team", "spin_team_reengaged"])
+def test_thread_helpers_visit_every_item_once(emul, kind):
+    """host_threads.hpp: the sleeping pool of the large host loops and the spin team of a small batch's call (engaged for the
+    duration of a call, helpers poll an epoch counter).  Many short jobs back to back — the pattern of the host-driven protocol,
+    a loop over the proofs between every two MSM phases — must visit every item exactly once, with fewer items than threads,
+    with one item, and an exception thrown by an item must reach the caller without disturbing the following jobs."""
+    for threads, n, jobs in ((4, 7, 300), (8, 3, 300), (3, 1, 50), (2, 64, 100), (8, 31, 200)):
+        assert emul.emul_thread_helpers(kind, threads, n, jobs, -1) == 0, (threads, n, jobs)
+    assert emul.emul_thread_helpers(kind, 4, 9, 40, 17) == 0

@@ -104,7 +104,11 @@ Engine::TeamScope::TeamScope(Engine* e, size_t batch) {
     return v && atoi(v) == 0;
   }();
   if (off || batch < 2) return;
-  const size_t want = std::min<size_t>(batch, e->host_threads_ > 0 ? (size_t)e->host_threads_ : 8);
+  static const size_t team_max = [] {   // CPX_SPIN_TEAM_THREADS: size of the team when the context's host-thread count is not set
+    const char* v = getenv("CPX_SPIN_TEAM_THREADS");
+    return v && atoi(v) > 0 ? (size_t)atoi(v) : (size_t)8;
+  }();
+  const size_t want = std::min<size_t>(batch, e->host_threads_ > 0 ? (size_t)e->host_threads_ : team_max);
   if (want < 2) return;
   if (!e->team_ || e->team_->size() < want) e->team_.reset(new SpinTeam(want - 1));
   t = e->team_.get();

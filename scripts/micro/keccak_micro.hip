@@ -1,0 +1,38 @@
+// gfx950 latency of the lane-parallel Keccak-f[1600] of wave_strobe.hpp (32 lanes per state) and of a rate block absorbed from memory.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I curdleproofs_amd/csrc scripts/micro/keccak_micro.hip -o scripts/micro/keccak_micro
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include "wave_strobe.hpp"
+using namespace cpx;
+#define HIPCHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ __launch_bounds__(64) void k(const uint8_t* msg, size_t len, uint64_t* t, uint64_t* out, int reps) {
+  __shared__ uint8_t scratch_all[2][64];
+  WaveStrobe s;
+  s.l = threadIdx.x & 31;
+  s.init("bench", 5, scratch_all[threadIdx.x >> 5]);
+  uint64_t t0 = wall_clock64();
+  for (int i = 0; i < reps; i++) s.keccak();
+  uint64_t t1 = wall_clock64();
+  s.absorb(msg, len);
+  uint64_t t2 = wall_clock64();
+  if (s.l < 25) out[blockIdx.x * 64 + threadIdx.x] = s.a;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { t[0] = t1 - t0; t[1] = t2 - t1; }
+}
+int main() {
+  const size_t len = 166 * 256;
+  uint8_t* dmsg; uint64_t *dt, *dout;
+  HIPCHECK(hipMalloc(&dmsg, len)); HIPCHECK(hipMemset(dmsg, 0x5a, len)); HIPCHECK(hipMalloc(&dt, 64)); HIPCHECK(hipMalloc(&dout, 64 * 8 * 4096));
+  const int reps = 256;
+  for (int blocks : {1, 64, 2048, 4096}) {
+    for (int rep = 0; rep < 2; rep++) {
+      hipLaunchKernelGGL(k, dim3(blocks), dim3(64), 0, 0, dmsg, len, dt, dout, reps);
+      HIPCHECK(hipDeviceSynchronize());
+    }
+    uint64_t t[2];
+    HIPCHECK(hipMemcpy(t, dt, sizeof t, hipMemcpyDeviceToHost));
+    printf("%5d work-groups: keccak-f %.2f us each; absorbing a 166-byte block (+ its permutation) %.2f us\n", blocks, t[0] / 100.0 / reps, t[1] / 100.0 / 256);
+  }
+  return 0;
+}

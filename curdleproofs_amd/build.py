@@ -73,7 +73,20 @@ def build(force=False, verbose=False):
             print(out.decode())
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-lpthread"]
     subprocess.check_call(cmd)
+    build_selfcheck()
     return LIB
+
+
+SELFCHECK = os.path.join(OUT_DIR, "quad_selfcheck")
+
+
+def build_selfcheck():
+    """The device-side self-check of the quad-cooperative point formulas (g1_28_quad.hpp against the one-lane formulas of
+    g1_28.hpp, every special case), an executable that travels with the library; tests/test_gpu_parity.py runs it."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    src = os.path.join(HERE, "..", "scripts", "micro", "quad_micro.hip")
+    subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-I", CSRC, src, "-o", SELFCHECK])
+    return SELFCHECK
 
 
 if __name__ == "__main__":

@@ -56,10 +56,12 @@ __global__ __launch_bounds__(64) void k(const Aff* in, uint64_t* t, Aff* out_ref
   const TJac refd = t_dbl(ref);
   const TAcc rd = xyzz28_dbl_quad(rq);
   const TAcc rd1 = xyzz28_dbl(rq);
+  const TJac rdj = jac28_dbl_quad(ref);
   if ((lane & 3) == 0) { out_ref[quad] = to_aff_std(ref); out_ref[16 + quad] = to_aff_std(refd); out_ref[32 + quad] = to_aff_std(refd); }
   out_quad[lane] = to_aff_std(t_acc_to_jac(rq));
   out_quad[64 + lane] = to_aff_std(t_acc_to_jac(rd));
   out_quad[128 + lane] = to_aff_std(t_acc_to_jac(rd1));
+  out_quad[256 + lane] = to_aff_std(rdj);
   TJac pj = ref, qj = t_acc_to_jac(pb);
   uint64_t t0 = wall_clock64();
   for (int i = 0; i < reps; i++) pj = t_add(pj, qj);
@@ -87,7 +89,7 @@ int main() {
   const uint32_t gy[12] = {0x0ce72271, 0xbaac93d5, 0x7918fd8e, 0x8c22631a, 0x570725ce, 0xdd595f13, 0x50405194, 0x51ac5829, 0xad0059c0, 0x0e1c8c3f, 0x5008a26a, 0x0bbc3efc};
   memcpy(g.x.v, gx, 48); memcpy(g.y.v, gy, 48);
   Aff *din, *dref, *dq; uint64_t* dt;
-  HIPCHECK(hipMalloc(&din, 16 * sizeof(Aff))); HIPCHECK(hipMalloc(&dref, 64 * sizeof(Aff))); HIPCHECK(hipMalloc(&dq, 256 * sizeof(Aff))); HIPCHECK(hipMalloc(&dt, 64));
+  HIPCHECK(hipMalloc(&din, 16 * sizeof(Aff))); HIPCHECK(hipMalloc(&dref, 64 * sizeof(Aff))); HIPCHECK(hipMalloc(&dq, 320 * sizeof(Aff))); HIPCHECK(hipMalloc(&dt, 64));
   hipLaunchKernelGGL(k_mk, dim3(1), dim3(16), 0, 0, g, din);
   HIPCHECK(hipDeviceSynchronize());
   const int reps = 32;
@@ -97,7 +99,7 @@ int main() {
     hipLaunchKernelGGL(k_time, dim3(1), dim3(64), 0, 0, din, dt, dq + 192, reps);
     HIPCHECK(hipDeviceSynchronize());
   }
-  static Aff ref[64], q[256];
+  static Aff ref[64], q[320];
   uint64_t t[6];
   HIPCHECK(hipMemcpy(ref, dref, sizeof ref, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(q, dq, sizeof q, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(t, dt, sizeof t, hipMemcpyDeviceToHost));
   int bad = 0;
@@ -105,10 +107,11 @@ int main() {
     if (memcmp(&q[lane], &ref[lane >> 2], sizeof(Aff))) { bad++; printf("add mismatch lane %d\n", lane); }
     if (memcmp(&q[64 + lane], &ref[16 + (lane >> 2)], sizeof(Aff))) { bad++; printf("dbl_quad mismatch lane %d\n", lane); }
     if (memcmp(&q[128 + lane], &ref[32 + (lane >> 2)], sizeof(Aff))) { bad++; printf("dbl mismatch lane %d\n", lane); }
+    if (memcmp(&q[256 + lane], &ref[16 + (lane >> 2)], sizeof(Aff))) { bad++; printf("jac dbl_quad mismatch lane %d\n", lane); }
   }
   int ident = 0;
   for (int qd = 0; qd < 16; qd++) { bool z = true; for (int j = 0; j < 12; j++) z = z && ref[qd].x.v[j] == 0 && ref[qd].y.v[j] == 0; ident += z; }
-  printf("checked 3 x 64 results against the one-lane formulas: %d mismatches (%d identity results among the sums)\n", bad, ident);
+  printf("checked 4 x 64 results against the one-lane formulas: %d mismatches (%d identity results among the sums)\n", bad, ident);
   const double us = 1.0 / 100.0;
   printf("t_add (Jacobian, one lane)   %.2f us each\n", t[0] * us / reps);
   printf("xyzz28_add_quad              %.2f us each\n", t[4] * us / reps);

@@ -26,6 +26,17 @@ def test_native_library_loaded():
     assert L.cpx_device_count() >= 1, "no HIP device visible: the product path has no CPU fallback"
 
 
+def test_quad_cooperative_formulas_match_one_lane_formulas():
+    """g1_28_quad.hpp (point additions / doublings spread over the four lanes of a quad: the latency kernels) against the
+    one-lane formulas of g1_28.hpp on the device: generic sums, P + P, P - P, identity operands, doublings.  The check is
+    scripts/micro/quad_micro.hip, built with the library (curdleproofs_amd/build.py)."""
+    import subprocess
+    from curdleproofs_amd.build import SELFCHECK
+    assert os.path.exists(SELFCHECK), "run python -m curdleproofs_amd.build"
+    r = subprocess.run([SELFCHECK], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 31, 32, 33, 64, 128, 252, 256, 257, 300, 600])
 def test_msm_matches_oracle(ctx, orc, n):
     rng = orc.rng(1000 + n)

@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
   uint8_t* scratch = scratch_all[grp];
   if (p >= nproofs) return;   // whole 32-lane groups leave together
   WaveStrobe t;
-  t.l = threadIdx.x & 31;
+  t.set_lane(threadIdx.x & 31);
   t.init("curdleproofs", 12, scratch);
   for (int v = 0; v < 4; v++) {   // Vec<G1Affine>: u64-LE length prefix, then the compressed points, as one message
     t.append_begin("curdleproofs_step1", 18, 8 + 48 * (size_t)ell, scratch);
@@ -1368,15 +1368,15 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
       t.len4(64, scratch);
       t.begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
       // squeeze 64 bytes = lanes 0..7 of the state, which the PRF operation overwrites with zero (pos is 0 here)
-      uint64_t w[4];
-      CPX_UNROLL for (int j = 0; j < 4; j++) w[j] = t.shfl(t.a, j);
-      if (t.l < 8) t.a = 0;
+      uint64_t sq[4];
+      CPX_UNROLL for (int j = 0; j < 4; j++) sq[j] = t.shfl(t.a, WaveStrobe::lane_of_word(j));
+      if (t.w >= 0 && t.w < 8) t.a = 0;
       t.pos = 64;
-      w[3] &= 0x7fffffffffffffffULL;
+      sq[3] &= 0x7fffffffffffffffULL;
       Fr c;
       CPX_UNROLL for (int j = 0; j < 4; j++) {
-        c.v[2 * j] = (uint32_t)w[j];
-        c.v[2 * j + 1] = (uint32_t)(w[j] >> 32);
+        c.v[2 * j] = (uint32_t)sq[j];
+        c.v[2 * j + 1] = (uint32_t)(sq[j] >> 32);
       }
       bool nz = false, lt = false;
       for (int j = 0; j < 8; j++) nz |= c.v[j] != 0;
@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
       }
       if (lt && nz) {
         if (t.l < 4) {
-          CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * t.l + j] = (uint8_t)(w[t.l] >> (8 * j));
+          CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * t.l + j] = (uint8_t)(sq[t.l] >> (8 * j));
         }
         wave_lds_sync();
         t.append_begin("curdleproofs_vec_a", 18, 32, scratch);
@@ -1398,10 +1398,7 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
       }
     }
   }
-  uint64_t* o = out_state + (size_t)p * 27;
-  if (t.l < 25) o[t.l] = t.a;
-  if (t.l == 25) o[25] = t.pos;
-  if (t.l == 26) o[26] = t.pos_begin;
+  t.store(out_state + (size_t)p * 27);
 }
 
 // ------------------------------------------------------------------ micro-benchmarks (bench.py --micro)

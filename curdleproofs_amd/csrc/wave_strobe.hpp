@@ -1,9 +1,13 @@
 // Lane-parallel STROBE-128 / Keccak-f[1600] for the device side of the transcripts — product code (device only).
 //
-// Half a wave (32 lanes) per transcript: lane l < 25 holds 64-bit lane l of the Keccak state (x = l % 5, y = l / 5); a round
-// is 9 cross-lane shuffles (theta 6, rho+pi 1, chi 2) instead of ~150 dependent 64-bit operations on one lane (a single
-// GPU lane needs ~17 us per permutation, the 32-lane form ~4 us).  Message bytes are absorbed by the lane that owns their
-// position in the rate.  Same semantics as strobe.hpp (the host's code, merlin 3.0.0 as used by transcript.rs:28-60 of
+// Half a wave (32 lanes) per transcript: 25 of the lanes hold one 64-bit word of the Keccak state each — word x + 5 y sits in lane
+// 5 y + x (+ 1 for y >= 3): lane 15 stays empty so that no plane (the five words of one y) straddles the two 16-lane DPP rows of
+// the group.  A round is then two stages of ds_bpermute (theta's column parities: 4 shuffles; rho + pi: 1) and two stages of DPP row
+// shifts (theta's neighbour columns — a column parity is the same in every plane, so lane l - 1 / l + 1 has it — and chi's x + 1,
+// x + 2 inside the plane), instead of ~150 dependent 64-bit operations on one lane (a single GPU lane needs ~17 us per
+// permutation; this form 5.6 us alone on a SIMD and 7.1 us with 4096 groups in flight, with all four stages as ds_bpermute 6.0 and
+// 9.6 us: scripts/micro/keccak_micro.hip, which also checks it against the host permutation; +0.5 % on the bench, 12.80 k against
+// 12.74 k proofs/s on the same box).  Message bytes are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.hpp (the host's code, merlin 3.0.0 as used by transcript.rs:28-60 of
 // the reference), pinned by the bit-exact proof tests.  When a whole 64-lane wave drives ONE transcript, both halves run
 // the same operations on the same inputs and hold identical copies of the state.
 #pragma once
@@ -21,9 +25,22 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 struct WaveStrobe {
-  uint64_t a;                 // this lane's 64-bit lane of the state (lanes >= 25 keep 0)
+  uint64_t a;                 // this lane's 64-bit word of the state (lanes without a word keep 0)
   uint32_t pos, pos_begin;    // uniform over the 32 lanes of a proof
   int l;                      // lane within the 32-lane group
+  int w;                      // the state word this lane holds (0..24), -1 for the empty lanes 15 and 26..31
+
+  static __device__ __forceinline__ int lane_of_word(int word) { return word + (word >= 15 ? 1 : 0); }
+  static __device__ __forceinline__ int word_of_lane(int lane) { return lane < 15 ? lane : (lane >= 16 && lane <= 25 ? lane - 1 : -1); }
+  __device__ __forceinline__ void set_lane(int lane_in_group) {
+    l = lane_in_group;
+    w = word_of_lane(l);
+  }
+  template <int CTRL> static __device__ __forceinline__ uint64_t dpp64(uint64_t v) {   // out-of-row sources read as zero
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
+    return ((uint64_t)hi << 32) | lo;
+  }
 
   __device__ __forceinline__ uint64_t shfl(uint64_t v, int src) const {
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 32), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 32);
@@ -38,25 +55,34 @@ struct WaveStrobe {
                              0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
     // rotation offsets r[x + 5y] of rho
     const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    const int lc = l < 25 ? l : 0;   // idle lanes mirror lane 0 (their value is never used)
-    const int x = lc % 5, y = lc / 5;
+    constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110;   // DPP row shifts: row_shl:n reads lane i + n, row_shr:n lane i - n (within 16 lanes)
+    const int wc = w >= 0 ? w : 0;   // empty lanes run along on word 0's indices (nobody reads them, they are cleared at the end)
+    const int x = wc % 5, y = wc / 5;
+    int col[4];
+    CPX_UNROLL for (int k = 1; k < 5; k++) col[k - 1] = lane_of_word(x + 5 * ((y + k) % 5));
     // rho + pi as a gather: destination (X, Y) = (y, (2x + 3y) % 5)  <=>  source x = (X + 3Y) % 5, y = X
-    const int sx = (x + 3 * y) % 5, sy = x, src = sx + 5 * sy, rot = RHO[src];
-    const int xm1 = (x + 4) % 5 + 5 * y, xp1 = (x + 1) % 5 + 5 * y, xp2 = (x + 2) % 5 + 5 * y;
+    const int sx = (x + 3 * y) % 5, sy = x, src = lane_of_word(sx + 5 * sy), rot = RHO[sx + 5 * sy];
+    // a column parity is the same in all planes: lane l - 1 holds column x - 1 and lane l + 1 column x + 1, except next to the
+    // row ends and the empty lanes, where the lane four further holds the same column
+    const bool m1_alt = l == 0 || l == 16, p1_alt = l == 14 || l == 25;
     for (int r = 0; r < 24; r++) {
       uint64_t c = a;
-      CPX_UNROLL for (int k = 1; k < 5; k++) c ^= shfl(a, (lc + 5 * k) % 25);     // column parity (same for every y)
-      const uint64_t d = shfl(c, xm1) ^ rol64(shfl(c, xp1), 1);
-      a ^= d;
+      CPX_UNROLL for (int k = 0; k < 4; k++) c ^= shfl(a, col[k]);
+      // (both candidates are fetched by every lane, then one is picked: a DPP read inside a divergent branch would see disabled lanes)
+      const uint64_t cm_a = dpp64<ROW_SHL + 4>(c), cm_b = dpp64<ROW_SHR + 1>(c), cp_a = dpp64<ROW_SHR + 4>(c), cp_b = dpp64<ROW_SHL + 1>(c);
+      const uint64_t cm1 = m1_alt ? cm_a : cm_b, cp1 = p1_alt ? cp_a : cp_b;
+      a ^= cm1 ^ rol64(cp1, 1);
       uint64_t b = shfl(a, src);
       b = rot ? ((b << rot) | (b >> (64 - rot))) : b;
-      a = b ^ (~shfl(b, xp1) & shfl(b, xp2));
-      if (l == 0) a ^= RC[r];
+      const uint64_t b1_a = dpp64<ROW_SHL + 1>(b), b1_b = dpp64<ROW_SHR + 4>(b), b2_a = dpp64<ROW_SHL + 2>(b), b2_b = dpp64<ROW_SHR + 3>(b);
+      const uint64_t b1 = x < 4 ? b1_a : b1_b, b2 = x < 3 ? b2_a : b2_b;   // (x + 1) % 5, (x + 2) % 5 of the same plane
+      a = b ^ (~b1 & b2);
+      if (w == 0) a ^= RC[r];
     }
-    if (l >= 25) a = 0;
+    if (w < 0) a = 0;
   }
   __device__ __forceinline__ void xor_byte(uint32_t i, uint8_t b) {
-    if ((int)(i >> 3) == l) a ^= (uint64_t)b << (8 * (i & 7));
+    if ((int)(i >> 3) == w) a ^= (uint64_t)b << (8 * (i & 7));
   }
   __device__ void run_f() {
     xor_byte(pos, (uint8_t)pos_begin);
@@ -71,8 +97,8 @@ struct WaveStrobe {
       const uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), n);
       uint64_t v = 0;
       CPX_UNROLL for (int j = 0; j < 8; j++) {
-        const uint32_t sidx = 8u * (uint32_t)l + j;   // state byte owned by this lane
-        if (sidx >= pos && sidx < pos + k) v |= (uint64_t)d[sidx - pos] << (8 * j);
+        const uint32_t sidx = 8u * (uint32_t)w + j;   // state byte owned by this lane (w = -1: beyond every position)
+        if (w >= 0 && sidx >= pos && sidx < pos + k) v |= (uint64_t)d[sidx - pos] << (8 * j);
       }
       a ^= v;
       pos += k;
@@ -117,15 +143,15 @@ struct WaveStrobe {
   }
   // ---- state import / export ([27] u64: 25 lanes, pos, pos_begin — the layout host::Transcript::load_state reads) ----
   __device__ __forceinline__ void load(const uint64_t* st27, int lane_in_group) {
-    l = lane_in_group;
-    a = l < 25 ? st27[l] : 0;
+    set_lane(lane_in_group);
+    a = w >= 0 ? st27[w] : 0;
     pos = (uint32_t)st27[25];
     pos_begin = (uint32_t)st27[26];
   }
   __device__ __forceinline__ void store(uint64_t* st27) const {
-    if (l < 25) st27[l] = a;
-    if (l == 25) st27[25] = pos;
-    if (l == 26) st27[26] = pos_begin;
+    if (w >= 0) st27[w] = a;
+    if (l == 26) st27[25] = pos;
+    if (l == 27) st27[26] = pos_begin;
   }
   // append_message(label, data): data readable by every lane (global / LDS / constant)
   __device__ void append_message(const char* label, size_t label_len, const uint8_t* data, size_t len, uint8_t* scratch) {
@@ -153,15 +179,15 @@ struct WaveStrobe {
       len4(64, scratch);
       begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
       // squeeze 64 bytes = lanes 0..7 of the state, which the PRF operation overwrites with zero (pos is 0 here)
-      uint64_t w[4];
-      CPX_UNROLL for (int j = 0; j < 4; j++) w[j] = shfl(a, j);
-      if (l < 8) a = 0;
+      uint64_t sq[4];
+      CPX_UNROLL for (int j = 0; j < 4; j++) sq[j] = shfl(a, lane_of_word(j));
+      if (w >= 0 && w < 8) a = 0;
       pos = 64;
-      w[3] &= 0x7fffffffffffffffULL;
+      sq[3] &= 0x7fffffffffffffffULL;
       Fr c;
       CPX_UNROLL for (int j = 0; j < 4; j++) {
-        c.v[2 * j] = (uint32_t)w[j];
-        c.v[2 * j + 1] = (uint32_t)(w[j] >> 32);
+        c.v[2 * j] = (uint32_t)sq[j];
+        c.v[2 * j + 1] = (uint32_t)(sq[j] >> 32);
       }
       bool nz = false, lt = false;
       for (int j = 0; j < 8; j++) nz |= c.v[j] != 0;
@@ -173,7 +199,7 @@ struct WaveStrobe {
       }
       if (lt && nz) {
         if (l < 4) {
-          CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * l + j] = (uint8_t)(w[l] >> (8 * j));
+          CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * l + j] = (uint8_t)(sq[l] >> (8 * j));
         }
         wave_lds_sync();
         append_begin(label, label_len, 32, scratch);

@@ -10,17 +10,42 @@ using namespace cpx;
 __global__ __launch_bounds__(64) void k(const uint8_t* msg, size_t len, uint64_t* t, uint64_t* out, int reps) {
   __shared__ uint8_t scratch_all[2][64];
   WaveStrobe s;
-  s.l = threadIdx.x & 31;
+  s.set_lane(threadIdx.x & 31);
   s.init("bench", 5, scratch_all[threadIdx.x >> 5]);
   uint64_t t0 = wall_clock64();
   for (int i = 0; i < reps; i++) s.keccak();
   uint64_t t1 = wall_clock64();
   s.absorb(msg, len);
   uint64_t t2 = wall_clock64();
-  if (s.l < 25) out[blockIdx.x * 64 + threadIdx.x] = s.a;
+  if (s.w >= 0) out[blockIdx.x * 64 + (threadIdx.x & 32) + s.w] = s.a;
   if (threadIdx.x == 0 && blockIdx.x == 0) { t[0] = t1 - t0; t[1] = t2 - t1; }
 }
+__global__ __launch_bounds__(64) void k_check(const uint64_t* in27, uint64_t* out27) {
+  WaveStrobe s;
+  s.load(in27, threadIdx.x & 31);
+  s.keccak();
+  if (threadIdx.x < 32) s.store(out27);
+  else s.store(out27 + 27);   // the second half of the wave runs the same permutation
+}
 int main() {
+  {   // one permutation of a non-trivial state against the host's keccak_f1600 (strobe.hpp)
+    uint64_t h[27], ref[25], got[54];
+    for (int i = 0; i < 25; i++) h[i] = ref[i] = 0x9e3779b97f4a7c15ULL * (i + 1) ^ (0x0123456789abcdefULL << (i % 7));
+    h[25] = 17; h[26] = 3;
+    keccak_f1600(ref);
+    uint64_t *din, *dout;
+    HIPCHECK(hipMalloc(&din, sizeof h)); HIPCHECK(hipMalloc(&dout, sizeof got));
+    HIPCHECK(hipMemcpy(din, h, sizeof h, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, 0, din, dout);
+    HIPCHECK(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int half = 0; half < 2; half++) {
+      for (int i = 0; i < 25; i++) bad += got[27 * half + i] != ref[i];
+      bad += got[27 * half + 25] != 17 || got[27 * half + 26] != 3;
+    }
+    printf("lane-parallel keccak-f[1600] against the host permutation: %d mismatches\n", bad);
+    if (bad) return 1;
+  }
   const size_t len = 166 * 256;
   uint8_t* dmsg; uint64_t *dt, *dout;
   HIPCHECK(hipMalloc(&dmsg, len)); HIPCHECK(hipMemset(dmsg, 0x5a, len)); HIPCHECK(hipMalloc(&dt, 64)); HIPCHECK(hipMalloc(&dout, 64 * 8 * 4096));

@@ -128,7 +128,9 @@ template <bool INL> CPX_PT_FN Xyzz28 xyzz28_add_mixed_t(const Xyzz28& p, const A
   const F28 ppp = mul(pp_, pp2), qq = mul(p.x, pp2);
   Xyzz28 r;
   r.x = f28_sub(f28_sub(sqr(rr), ppp), f28_shl<1>(qq));
-  r.y = f28_sub(mul(rr, f28_sub(qq, r.x)), mul(p.y, ppp));
+  // the two products of Y3 share one Montgomery reduction where the products are inlined (the bucket loops)
+  if (INL) r.y = f28_mulsub_body(rr, f28_sub(qq, r.x), p.y, ppp);
+  else r.y = f28_sub(mul(rr, f28_sub(qq, r.x)), mul(p.y, ppp));
   r.zz = zz3;
   r.zzz = mul(p.zzz, ppp);
   return r;

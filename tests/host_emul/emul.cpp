@@ -195,6 +195,24 @@ void emul_f28_mul(const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
     memcpy(out + 48 * i, z.v, 48);
   }
 }
+// a b - c d with one reduction (f28_mulsub_body), operands blown up to `scale` x their canonical value by lazy additions first
+void emul_f28_mulsub(const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, uint8_t* out, size_t n, int scale) {
+  for (size_t i = 0; i < n; i++) {
+    Fp x[4];
+    memcpy(x[0].v, a + 48 * i, 48);
+    memcpy(x[1].v, b + 48 * i, 48);
+    memcpy(x[2].v, c + 48 * i, 48);
+    memcpy(x[3].v, d + 48 * i, 48);
+    F28 v[4];
+    for (int j = 0; j < 4; j++) {
+      const F28 base = f28_from_std(x[j]);
+      v[j] = base;
+      for (int k = 1; k < scale; k++) v[j] = f28_add(v[j], base);   // scale * value, unreduced
+    }
+    Fp z = f28_to_std(f28_mulsub_body(v[0], v[1], v[2], v[3]));
+    memcpy(out + 48 * i, z.v, 48);
+  }
+}
 // lazy chain: ((x + y) * 8 - y * 2) * (x - y) - x * x, and the inverse of x
 void emul_f28_lazy(const uint8_t* a, const uint8_t* b, uint8_t* out /*2*48*/) {
   Fp x, y;
@@ -245,7 +263,9 @@ void emul_f28_xyzz_sum(const uint8_t* bases, size_t n, const uint8_t* signs, uin
   Xyzz28 acc = Xyzz28::identity();
   double mx = 0, my = 0;
   for (size_t i = 0; i < n; i++) {
-    acc = xyzz28_add_mixed(acc, aff28_cneg(aff28_from_std(P[i]), signs[i] & 1));
+    // alternate between the called-product form and the inlined form of the bucket loops (Y3 with one shared reduction)
+    acc = (i & 1) ? xyzz28_add_mixed_t<true>(acc, aff28_cneg(aff28_from_std(P[i]), signs[i] & 1))
+                  : xyzz28_add_mixed(acc, aff28_cneg(aff28_from_std(P[i]), signs[i] & 1));
     mx = std::max(mx, f28_mag(acc.x));
     my = std::max(my, f28_mag(acc.y));
   }

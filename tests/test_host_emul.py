@@ -38,6 +38,7 @@ def emul():
     L.emul_smul.argtypes = [vp, vp, vp, vp]
     L.emul_challenges.argtypes = [vp, sz, vp]
     L.emul_f28_mul.argtypes = [vp, vp, vp, sz]
+    L.emul_f28_mulsub.argtypes = [vp, vp, vp, vp, vp, sz, ctypes.c_int]
     L.emul_f28_msm.argtypes = [vp, vp, sz, vp, vp]
     L.emul_f28_xyzz_sum.argtypes = [vp, sz, vp, vp, vp]
     L.emul_quad_program.argtypes = [ctypes.c_int, vp, vp]
@@ -166,6 +167,22 @@ def test_f28_field_matches_oracle(emul, orc):
         emul.emul_f28_lazy(_b(_to_mont(x)), _b(_to_mont(y)), r)
         assert _from_mont(bytes(r)[:48]) == (((x + y) * 8 - 2 * y) * (x - y) - x * x) % P
         assert _from_mont(bytes(r)[48:]) == pow(-x, -1, P)
+
+
+def test_f28_fused_difference_of_products(emul):
+    """f28_mulsub_body: a b - c d with ONE Montgomery reduction (the Y3 of the bucket loops' mixed addition), on canonical
+    operands and on operands 12 x and 35 x their canonical value (the lazy magnitudes the point formulas may reach: the
+    product bound is |a||b| + |c||d| < 2^11.3 p^2)."""
+    vals = [int.from_bytes(os.urandom(48), "little") % P for _ in range(120)] + [0, 1, P - 1, P - 2, 1 << 380, (P - 1) // 2]
+    rot = lambda k: vals[k:] + vals[:k]
+    enc = lambda vs: b"".join(_to_mont(v) for v in vs)
+    a, b, c, d = vals, rot(1), rot(7), rot(13)
+    for scale in (1, 12, 35):
+        o = _o(48 * len(vals))
+        emul.emul_f28_mulsub(_b(enc(a)), _b(enc(b)), _b(enc(c)), _b(enc(d)), o, len(vals), scale)
+        got = [_from_mont(bytes(o)[48 * i:48 * i + 48]) for i in range(len(vals))]
+        want = [(scale * scale * (w * x - y * z)) % P for w, x, y, z in zip(a, b, c, d)]
+        assert got == want, scale
 
 
 def test_f28_point_formulas(emul, orc):

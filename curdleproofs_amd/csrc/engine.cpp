@@ -282,7 +282,7 @@ void Engine::run_smul(const std::vector<SmulTask>& tasks, int cnt, const S* scal
 void Engine::ensure_raw_sets(size_t nsets) {
   d_raw_.ensure(std::max<size_t>(nsets, 1) * raw_set_words());
   d_rawslot_.ensure(std::max<size_t>(nsets, 1));
-  d_rawmid_.ensure(std::max<size_t>(nsets, 1) * 16);
+  d_rawmid_.ensure(std::max<size_t>(nsets, 1) * reduce_mid_per_set());
 }
 void Engine::reduce_sets(size_t nplain, size_t nweighted, TJac* part) {
   tick("k_reduce_sets", 0, (double)(nplain + nweighted), true);   // up to four launches (groups of 8 lanes, then the groups of a set; plain / bucket sets)
@@ -1006,7 +1006,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     side_.digits.ensure(9 * nt * ell);
     side_.raw.ensure(nsets * raw_set_words());
     side_.rawslot.ensure(nsets);
-    side_.mid.ensure(nsets * 16);
+    side_.mid.ensure(nsets * reduce_mid_per_set());
     side_.part.ensure(nsets);
     launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, sside, (int)slices);
     launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nsets, side_.mid.p, side_.part.p, sside, (int)B);
@@ -1024,7 +1024,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     tab_.stage.ensure(b_blob);
     tab_.raw.ensure(nt * parts * raw_set_words());
     tab_.rawslot.ensure(nt * parts);
-    tab_.mid.ensure(nt * parts * 16);
+    tab_.mid.ensure(nt * parts * reduce_mid_per_set());
     tab_.part.ensure(nt * parts);
     tab_.comp.ensure(nt * 48);
     tab_.hcomp.ensure(nt * 48);

@@ -153,7 +153,7 @@ void Engine::prepare_device_prover() {
   side_.digits.ensure(9 * 2 * B * ell);
   side_.raw.ensure(2 * B * 32 * raw_set_words());
   side_.rawslot.ensure(2 * B * 32);
-  side_.mid.ensure(2 * B * 32 * 16);
+  side_.mid.ensure(2 * B * 32 * reduce_mid_per_set());
   side_.part.ensure(2 * B * 32);
   const std::vector<const void*> sig = {d_pp_.p,     d_ptab_.p,    d_psrc_.p,  d_bytes_.p,  d_mcomp_.p,   d_tstate_.p,   d_veca_.p,      d_rvec_.p,
                                         dp.rvec2.p,  d_rgam_.p,    d_rbeta_.p, d_rout_.p,   dp.perm.p,    dp.k.p,        dp.mbl.p,       dp.rnd.p,

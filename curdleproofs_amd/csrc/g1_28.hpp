@@ -136,6 +136,41 @@ template <bool INL> CPX_PT_FN Xyzz28 xyzz28_add_mixed_t(const Xyzz28& p, const A
   return r;
 }
 CPX_PT_FN Xyzz28 xyzz28_add_mixed(const Xyzz28& p, const Aff28& q) { return xyzz28_add_mixed_t<false>(p, q); }
+// 2 P for a full XYZZ point (dbl-2008-s-1): 6M + 3S
+CPX_PT_FN Xyzz28 xyzz28_dbl(const Xyzz28& p) {
+  if (p.is_identity()) return p;
+  const F28 u = f28_shl<1>(p.y), v = f28_sqr(u), w = f28_mul(u, v), s = f28_mul(p.x, v);
+  const F28 xx = f28_sqr(p.x), m = f28_add(f28_shl<1>(xx), xx);
+  Xyzz28 r;
+  r.x = f28_sub(f28_sqr(m), f28_shl<1>(s));
+  r.y = f28_sub(f28_mul(m, f28_sub(s, r.x)), f28_mul(w, p.y));
+  r.zz = f28_mul(v, p.zz);
+  r.zzz = f28_mul(w, p.zzz);
+  return r;
+}
+// P + Q for two full XYZZ points (add-2008-s), complete: 12M + 2S, the two products of Y3 under one reduction — 5110
+// multiply-adds against the 5817 of the Jacobian addition (11M + 5S).  What the reduction kernels add lane accumulators with.
+// Magnitudes (units of p): products lie in (-0.81, 1.81); P, R within +-3.62; X3 in (-6.24, 4.24); Q - X3 within +-8.1;
+// Y3 within +-2.62 (+ the slack of the shared reduction): every operand product stays far below 2^11.3 p^2.
+CPX_PT_FN Xyzz28 xyzz28_add(const Xyzz28& p, const Xyzz28& q) {
+  if (p.is_identity()) return q;
+  if (q.is_identity()) return p;
+  const F28 u1 = f28_mul(p.x, q.zz), u2 = f28_mul(q.x, p.zz), s1 = f28_mul(p.y, q.zzz), s2 = f28_mul(q.y, p.zzz);
+  const F28 pp_ = f28_sub(u2, u1), rr = f28_sub(s2, s1);
+  const F28 pp2 = f28_sqr(pp_);
+  const F28 zz3 = f28_mul(f28_mul(p.zz, q.zz), pp2);
+  if (f28_product_is_zero(zz3)) {   // same x: P = +-Q
+    if (f28_product_is_zero(f28_mul(rr, f28_one()))) return xyzz28_dbl(p);
+    return Xyzz28::identity();
+  }
+  const F28 ppp = f28_mul(pp_, pp2), qq = f28_mul(u1, pp2);
+  Xyzz28 r;
+  r.x = f28_sub(f28_sub(f28_sqr(rr), ppp), f28_shl<1>(qq));
+  r.y = f28_mulsub_body(rr, f28_sub(qq, r.x), s1, ppp);
+  r.zz = zz3;
+  r.zzz = f28_mul(f28_mul(p.zzz, q.zzz), ppp);
+  return r;
+}
 // same point in Jacobian coordinates with Z = ZZ: (X ZZ, Y ZZZ, ZZ)
 CPX_HD Jac28 xyzz28_to_jac(const Xyzz28& p) {
   if (p.is_identity()) return Jac28::identity();
@@ -276,6 +311,8 @@ typedef Xyzz28 TAcc;
 CPX_HD TAcc t_acc_add_mixed(const TAcc& p, const TAff& q) { return xyzz28_add_mixed(p, q); }
 CPX_HD TAcc t_acc_add_mixed_inl(const TAcc& p, const TAff& q) { return xyzz28_add_mixed_t<true>(p, q); }
 CPX_HD TJac t_acc_to_jac(const TAcc& p) { return xyzz28_to_jac(p); }
+CPX_HD TAcc t_acc_add(const TAcc& p, const TAcc& q) { return xyzz28_add(p, q); }
+CPX_HD TAcc t_acc_dbl(const TAcc& p) { return xyzz28_dbl(p); }
 CPX_HD TF t_inv(const TF& a) { return f28_inv_euclid(a); }
 CPX_HD TF t_neg(const TF& a) { return f28_neg(a); }
 CPX_HD TF t_beta() { return f28_const(F28Cfg::BETA); }   // (x, y) -> (beta x, y) is multiplication by -z^2 on G1 (glv.hpp)

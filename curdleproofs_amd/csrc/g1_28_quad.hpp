@@ -35,19 +35,6 @@ __device__ __forceinline__ F28 quad_sel(int sub, const F28& a0, const F28& a1, c
   return r;
 }
 
-// 2 P for a full XYZZ point (dbl-2008-s-1), one lane
-__device__ __forceinline__ Xyzz28 xyzz28_dbl(const Xyzz28& p) {
-  if (p.is_identity()) return p;
-  const F28 u = f28_shl<1>(p.y), v = f28_sqr(u), w = f28_mul(u, v), s = f28_mul(p.x, v);
-  const F28 xx = f28_sqr(p.x), m = f28_add(f28_shl<1>(xx), xx);
-  Xyzz28 r;
-  r.x = f28_sub(f28_sqr(m), f28_shl<1>(s));
-  r.y = f28_sub(f28_mul(m, f28_sub(s, r.x)), f28_mul(w, p.y));
-  r.zz = f28_mul(v, p.zz);
-  r.zzz = f28_mul(w, p.zzz);
-  return r;
-}
-
 // P + Q.  Operands and result replicated over the quad.  Returns QUAD_OK with r = P + Q in the generic case; otherwise r is
 // meaningless and the code tells the caller — who still has the operands in memory, here they would pin 112 registers to the end —
 // what the sum is (identical in the four lanes).

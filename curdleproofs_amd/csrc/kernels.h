@@ -68,6 +68,7 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_ra
 // each; tblw: 2 sets per wave, fix: 1) plus the partial-sum slot every set belongs to; launch_reduce_sets turns them
 // into d_part[slot] (bucket sets of k_msm_tblw: weighted sums; k_msm_fix: plain sums).
 size_t raw_set_words();
+size_t reduce_mid_per_set();   // TJac entries of launch_reduce_sets' d_mid scratch per set (it holds 16 extended-Jacobian group sums)
 // Bucket MSM over caller-supplied bases with the endomorphism split and radix-256 windows (no shifted copies): 16 waves
 // per task, 32 raw sets per task; after launch_reduce_sets(weighted) the partial sums part[task*32 + 2w + h] carry the
 // weight 2^(8w): launch_msm_tail(part, ..., group 16, shift 8, dup 2) finishes.  d_conv: 2 x (sum of n) TAff scratch
@@ -80,7 +81,7 @@ void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv
 // The first nplain sets are plain sums, the following nweighted ones bucket sets (lower / upper half alternating).
 // nproofs: how many proofs the batch in flight holds (0: unknown) — picks between the wave-per-set and the work-efficient kernels
 void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s,
-                        int nproofs = 0);   // d_mid: 16 TJac per set
+                        int nproofs = 0);   // d_mid: reduce_mid_per_set() TJac per set
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
 // endo = false: copy c = 2^(256 c / C) P.   endo = true (the tables k_msm_tblw reads): copies 0..C/2-1 = 2^(8c) P and

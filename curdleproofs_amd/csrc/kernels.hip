@@ -272,45 +272,54 @@ __device__ __forceinline__ TAcc raw_load(const uint32_t* __restrict__ set, int l
 
 // Two launches so that no lane idles while a few finish: level 1 = thread per (set, group of 8 lanes), level 2 = thread
 // per set over the 8 group results (mid: [set][8] x {S, W}).
-template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_sets(const uint32_t* __restrict__ raw, int nsets, TJac* __restrict__ mid) {
+// (Both levels stay in the accumulators' extended-Jacobian coordinates: a full XYZZ addition is 12M + 2S with Y3 under one
+// reduction, 5110 multiply-adds, against 5817 for the Jacobian 11M + 5S plus two products per input for the conversion; only the
+// partial sum a set ends in is converted.)
+constexpr int MID_PER_SET = 16;   // TAcc entries of `mid` per set: 8 groups x {S, W}
+template <bool WEIGHTED> __global__ __launch_bounds__(64, 2) void k_reduce_sets(const uint32_t* __restrict__ raw, int nsets, TAcc* __restrict__ mid) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= nsets * 8) return;
   const int set = t >> 3, g = t & 7;
   const uint32_t* rs = raw + (size_t)set * RAW_SET_WORDS;
-  TJac run = t_acc_to_jac(raw_load(rs, g * 8 + 7));
-  TJac w = run;
+  // the weighted running sum W waits in its output slot between its additions (two XYZZ sums live in registers beside the
+  // operands of an addition are 300 VGPRs: one wave per SIMD instead of two)
+  TAcc run = raw_load(rs, g * 8 + 7);
+  TAcc* const wslot = mid + (size_t)t * 2 + 1;
+  if (WEIGHTED) *wslot = run;
   for (int j = 6; j >= 0; j--) {
-    run = t_add(run, t_acc_to_jac(raw_load(rs, g * 8 + j)));
-    if (WEIGHTED) w = t_add(w, run);
+    run = t_acc_add(run, raw_load(rs, g * 8 + j));
+    if (WEIGHTED) *wslot = t_acc_add(*wslot, run);
   }
   mid[(size_t)t * (WEIGHTED ? 2 : 1)] = run;
-  if (WEIGHTED) mid[(size_t)t * 2 + 1] = w;
 }
-template <bool WEIGHTED> __global__ __launch_bounds__(64) void k_reduce_groups(const TJac* __restrict__ mid, const uint32_t* __restrict__ slot, int nsets,
+template <bool WEIGHTED> __global__ __launch_bounds__(64, 2) void k_reduce_groups(TAcc* __restrict__ mid, const uint32_t* __restrict__ slot, int nsets,
                                                                               TJac* __restrict__ part) {
   const int set = blockIdx.x * 64 + threadIdx.x;
   if (set >= nsets) return;
-  const TJac* m = mid + (size_t)set * 8 * (WEIGHTED ? 2 : 1);
+  const TAcc* m = mid + (size_t)set * 8 * (WEIGHTED ? 2 : 1);
   if (!WEIGHTED) {
-    TJac run = m[7];
-    for (int k = 6; k >= 0; k--) run = t_add(run, m[k]);
-    part[slot[set]] = run;
+    TAcc run = m[7];
+    for (int k = 6; k >= 0; k--) run = t_acc_add(run, m[k]);
+    part[slot[set]] = t_acc_to_jac(run);
     return;
   }
-  TJac run = m[2 * 7];                          // S_7
-  TJac v = run;
+  // (v waits in the slot of S_7, which is dead once it has been read, while run is being updated: see k_reduce_sets)
+  TAcc* const vslot = mid + (size_t)set * 16 + 2 * 7;
+  TAcc run = m[2 * 7];                          // S_7
   for (int k = 6; k >= 1; k--) {
-    run = t_add(run, m[2 * k]);
-    v = t_add(v, run);
+    run = t_acc_add(run, m[2 * k]);
+    *vslot = t_acc_add(*vslot, run);
   }
-  run = t_add(run, m[0]);                       // run = sum_g S_g, v = sum_g g S_g
-  for (int d = 0; d < 3; d++) v = t_dbl(v);     // 8 v
-  for (int k = 0; k < 8; k++) v = t_add(v, m[2 * k + 1]);
-  if (set & 1) {                                // upper half of the magnitudes
-    for (int d = 0; d < 6; d++) run = t_dbl(run);
-    v = t_add(v, run);
+  run = t_acc_add(run, m[0]);                   // run = sum_g S_g, *vslot = sum_g g S_g
+  TAcc v = *vslot;
+  if (set & 1) {                                // upper half of the magnitudes: + 64 sum_g S_g, parked while v is finished
+    for (int d = 0; d < 6; d++) run = t_acc_dbl(run);
+    *vslot = run;
   }
-  part[slot[set]] = v;
+  for (int d = 0; d < 3; d++) v = t_acc_dbl(v); // 8 v
+  for (int k = 0; k < 8; k++) v = t_acc_add(v, m[2 * k + 1]);
+  if (set & 1) v = t_acc_add(v, *vslot);
+  part[slot[set]] = t_acc_to_jac(v);
 }
 
 // Small grids (a few proofs in flight: latency matters, not throughput): one WAVE per set and every point addition spread over the
@@ -1533,6 +1542,7 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_ra
   }
 }
 size_t raw_set_words() { return RAW_SET_WORDS; }
+size_t reduce_mid_per_set() { return (MID_PER_SET * sizeof(TAcc) + sizeof(TJac) - 1) / sizeof(TJac); }
 void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s, int nproofs) {
   const int nsets = nplain + nweighted;
   if (nsets <= 0) return;
@@ -1551,13 +1561,14 @@ void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int n
     return;
   }
   const dim3 block(64);
+  TAcc* const mid = reinterpret_cast<TAcc*>(d_mid);   // reduce_mid_per_set() TJac per set hold MID_PER_SET TAcc
   if (nplain > 0) {
-    CPX_LAUNCH(k_reduce_sets<false>, dim3((nplain * 8 + 63) / 64), block, 0, s, d_raw, nplain, d_mid);
-    CPX_LAUNCH(k_reduce_groups<false>, dim3((nplain + 63) / 64), block, 0, s, d_mid, d_raw_slot, nplain, d_part);
+    CPX_LAUNCH(k_reduce_sets<false>, dim3((nplain * 8 + 63) / 64), block, 0, s, d_raw, nplain, mid);
+    CPX_LAUNCH(k_reduce_groups<false>, dim3((nplain + 63) / 64), block, 0, s, mid, d_raw_slot, nplain, d_part);
   }
   if (nweighted > 0) {   // (an even number of plain sets keeps the lower / upper parity of the bucket sets)
     const uint32_t* raw_w = d_raw + (size_t)nplain * RAW_SET_WORDS;
-    TJac* mid_w = d_mid + (size_t)nplain * 16;
+    TAcc* mid_w = mid + (size_t)nplain * MID_PER_SET;
     CPX_LAUNCH(k_reduce_sets<true>, dim3((nweighted * 8 + 63) / 64), block, 0, s, raw_w, nweighted, mid_w);
     CPX_LAUNCH(k_reduce_groups<true>, dim3((nweighted + 63) / 64), block, 0, s, mid_w, d_raw_slot + nplain, nweighted, d_part);
   }

@@ -276,6 +276,39 @@ void emul_f28_xyzz_sum(const uint8_t* bases, size_t n, const uint8_t* signs, uin
   mags[0] = mx;
   mags[1] = my;
 }
+// the reduction kernels' full XYZZ addition (xyzz28_add, complete): the signed sum of n points, each first brought to a
+// representation with ZZ != 1, added up front to back and as a tree; then the exceptional cases on point 0:
+// out = [sum (chain), sum (tree), A + A, A + (-A), O + A, A + O, 2A (xyzz28_dbl), (A + A) + A]
+void emul_f28_xyzz_full(const uint8_t* bases, size_t n, const uint8_t* signs, uint8_t* out /* 8 * 96 */, double* mags) {
+  const Aff* P = reinterpret_cast<const Aff*>(bases);
+  std::vector<Xyzz28> v(n);
+  double mx = 0, my = 0;
+  for (size_t i = 0; i < n; i++) {
+    const Aff28 a = aff28_cneg(aff28_from_std(P[i]), signs[i] & 1);
+    Xyzz28 t = xyzz28_add_mixed(xyzz28_add_mixed(Xyzz28::identity(), a), a);   // 2A
+    v[i] = xyzz28_add_mixed(t, aff28_cneg(a, true));                              // A with ZZ != 1
+  }
+  Xyzz28 chain = Xyzz28::identity();
+  for (size_t i = 0; i < n; i++) {
+    chain = xyzz28_add(chain, v[i]);
+    mx = std::max(mx, f28_mag(chain.x));
+    my = std::max(my, f28_mag(chain.y));
+  }
+  std::vector<Xyzz28> tr = v;
+  for (size_t m = n; m > 1; m = (m + 1) / 2)
+    for (size_t i = 0; i < m / 2; i++) tr[i] = xyzz28_add(tr[i], tr[m - 1 - i]);
+  const Xyzz28 A = v[0], nA = Xyzz28{A.x, f28_neg(A.y), A.zz, A.zzz};
+  const Xyzz28 res[8] = {chain, n ? tr[0] : Xyzz28::identity(), xyzz28_add(A, A), xyzz28_add(A, nA), xyzz28_add(Xyzz28::identity(), A),
+                         xyzz28_add(A, Xyzz28::identity()), xyzz28_dbl(A), xyzz28_add(xyzz28_add(A, A), A)};
+  for (int k = 0; k < 8; k++) {
+    const Jac28 j = xyzz28_to_jac(res[k]);
+    Aff r = Aff::identity();
+    if (!j.is_identity()) r = aff28_to_std(jac28_to_affine_with_zinv(j, f28_inv(j.z)));
+    memcpy(out + 96 * k, &r, 96);
+  }
+  mags[0] = mx;
+  mags[1] = my;
+}
 // exceptional cases of the complete formulas: P+P, P+(-P), P+O, O+P in mixed and Jacobian form -> 8 affine outputs
 void emul_f28_edges(const uint8_t* base, uint8_t* out /*8*96*/) {
   Aff p;

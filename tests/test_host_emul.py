@@ -41,6 +41,7 @@ def emul():
     L.emul_f28_mulsub.argtypes = [vp, vp, vp, vp, vp, sz, ctypes.c_int]
     L.emul_f28_msm.argtypes = [vp, vp, sz, vp, vp]
     L.emul_f28_xyzz_sum.argtypes = [vp, sz, vp, vp, vp]
+    L.emul_f28_xyzz_full.argtypes = [vp, sz, vp, vp, vp]
     L.emul_quad_program.argtypes = [ctypes.c_int, vp, vp]
     L.emul_quad_program.restype = None
     L.emul_thread_helpers.argtypes = [ctypes.c_int, sz, sz, sz, ctypes.c_long]
@@ -211,6 +212,34 @@ def test_f28_point_formulas(emul, orc):
     emul.emul_f28_edges(_b(g), e)
     got = [bytes(e)[i * AFF:(i + 1) * AFF] for i in range(8)]
     assert got == [mult(2), bytes(AFF), mult(4), mult(1), mult(8), bytes(AFF), mult(4), mult(3)]
+
+
+def test_f28_full_xyzz_addition(emul, orc):
+    """xyzz28_add / xyzz28_dbl (g1_28.hpp): the complete extended-Jacobian addition the reduction kernels add lane accumulators
+    with (Y3 under one shared reduction), against the oracle: signed sums of points with ZZ != 1 as a chain and as a tree,
+    repeated and opposite points among them, and the exceptional cases; magnitudes as documented."""
+    n = 24
+    rng = orc.rng(91)
+    bases = bytearray(rng.g1_affine(n))
+    bases[5 * AFF:6 * AFF] = bases[4 * AFF:5 * AFF]       # a repeated point
+    bases[9 * AFF:10 * AFF] = bases[0:AFF]
+    signs = bytes([(i * 7 + 3) % 3 == 0 for i in range(n)])
+    signs = signs[:9] + bytes([1 - signs[0]]) + signs[10:]   # point 9 = -(point 0)
+    out = _o(8 * AFF)
+    mags = (ctypes.c_double * 2)()
+    emul.emul_f28_xyzz_full(_b(bytes(bases)), n, _b(signs), out, mags)
+    got = [bytes(out)[i * AFF:(i + 1) * AFF] for i in range(8)]
+    rmod = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    sc = b"".join(orc.fr_from_canonical_bytes(((rmod - 1) if s else 1).to_bytes(32, "little")) for s in signs)
+    total = orc.g1_to_affine(orc.g1_msm(bytes(bases), sc, naive=True))
+    a0 = bytes(bases[:AFF])
+    k0 = (rmod - 1) if signs[0] else 1
+
+    def mult(k):
+        return orc.g1_to_affine(orc.g1_msm(a0, orc.fr_from_canonical_bytes((k * k0 % rmod).to_bytes(32, "little")), naive=True))
+    assert got[0] == total and got[1] == total
+    assert got[2:] == [mult(2), bytes(AFF), mult(1), mult(1), mult(2), mult(3)]
+    assert mags[0] <= 6.3 and mags[1] <= 2.7, list(mags)
 
 
 def test_f28_sqrt_and_endomorphism_subgroup_test(emul, orc):

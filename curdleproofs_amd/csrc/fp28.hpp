@@ -73,6 +73,28 @@ CPX_HD F28 f28_sub(const F28& a, const F28& b) {
   f28_normalize(r);
   return r;
 }
+// Differences that only FEED PRODUCTS skip the carry pass: the limb-wise difference of two normalised values has signed limbs
+// below 2^28 in magnitude, the column sums of the signed multiply-adds keep the bounds of normalised operands (28 terms of
+// < 2^56 per product), and the product's own output is normalised again.  Not for values that are stored, tested for zero or
+// run through further additions (their limbs would grow): those take f28_sub.  (39 instructions per carry pass, ~5 % of a mixed
+// addition's instructions in total.)
+CPX_HD F28 f28_sub_lazy(const F28& a, const F28& b) {
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i];
+  return r;
+}
+CPX_HD F28 f28_cneg_lazy(const F28& a, bool neg) {   // +-a for a normalised a: limbs in (-2^28, 2^28)
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = neg ? -a.v[i] : a.v[i];
+  return r;
+}
+// a - b - 2 c with one carry pass (limbs stay below 2^30 before it)
+CPX_HD F28 f28_sub_sub2(const F28& a, const F28& b, const F28& c) {
+  F28 r;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = a.v[i] - b.v[i] - 2 * c.v[i];
+  f28_normalize(r);
+  return r;
+}
 CPX_HD F28 f28_neg(const F28& a) {
   F28 r;
   CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = -a.v[i];

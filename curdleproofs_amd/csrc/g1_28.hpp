@@ -26,6 +26,8 @@ struct Jac28 {
 };
 
 CPX_HD Aff28 aff28_cneg(const Aff28& p, bool neg) { return Aff28{p.x, f28_cneg(p.y, neg)}; }
+// for a point that goes straight into a mixed addition (y only feeds products there)
+CPX_HD Aff28 aff28_cneg_lazy(const Aff28& p, bool neg) { return Aff28{p.x, f28_cneg_lazy(p.y, neg)}; }
 
 // 7 multiplications; D = 4 X Y^2 as a product instead of 2((X+B)^2 - A - C)
 CPX_PT_FN Jac28 jac28_dbl(const Jac28& p) {
@@ -116,9 +118,13 @@ template <bool INL> CPX_PT_FN Xyzz28 xyzz28_add_mixed_t(const Xyzz28& p, const A
   auto mul = [](const F28& a, const F28& b) { return INL ? f28_mul_body(a, b) : f28_mul(a, b); };
   auto sqr = [](const F28& a) { return INL ? f28_sqr_body(a) : f28_sqr(a); };
   if (q.is_identity()) return p;
-  if (p.is_identity()) return Xyzz28{q.x, q.y, f28_one(), f28_one()};
+  if (p.is_identity()) {   // (q.y may come from aff28_cneg_lazy: a stored coordinate gets its carry pass)
+    F28 qy = q.y;
+    f28_normalize(qy);
+    return Xyzz28{q.x, qy, f28_one(), f28_one()};
+  }
   const F28 u2 = mul(q.x, p.zz), s2 = mul(q.y, p.zzz);
-  const F28 pp_ = f28_sub(u2, p.x), rr = f28_sub(s2, p.y);
+  const F28 pp_ = f28_sub_lazy(u2, p.x), rr = f28_sub_lazy(s2, p.y);   // P, R and Q - X3 only feed products: no carry pass
   const F28 pp2 = sqr(pp_);
   const F28 zz3 = mul(p.zz, pp2);
   if (f28_product_is_zero(zz3)) {   // same x: P = +-Q
@@ -127,10 +133,10 @@ template <bool INL> CPX_PT_FN Xyzz28 xyzz28_add_mixed_t(const Xyzz28& p, const A
   }
   const F28 ppp = mul(pp_, pp2), qq = mul(p.x, pp2);
   Xyzz28 r;
-  r.x = f28_sub(f28_sub(sqr(rr), ppp), f28_shl<1>(qq));
+  r.x = f28_sub_sub2(sqr(rr), ppp, qq);
   // the two products of Y3 share one Montgomery reduction where the products are inlined (the bucket loops)
-  if (INL) r.y = f28_mulsub_body(rr, f28_sub(qq, r.x), p.y, ppp);
-  else r.y = f28_sub(mul(rr, f28_sub(qq, r.x)), mul(p.y, ppp));
+  if (INL) r.y = f28_mulsub_body(rr, f28_sub_lazy(qq, r.x), p.y, ppp);
+  else r.y = f28_sub(mul(rr, f28_sub_lazy(qq, r.x)), mul(p.y, ppp));
   r.zz = zz3;
   r.zzz = mul(p.zzz, ppp);
   return r;
@@ -156,7 +162,7 @@ CPX_PT_FN Xyzz28 xyzz28_add(const Xyzz28& p, const Xyzz28& q) {
   if (p.is_identity()) return q;
   if (q.is_identity()) return p;
   const F28 u1 = f28_mul(p.x, q.zz), u2 = f28_mul(q.x, p.zz), s1 = f28_mul(p.y, q.zzz), s2 = f28_mul(q.y, p.zzz);
-  const F28 pp_ = f28_sub(u2, u1), rr = f28_sub(s2, s1);
+  const F28 pp_ = f28_sub_lazy(u2, u1), rr = f28_sub_lazy(s2, s1);
   const F28 pp2 = f28_sqr(pp_);
   const F28 zz3 = f28_mul(f28_mul(p.zz, q.zz), pp2);
   if (f28_product_is_zero(zz3)) {   // same x: P = +-Q
@@ -165,8 +171,8 @@ CPX_PT_FN Xyzz28 xyzz28_add(const Xyzz28& p, const Xyzz28& q) {
   }
   const F28 ppp = f28_mul(pp_, pp2), qq = f28_mul(u1, pp2);
   Xyzz28 r;
-  r.x = f28_sub(f28_sub(f28_sqr(rr), ppp), f28_shl<1>(qq));
-  r.y = f28_mulsub_body(rr, f28_sub(qq, r.x), s1, ppp);
+  r.x = f28_sub_sub2(f28_sqr(rr), ppp, qq);
+  r.y = f28_mulsub_body(rr, f28_sub_lazy(qq, r.x), s1, ppp);
   r.zz = zz3;
   r.zzz = f28_mul(f28_mul(p.zzz, q.zzz), ppp);
   return r;
@@ -301,6 +307,7 @@ CPX_HD TJac t_dbl(const TJac& p) { return jac28_dbl(p); }
 CPX_HD TJac t_add_mixed(const TJac& p, const TAff& q) { return jac28_add_mixed(p, q); }
 CPX_HD TJac t_add(const TJac& p, const TJac& q) { return jac28_add(p, q); }
 CPX_HD TAff t_cneg(const TAff& p, bool neg) { return aff28_cneg(p, neg); }
+CPX_HD TAff t_cneg_lazy(const TAff& p, bool neg) { return aff28_cneg_lazy(p, neg); }
 CPX_HD TAff t_to_affine(const TJac& p, const TF& zinv) { return jac28_to_affine_with_zinv(p, zinv); }
 CPX_HD TAff t_from_std(const Aff& a) { return aff28_from_std(a); }
 CPX_HD Aff t_to_std(const TAff& a) { return aff28_to_std(a); }

@@ -563,7 +563,7 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
       }
       const uint32_t e = list[k < c0 ? s0_ + k : s1_ + (k - c0)];
       const TAff q = *tbl_point(task, next + (e >> 6), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & 31u));
-      xacc = t_acc_add_mixed_inl(xacc, t_cneg(q, (e & 1u) != 0));   // products inlined: no argument moves, 231 VGPRs, no scratch
+      xacc = t_acc_add_mixed_inl(xacc, t_cneg_lazy(q, (e & 1u) != 0));   // products inlined: no argument moves, 231 VGPRs, no scratch
     }
     if (c1 == 0) {
       raw_store(rb0, b0 & 63, xacc);
@@ -640,7 +640,7 @@ template <int CB, int FIX_WPW> __device__ __forceinline__ void msm_fix_body(cons
       const int d = dn;
       const TAff p = pn;
       pn = fetch(i + LPW, dn);
-      if (d) xacc = t_acc_add_mixed_inl(xacc, t_cneg(p, d < 0));
+      if (d) xacc = t_acc_add_mixed_inl(xacc, t_cneg_lazy(p, d < 0));
     }
   }
   // all entries carry weight 1: the wave's 64 accumulators form one plain raw set (k_reduce_sets adds them up)

@@ -264,7 +264,7 @@ void emul_f28_xyzz_sum(const uint8_t* bases, size_t n, const uint8_t* signs, uin
   double mx = 0, my = 0;
   for (size_t i = 0; i < n; i++) {
     // alternate between the called-product form and the inlined form of the bucket loops (Y3 with one shared reduction)
-    acc = (i & 1) ? xyzz28_add_mixed_t<true>(acc, aff28_cneg(aff28_from_std(P[i]), signs[i] & 1))
+    acc = (i & 1) ? xyzz28_add_mixed_t<true>(acc, aff28_cneg_lazy(aff28_from_std(P[i]), signs[i] & 1))   // as the bucket loops call it
                   : xyzz28_add_mixed(acc, aff28_cneg(aff28_from_std(P[i]), signs[i] & 1));
     mx = std::max(mx, f28_mag(acc.x));
     my = std::max(my, f28_mag(acc.y));

@@ -306,6 +306,12 @@ def test_f28_xyzz_accumulation(emul, orc):
     want = orc.g1_to_affine(orc.g1_msm(b"".join(seq), scal, naive=True))
     assert bytes(o) == want
     assert mags[0] <= 6.3 and mags[1] <= 2.7, list(mags)
+    # a long bucket (the lazy, carry-pass-free differences of the inlined form alternate with the called form on every point)
+    many = [rng.g1_affine(1) for _ in range(300)]
+    sg = bytes([(i * 5 + i // 7) & 1 for i in range(300)])
+    emul.emul_f28_xyzz_sum(_b(b"".join(many)), 300, _b(sg), o, mags)
+    assert bytes(o) == orc.g1_to_affine(orc.g1_msm(b"".join(many), b"".join(rm1 if x else orc.fr_from_u64(1) for x in sg), naive=True))
+    assert mags[0] <= 6.3 and mags[1] <= 2.7, list(mags)
     # a bucket that starts with the same point twice, then its negation twice: back to the identity
     seq2 = [pts[6], pts[6], pts[6], pts[6]]
     emul.emul_f28_xyzz_sum(_b(b"".join(seq2)), 4, _b(bytes([0, 0, 1, 1])), o, mags)

@@ -460,8 +460,13 @@ def main():
                              "roofline.valu gives the modular-multiplication roofline (DESIGN.md section 5)")
         # The honest bound of this integer path: modular multiplications on the VALU.  Peak = dependent
         # Montgomery-product chains on the table kernels' 28-bit-limb field at full occupancy, measured now on this GPU
-        # (k_bench_f28mul); achieved = the dominant kernel's point additions x 11 products (7M + 4S mixed addition).
-        mulmods_per_point = {"k_msm_tblw": 32 * 255.0 / 256 * 11, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * 11.0, "k_smul": 0.0}[dom.split("<")[0]]
+        # (k_bench_f28mul: 392 multiply-adds per product); achieved = the dominant kernel's point additions x the product equivalents
+        # of one mixed addition.  The extended-Jacobian mixed addition of the bucket loops is 8M + 2S with the two products of Y3
+        # under one reduction: 3542 multiply-adds = 9.04 products of 392 (rounds 1-2 of this build counted 11, the Jacobian 7M + 4S,
+        # for an addition that cost 9.5: their fractions read 16 % too high).
+        PROD_PER_ADD = 3542.0 / 392.0
+        mulmods_per_point = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * PROD_PER_ADD,
+                             "k_smul": 0.0}[dom.split("<")[0]]
         os.environ["CPX_BENCH_FIELD"] = "28"
         peak_mm = ctxs[0].bench_fpmul(2048, 1000, 2)
         ach_mm = st["units"] * mulmods_per_point / (st["ms"] * 1e-3) if st["ms"] else 0.0
@@ -469,8 +474,8 @@ def main():
                                 mulmods_per_point=mulmods_per_point,
                                 note="kernel time is measured with all engine contexts sharing the GPU, so it includes the other contexts' kernels; "
                                      "'isolated' repeats the measurement with one context running alone after the timed region")
-        if iso:   # every MSM kernel, one context alone: point-scalar pairs, additions x 11 products against the measured peak
-            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * 11, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * 11.0}
+        if iso:   # every MSM kernel, one context alone: point-scalar pairs, additions x their product equivalents against the measured peak
+            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * PROD_PER_ADD}
             roofline["valu"]["isolated_by_kernel"] = {
                 k: dict(pairs_per_proof=v["units"] / (B // K), ms_per_proof_batch=v["ms"],
                         frac=(v["units"] * per_pair[k.split("<")[0]] / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None)

@@ -44,14 +44,14 @@ __device__ __forceinline__ int xyzz28_add_quad_core(const Xyzz28& p, const Xyzz2
   const int idcode = p.is_identity() ? QUAD_TAKE_Q : q.is_identity() ? QUAD_TAKE_P : QUAD_OK;
   F28 t = f28_mul(quad_sel(sub, p.x, q.x, p.y, q.y), quad_sel(sub, q.zz, p.zz, q.zzz, p.zzz));
   const F28 u1 = quad_bcast<0>(t), s1 = quad_bcast<2>(t);
-  const F28 pp_ = f28_sub(quad_bcast<1>(t), u1), rr = f28_sub(quad_bcast<3>(t), s1);
+  const F28 pp_ = f28_sub_lazy(quad_bcast<1>(t), u1), rr = f28_sub_lazy(quad_bcast<3>(t), s1);   // feed products only: no carry pass
   t = f28_mul(quad_sel(sub, pp_, rr, p.zz, p.zzz), quad_sel(sub, pp_, rr, q.zz, q.zzz));
   const F28 pp2 = quad_bcast<0>(t), rr2 = quad_bcast<1>(t), zz12 = quad_bcast<2>(t), zzz12 = quad_bcast<3>(t);
   t = f28_mul(quad_sel(sub, pp_, u1, zz12, rr), quad_sel(sub, pp2, pp2, pp2, f28_one()));
   const F28 ppp = quad_bcast<0>(t), qq = quad_bcast<1>(t), r1 = quad_bcast<3>(t);
   r.zz = quad_bcast<2>(t);
-  r.x = f28_sub(f28_sub(rr2, ppp), f28_shl<1>(qq));
-  t = f28_mul(quad_sel(sub, rr, s1, zzz12, zzz12), quad_sel(sub, f28_sub(qq, r.x), ppp, ppp, ppp));
+  r.x = f28_sub_sub2(rr2, ppp, qq);
+  t = f28_mul(quad_sel(sub, rr, s1, zzz12, zzz12), quad_sel(sub, f28_sub_lazy(qq, r.x), ppp, ppp, ppp));
   r.y = f28_sub(quad_bcast<0>(t), quad_bcast<1>(t));
   r.zzz = quad_bcast<2>(t);
   if (idcode != QUAD_OK) return idcode;
@@ -79,8 +79,8 @@ __device__ __forceinline__ Xyzz28 xyzz28_dbl_quad(const Xyzz28& p) {
   t = f28_mul(quad_sel(sub, u, p.x, m, m), quad_sel(sub, v, v, m, m));
   const F28 w = quad_bcast<0>(t), s = quad_bcast<1>(t), mm = quad_bcast<2>(t);
   Xyzz28 r;
-  r.x = f28_sub(mm, f28_shl<1>(s));
-  t = f28_mul(quad_sel(sub, m, w, v, w), quad_sel(sub, f28_sub(s, r.x), p.y, p.zz, p.zzz));
+  r.x = f28_sub_sub2(mm, F28::zero(), s);
+  t = f28_mul(quad_sel(sub, m, w, v, w), quad_sel(sub, f28_sub_lazy(s, r.x), p.y, p.zz, p.zzz));
   r.y = f28_sub(quad_bcast<0>(t), quad_bcast<1>(t));
   r.zz = quad_bcast<2>(t);
   r.zzz = quad_bcast<3>(t);
@@ -99,7 +99,7 @@ __device__ __forceinline__ Jac28 jac28_dbl_quad(const Jac28& p) {
   const F28 C = quad_bcast<0>(t), D = f28_shl<2>(quad_bcast<1>(t)), F = quad_bcast<2>(t);
   Jac28 r;
   r.x = f28_sub(F, f28_shl<1>(D));
-  r.y = f28_sub(f28_mul(E, f28_sub(D, r.x)), f28_shl<3>(C));   // the same product in the four lanes: nothing to exchange
+  r.y = f28_sub(f28_mul(E, f28_sub_lazy(D, r.x)), f28_shl<3>(C));   // the same product in the four lanes: nothing to exchange
   r.z = f28_shl<1>(yz);                                        // exact zero stays exact zero
   return r;
 }

@@ -27,7 +27,7 @@ python bench.py --fused-verify --synth-cache /tmp/synth.pkl 2>/dev/null | tail -
 python scripts/single_proof_latency.py > $O/${RND}_single_proof_latency.txt 2>&1
 # the lone-proof timeline (which kernel a lone proof waits for, launch by launch) and the micro-benchmarks behind the latency kernels
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/scripts/single_proof_timeline.py run > /dev/null 2>&1; python $R/scripts/single_proof_timeline.py report /tmp/tl > $O/${RND}_single_proof_timeline.txt 2>&1 )
-for m in quad_micro lat_micro place_micro; do
+for m in quad_micro lat_micro place_micro keccak_micro; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I curdleproofs_amd/csrc scripts/micro/$m.hip -o /tmp/$m > /dev/null 2>&1 && timeout 120 /tmp/$m > $O/${RND}_$m.txt 2>&1
 done
 python scripts/shape_sweep.py 128 2>&1 | tail -1 > $O/${RND}_shape_128.txt

@@ -478,7 +478,10 @@ def main():
             per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * PROD_PER_ADD}
             roofline["valu"]["isolated_by_kernel"] = {
                 k: dict(pairs_per_proof=v["units"] / (B // K), ms_per_proof_batch=v["ms"],
-                        frac=(v["units"] * per_pair[k.split("<")[0]] / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None)
+                        frac=(v["units"] * per_pair[k.split("<")[0]] / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None,
+                        # the same measurement in the accounting of rounds 1-2a (11 products per addition), for comparison with their numbers
+                        frac_at_11_products_per_addition=(v["units"] * per_pair[k.split("<")[0]] * (11.0 / PROD_PER_ADD if k.split("<")[0] != "k_msm_accw" else 1.0)
+                                                          / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None)
                 for k, v in iso.items() if k.split("<")[0] in per_pair and v["ms"]}
         if iso and dom in iso and iso[dom]["ms"]:
             ist = iso[dom]

@@ -467,7 +467,7 @@ def main():
         PROD_PER_ADD = 3542.0 / 392.0
         mulmods_per_point = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * PROD_PER_ADD,
                              "k_smul": 0.0}[dom.split("<")[0]]
-        os.environ["CPX_BENCH_FIELD"] = "28"
+        ctxs[0].set_option("bench_field", 28)
         peak_mm = ctxs[0].bench_fpmul(2048, 1000, 2)
         ach_mm = st["units"] * mulmods_per_point / (st["ms"] * 1e-3) if st["ms"] else 0.0
         roofline["valu"] = dict(achieved=ach_mm, peak=peak_mm, unit="381-bit modular products/s", frac=ach_mm / peak_mm if peak_mm else None,

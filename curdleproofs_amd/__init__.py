@@ -50,7 +50,7 @@ class ProofError(CpxError):
 _lib = None
 
 EXPORTS = [
-    "cpx_host_alloc", "cpx_host_free", "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size",
+    "cpx_host_alloc", "cpx_host_free", "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_option", "cpx_ctx_get_option", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size", "cpx_batch_size",
     "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress",
     "cpx_accum_new", "cpx_accum_free", "cpx_accum_check", "cpx_accum_verify",
     "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify", "cpx_batch_verify_fused", "cpx_g1_sum_jac",
@@ -80,10 +80,14 @@ def load_library():
     L.cpx_last_error.argtypes = [vp]
     L.cpx_last_error.restype = ctypes.c_char_p
     L.cpx_device_count.argtypes = []
+    L.cpx_ctx_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_longlong]
+    L.cpx_ctx_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]
     L.cpx_ctx_set_crs.argtypes = [vp, sz, vp, sz]
     L.cpx_crs_sums.argtypes = [vp, vp, vp]
     L.cpx_proof_size.argtypes = [vp]
     L.cpx_proof_size.restype = sz
+    L.cpx_batch_size.argtypes = [vp]
+    L.cpx_batch_size.restype = sz
     L.cpx_g1_msm.argtypes = [vp, vp, vp, sz, vp]
     L.cpx_g1_msm_jac.argtypes = [vp, vp, vp, sz, vp]
     L.cpx_g1_fold.argtypes = [vp, vp, vp, vp, sz]
@@ -158,7 +162,7 @@ def _pinned_array(ctype, n):
 class Context:
     """One HIP device + stream + device-resident CRS (cpx_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, options=None):
         self._L = load_library()
         h = ctypes.c_void_p()
         rc = self._L.cpx_ctx_create(device, ctypes.byref(h))
@@ -166,7 +170,23 @@ class Context:
             raise CpxError(rc, "cpx_ctx_create(device=%d): no usable MI355X/HIP device" % device)
         self._h = h
         self.ell = None
-        self.batch = 0
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
+
+    @property
+    def batch(self):
+        """instances currently loaded into the engine (cpx_batch_size): the library is the one source of truth — a Whisk shuffle call
+        replaces the loaded batch by its single instance, also when it fails half-way"""
+        return self._L.cpx_batch_size(self._h) if getattr(self, "_h", None) else 0
+
+    def set_option(self, key, value):
+        """Per-context tunable (include/cpx.h cpx_ctx_set_option; keys: curdleproofs_amd/csrc/kernels.h `Options`)."""
+        self._check(self._L.cpx_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_longlong(0)
+        self._check(self._L.cpx_ctx_get_option(self._h, key.encode(), ctypes.byref(v)))
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -263,7 +283,6 @@ class Context:
             if len(v) != batch * self.ell * AFF:
                 raise ValueError("every instance vector must hold batch * ell affine points (%d bytes), got %d" % (batch * self.ell * AFF, len(v)))
         self._check(self._L.cpx_batch_load(self._h, batch, _in(vec_R), _in(vec_S), _in(vec_T), _in(vec_U), _in(M)))
-        self.batch = batch
 
     @staticmethod
     def marshal(data):
@@ -313,7 +332,7 @@ class Context:
         blob = proofs if isinstance(proofs, ctypes.Array) else b"".join(proofs)
         if _len(blob) != B * psz or _len(rand) != B * 8 * FR:
             raise ValueError("verify_batch: batch * proof_size proof bytes and 8 random factors per proof")
-        verdict = (ctypes.c_int * B)()
+        verdict = (ctypes.c_int * B)(*([CPX_ERR_INTERNAL] * B))   # an entry the library does not write is never read as "accepted"
         self._check(self._L.cpx_batch_verify(self._h, _in(blob), _in(rand), verdict))
         return list(verdict)
 

@@ -6,9 +6,13 @@ H_sum are recomputed by `Context.set_crs` and compared with the file's, so a CRS
 refused (the reference trusts the file).  No CPU group arithmetic here.
 """
 import json
+import re
 
 from . import AFF, N_BLINDERS, CPX_ERR_DESERIALIZE, CpxError
 from . import whisk
+
+
+_HEX_POINT = re.compile(r"^0x[0-9a-fA-F]{96}$")
 
 
 def crs_to_hex(ctx):
@@ -29,13 +33,9 @@ def crs_from_hex(ctx, obj):
     def unhex(s):
         if not isinstance(s, str) or not s.startswith("0x"):
             raise whisk.SerializationError("missing 0x prefix")
-        try:
-            b = bytes.fromhex(s[2:])
-        except ValueError:
-            raise whisk.SerializationError("not hex")
-        if len(b) != 48:
-            raise whisk.SerializationError("a compressed G1 point has 48 bytes")
-        return b
+        if not _HEX_POINT.match(s):   # hex::decode rejects whitespace and odd lengths; bytes.fromhex alone would skip blanks
+            raise whisk.SerializationError("a compressed G1 point is 0x + 96 hex digits")
+        return bytes.fromhex(s[2:])
     vec_G, vec_H = [unhex(s) for s in obj["vec_G"]], [unhex(s) for s in obj["vec_H"]]
     if len(vec_H) != N_BLINDERS:
         raise ValueError("vec_H must hold N_BLINDERS = 4 points")
@@ -47,9 +47,13 @@ def crs_from_hex(ctx, obj):
         if e.code == CPX_ERR_DESERIALIZE:
             raise whisk.SerializationError(str(e))
         raise
-    ctx.set_crs(ell, pts[:(ell + 7) * AFF])
-    if ctx.crs_sums() != (pts[(ell + 7) * AFF:(ell + 8) * AFF], pts[(ell + 8) * AFF:(ell + 9) * AFF]):
+    # the sums are checked BEFORE the CRS is loaded (tier-0 point sums on the device): a refused file leaves ctx as it was
+    one = whisk.pr.fp_to_wire(1)
+    jac = lambda lo, hi: b"".join(pts[i * AFF:(i + 1) * AFF] + (bytes(48) if pts[i * AFF:(i + 1) * AFF] == bytes(AFF) else one) for i in range(lo, hi))
+    sums = ctx.normalize(ctx.sum_jac(jac(0, ell))[0] + ctx.sum_jac(jac(ell, ell + N_BLINDERS))[0])
+    if sums != pts[(ell + 7) * AFF:(ell + 9) * AFF]:
         raise ValueError("G_sum / H_sum of the file are not the sums of vec_G / vec_H")
+    ctx.set_crs(ell, pts[:(ell + 7) * AFF])
     return ell
 
 

@@ -95,6 +95,21 @@ void cpx_ctx_destroy(cpx_ctx* ctx) {
   delete ctx->eng;
   delete ctx;
 }
+int cpx_ctx_set_option(cpx_ctx* ctx, const char* key, long long value) {
+  if (!ctx || !ctx->eng || !key) return CPX_ERR_ARG;
+  if (!ctx->eng->set_option(key, (long)value)) {
+    ctx->err = std::string("cpx_ctx_set_option: unknown key or value out of range: ") + key;
+    return CPX_ERR_ARG;
+  }
+  return CPX_OK;
+}
+int cpx_ctx_get_option(const cpx_ctx* ctx, const char* key, long long* value) {
+  if (!ctx || !ctx->eng || !key || !value) return CPX_ERR_ARG;
+  long v = 0;
+  if (!ctx->eng->get_option(key, &v)) return CPX_ERR_ARG;
+  *value = v;
+  return CPX_OK;
+}
 const char* cpx_last_error(const cpx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
 int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points, size_t n_points) {
@@ -113,6 +128,7 @@ int cpx_crs_sums(const cpx_ctx* ctx, uint8_t g_sum[96], uint8_t h_sum[96]) {
   ctx->eng->crs_sums(g_sum, h_sum);
   return CPX_OK;
 }
+size_t cpx_batch_size(const cpx_ctx* ctx) { return (ctx && ctx->eng) ? ctx->eng->batch() : 0; }
 size_t cpx_proof_size(const cpx_ctx* ctx) { return (ctx && ctx->eng && ctx->eng->ell()) ? ctx->eng->proof_size() : 0; }
 
 int cpx_g1_msm(cpx_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[144]) {

@@ -22,7 +22,12 @@ static inline S S_from_wire(const uint8_t* b) {
   return s;
 }
 
+std::atomic<int>& Engine::live_engines() {
+  static std::atomic<int> n{0};
+  return n;
+}
 Engine::Engine(int device) : device_(device) {
+  live_engines()++;
   try {
     CPX_HIP(hipSetDevice(device_));
     CPX_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -32,14 +37,20 @@ Engine::Engine(int device) : device_(device) {
     if (side_.ev) (void)hipEventDestroy(side_.ev);
     if (side_.stream) (void)hipStreamDestroy(side_.stream);
     if (stream_) (void)hipStreamDestroy(stream_);
+    live_engines()--;
     throw;
   }
-  if (const char* e = getenv("CPX_FIX_BITS")) {
-    int c = atoi(e);
-    if (c == 8 || c == 16) fix_bits_cfg_ = fix_bits_ = c;   // radix of the fixed-base CRS table (8: 0.1 GB, 16: 15 GB at ell = 252)
-  }
+  fix_bits_cfg_ = fix_bits_ = (int)opt_.fix_bits;   // radix of the fixed-base CRS table (8: 0.1 GB, 16: 17.5 GB at ell = 252)
+}
+bool Engine::set_option(const char* key, long value) {
+  if (!cpx::set_option(opt_, key, value)) return false;
+  fix_bits_cfg_ = (int)opt_.fix_bits;   // used by the next set_crs
+  dprove_.signature.clear();            // plans are laid out for a kernel selection: rebuild them
+  dverify_.signature.clear();
+  return true;
 }
 Engine::~Engine() {
+  live_engines()--;
   for (auto p : idx_allocs_) (void)hipFree(p);
   if (side_.ev) (void)hipEventDestroy(side_.ev);
   if (side_.ev2) (void)hipEventDestroy(side_.ev2);
@@ -99,16 +110,12 @@ void Engine::flush_timers() {
 }
 
 Engine::TeamScope::TeamScope(Engine* e, size_t batch) {
-  static const bool off = [] {
-    const char* v = getenv("CPX_SPIN_TEAM");
-    return v && atoi(v) == 0;
-  }();
-  if (off || batch < 2) return;
-  static const size_t team_max = [] {   // CPX_SPIN_TEAM_THREADS: size of the team when the context's host-thread count is not set
-    const char* v = getenv("CPX_SPIN_TEAM_THREADS");
-    return v && atoi(v) > 0 ? (size_t)atoi(v) : (size_t)8;
-  }();
-  const size_t want = std::min<size_t>(batch, e->host_threads_ > 0 ? (size_t)e->host_threads_ : team_max);
+  if (!e->opt_.spin_team || batch < 2) return;
+  const size_t team_max = (size_t)e->opt_.spin_team_threads;   // size of the team when the context's host-thread count is not set
+  // busy-waiting helpers only pay while they have cores of their own: the team is bounded by the cores this process may use
+  // (affinity mask and cgroup CPU quota) divided by the engine contexts alive in the process
+  const size_t fair = std::max<size_t>(1, effective_host_cores() / std::max<size_t>(1, (size_t)live_engines().load()));
+  const size_t want = std::min({batch, e->host_threads_ > 0 ? (size_t)e->host_threads_ : team_max, fair});
   if (want < 2) return;
   if (!e->team_ || e->team_->size() < want) e->team_.reset(new SpinTeam(want - 1));
   t = e->team_.get();
@@ -122,10 +129,7 @@ template <class F> void Engine::parallel_for(size_t n, F&& f) {
     team_->run(n, fn);
     return;
   }
-  static const size_t inline_below = [] {
-    const char* e = getenv("CPX_INLINE_BELOW");
-    return e ? (size_t)atol(e) : (size_t)16;
-  }();
+  const size_t inline_below = (size_t)opt_.inline_below;
   if (n < inline_below) {   // a handful of items: waking the pool (tens of sleeping threads) costs more than the work
     for (size_t i = 0; i < n; i++) f(i);
     return;
@@ -158,12 +162,7 @@ void Engine::wait_stream() {
 // ~0.25 us on a host core, ~1000 permutations per proof), and the host has idle cores.  In the host-driven mode the
 // transcript prefix of every loaded proof is hashed on the host as well.
 bool Engine::device_prefix(size_t B) const {
-  static const size_t min_batch = [] {
-    const char* e = getenv("CPX_DEVICE_MIN_BATCH");
-    if (!e) e = getenv("CPX_DEVICE_TRANSCRIPT_MIN_BATCH");   // former name
-    return e ? (size_t)atol(e) : (size_t)96;
-  }();
-  return B >= min_batch;
+  return B >= (size_t)opt_.device_min_batch;
 }
 // hipStreamSynchronize spins on a host core; an event created with hipEventBlockingSync puts the thread to sleep instead.  With
 // one thread per engine context and per rank, and hosts that give a container a small CPU quota, that matters.
@@ -242,10 +241,10 @@ void Engine::run_msm_phase(const std::vector<MsmReq>& reqs, std::vector<uint8_t>
   launch_msm_accum(d_tasks_.p, (int)nt, (int)max_n, d_conv_.p, d_wsum_.p, stream_);
   tock();
   tick("k_msm_tail", 0, (double)nt * 8);
-  launch_msm_tail(d_wsum_.p, d_part_.p, nullptr, (int)nt * 8, 8, 4, stream_);
+  launch_msm_tail(opt_, d_wsum_.p, d_part_.p, nullptr, (int)nt * 8, 8, 4, stream_);
   tock();
   tick("k_msm_tail", 0, (double)nt);
-  launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)nt, 8, 32, stream_);
+  launch_msm_tail(opt_, d_part_.p, nullptr, d_res_.p, (int)nt, 8, 32, stream_);
   tock();
   tick("k_finalize", 0, (double)nt);
   launch_finalize(d_res_.p, (int)nt, d_pp_.p, d_dst_.p, d_comp_.p, stream_);
@@ -286,7 +285,7 @@ void Engine::ensure_raw_sets(size_t nsets) {
 }
 void Engine::reduce_sets(size_t nplain, size_t nweighted, TJac* part) {
   tick("k_reduce_sets", 0, (double)(nplain + nweighted), true);   // up to four launches (groups of 8 lanes, then the groups of a set; plain / bucket sets)
-  launch_reduce_sets(d_raw_.p, d_rawslot_.p, (int)nplain, (int)nweighted, d_rawmid_.p, part ? part : d_tpart_.p, stream_, (int)B_);
+  launch_reduce_sets(opt_, d_raw_.p, d_rawslot_.p, (int)nplain, (int)nweighted, d_rawmid_.p, part ? part : d_tpart_.p, stream_, (int)B_);
   tock();
 }
 
@@ -306,13 +305,13 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     ntt_total += needs_tbl(r) ? 1 : 0;
     nft_total += (is_crs(r.seg0) ? 1 : 0) + (is_crs(r.seg1) ? 1 : 0);
   }
-  const int fix_wpw = fix ? msm_fix_windows_per_wave((int)nft_total, fix_bits_) : 16;
+  const int fix_wpw = fix ? msm_fix_windows_per_wave(opt_, (int)nft_total, fix_bits_) : 16;
   const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / fix_wpw) : 0;
-  const int tbl_wpw = msm_tblw_windows_per_wave((int)ntt_total);   // windows per wave of the shifted-table kernel
+  const int tbl_wpw = msm_tblw_windows_per_wave(opt_, (int)ntt_total);   // windows per wave of the shifted-table kernel
   uint32_t tbl_max_n = 0;
   for (const TblReq& r : reqs)
     if (needs_tbl(r)) tbl_max_n = std::max(tbl_max_n, (is_crs(r.seg0) ? 0u : r.seg0.n) + (is_crs(r.seg1) ? 0u : r.seg1.n));
-  const int tbl_slices = msm_tblw_slices((int)ntt_total, tbl_wpw, (int)tbl_max_n);   // a lone proof: several waves share a task's points
+  const int tbl_slices = msm_tblw_slices(opt_, (int)ntt_total, tbl_wpw, (int)tbl_max_n);   // a lone proof: several waves share a task's points
   const uint32_t tbl_parts = (uint32_t)(msm_tblw_parts(tbl_wpw) * tbl_slices);   // partial sums (2 per wave) per task
   // layout: per request its scalars (seg0 then seg1); shifted-table tasks and fixed-base tasks; partial ranges
   std::vector<size_t> soff(nt);
@@ -424,7 +423,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
   }
   reduce_sets(fix_sets, tbl_sets);
   tick("k_finalize_ranges", 0, (double)nt);
-  launch_finalize_ranges(d_tpart_.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, d_comp_.p, stream_, any_add ? d_u32 + 3 * nt : nullptr);
+  launch_finalize_ranges(opt_, d_tpart_.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, d_comp_.p, stream_, any_add ? d_u32 + 3 * nt : nullptr);
   tock();
   if (comp_out) {
     h_comp_.ensure(nt * 48);
@@ -438,6 +437,10 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
 void Engine::set_crs(size_t ell, const uint8_t* points) {
   const size_t n = ell + N_BLINDERS;
   if (ell == 0 || (n & (n - 1))) throw std::invalid_argument("ell + 4 must be a power of two");
+  // the cached device plans were laid out for the previous CRS (they embed its compressed H and table addresses, which a new
+  // allocation of the same size may reuse): a new CRS — also a refused one — starts from no plans
+  dprove_.signature.clear();
+  dverify_.signature.clear();
   try {
     set_crs_impl(ell, points);
   } catch (...) {   // e.g. out of device memory while building the tables: the context is left without a CRS, not half-initialised
@@ -533,7 +536,7 @@ void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
       CPX_HIP(hipMemcpy(d_row.p, row.data(), NC * sizeof(Aff), hipMemcpyHostToDevice));
       DevBuf<TblTmp> tmp;   // build scratch, released afterwards
       tmp.ensure(NC * (size_t)(copies_ - 1));
-      launch_table_build(d_row.p, 0, tab->ctab.p, 1, 0, (int)NC, (int)NC, copies_, true, tmp.p, stream_);
+      launch_table_build(opt_, d_row.p, 0, tab->ctab.p, 1, 0, (int)NC, (int)NC, copies_, true, tmp.p, stream_);
       CPX_HIP(hipStreamSynchronize(stream_));
       if (want_fix) {
         // multiples m * 2^(c w) * P, m <= 2^(c-1): shifted copies first, then the multiples
@@ -541,7 +544,7 @@ void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
         const size_t M = size_t(1) << (want_fix - 1);
         DevBuf<TAff> d_shift;
         d_shift.ensure((size_t)W * NC);
-        launch_table_build(d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, false, tmp.p, stream_);
+        launch_table_build(opt_, d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, false, tmp.p, stream_);
         tab->fixtab.ensure((size_t)W * M * NC);
         const int chunk = (int)std::min<size_t>(256, M);
         const size_t threads = ((size_t)W * NC + 63) / 64 * 64;
@@ -585,7 +588,7 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
     DevBuf<TblTask> tt;
     DevBuf<TJac> part;
     DevBuf<uint32_t> dig;
-    const int slices = msm_tblw_slices(1, 2, (int)n);
+    const int slices = msm_tblw_slices(opt_, 1, 2, (int)n);
     tt.ensure(1);
     part.ensure(32 * (size_t)slices);
     dig.ensure(9 * n);
@@ -594,7 +597,7 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
     launch_msm_endo(dt.p, 1, (int)n, conv.p, dig.p, tt.p, d_raw_.p, d_rawslot_.p, stream_, slices);
     tock();
     reduce_sets(0, 32 * (size_t)slices, part.p);
-    launch_msm_tail(part.p, nullptr, res.p, 1, 16, 8, stream_, nullptr, 0, 2 * slices);
+    launch_msm_tail(opt_, part.p, nullptr, res.p, 1, 16, 8, stream_, nullptr, 0, 2 * slices);
     CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
     CPX_HIP(hipStreamSynchronize(stream_));   // before the scratch buffers above go out of scope
     flush_timers();
@@ -603,8 +606,8 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   tick("k_msm_accw", 128.0 * n, (double)n);
   launch_msm_accum(dt.p, 1, (int)n, conv.p, w.p, stream_);
   tock();
-  launch_msm_tail(w.p, pt.p, nullptr, 8, 8, 4, stream_);
-  launch_msm_tail(pt.p, nullptr, res.p, 1, 8, 32, stream_);
+  launch_msm_tail(opt_, w.p, pt.p, nullptr, 8, 8, 4, stream_);
+  launch_msm_tail(opt_, pt.p, nullptr, res.p, 1, 8, 32, stream_);
   CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
   flush_timers();
@@ -697,7 +700,7 @@ int Engine::decompress(const uint8_t* comp, size_t n, uint8_t* out_aff, int chec
   dst.ensure(n);
   da.ensure(n);
   CPX_HIP(hipMemcpyAsync(dc.p, comp, n * 48, hipMemcpyHostToDevice, stream_));
-  launch_decompress(dc.p, (int)n, da.p, nullptr, dst.p, check_subgroup, stream_);
+  launch_decompress(opt_, dc.p, (int)n, da.p, nullptr, dst.p, check_subgroup, stream_);
   std::vector<uint8_t> st(n);
   CPX_HIP(hipMemcpyAsync(out_aff, da.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipMemcpyAsync(st.data(), dst.p, n, hipMemcpyDeviceToHost, stream_));
@@ -723,8 +726,7 @@ double Engine::bench_fpmul(int blocks, int iters, int reps) {
   hipEvent_t a, b;
   CPX_HIP(hipEventCreate(&a));
   CPX_HIP(hipEventCreate(&b));
-  const char* fld = getenv("CPX_BENCH_FIELD");
-  auto launch = (fld && atoi(fld) == 28) ? launch_bench_f28mul : launch_bench_fpmul;
+  auto launch = opt_.bench_field == 28 ? launch_bench_f28mul : launch_bench_fpmul;
   launch(d.p, blocks, iters, stream_);   // warm-up
   CPX_HIP(hipEventRecord(a, stream_));
   for (int r = 0; r < reps; r++) launch(d.p, blocks, iters, stream_);
@@ -818,14 +820,13 @@ void Engine::batch_prove(const uint32_t* permutation, const uint8_t* k_in, const
 // build and of the MSM tails) run BESIDE the phases of the main stream, and the dispatcher likes to put the main stream's single-wave
 // groups onto the very SIMDs those long waves occupy — two 200-VGPR waves then time-share one SIMD and a 120 us reduction took
 // 370 us.  The queues of these streams are therefore confined to the upper half of the CU mask (hipExtStreamCreateWithCUMask); the
-// main stream, unconfined, fills the GPU from the low end.  CPX_CU_MASK=0 creates plain streams (A/B runs).
+// main stream, unconfined, fills the GPU from the low end.  Option cu_mask = 0 creates plain streams (A/B runs).
 hipStream_t Engine::create_masked_stream(bool upper) {
   hipStream_t st = nullptr;
-  const char* e = getenv("CPX_CU_MASK");
   hipDeviceProp_t prop;
   CPX_HIP(hipGetDeviceProperties(&prop, device_));
   const int ncu = prop.multiProcessorCount;
-  if ((e && atoi(e) == 0) || ncu < 64) {
+  if (!opt_.cu_mask || ncu < 64) {
     CPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return st;
   }
@@ -869,7 +870,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipEventCreateWithFlags(&side_.lat_ev, hipEventDisableTiming));
   }
   const hipStream_t sside = side_.lat_stream;
-  TeamScope team(this, B);   // 2 ... 31 proofs: the host loops between the phases on spinning helper threads
+  TeamScope team(this, B);   // 2 ... device_min_batch - 1 (95) proofs: the host loops between the phases on spinning helper threads
   StreamSwap lat_main(stream_, B <= 8 ? side_.lat_main : nullptr, side_.lat_ev);   // a few proofs: the phases on the lower half of the CUs
   const SlotMap sm(L);
   const size_t nrand = 3 * n + 9;
@@ -921,9 +922,9 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipEventRecord(tab_.ev_start, stream_));
     CPX_HIP(hipStreamWaitEvent(tab_.stream, tab_.ev_start, 0));
     const size_t tmp_m = B * (size_t)(copies_ / 2 - 1);   // scratch entries of the M launch; the T | U launch takes the rest
-    launch_table_build(d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, 1, (int)NP, copies_, true, d_tbltmp_.p, tab_.stream);
+    launch_table_build(opt_, d_psrc_.p, NP, d_ptab_.p, (int)B, (size_t)copies_ * NP, 1, (int)NP, copies_, true, d_tbltmp_.p, tab_.stream);
     CPX_HIP(hipEventRecord(tab_.ev_m, tab_.stream));
-    launch_table_build(d_psrc_.p + 1, NP, d_ptab_.p + 1, (int)B, (size_t)copies_ * NP, (int)(2 * n), (int)NP, copies_, true, d_tbltmp_.p + tmp_m, tab_.stream);
+    launch_table_build(opt_, d_psrc_.p + 1, NP, d_ptab_.p + 1, (int)B, (size_t)copies_ * NP, (int)(2 * n), (int)NP, copies_, true, d_tbltmp_.p + tmp_m, tab_.stream);
     const uint8_t* mcomp = h_mcomp_.p;
     wait_side();
     parallel_for(B, [&](size_t p) {
@@ -1000,7 +1001,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(side_.scal.p, hs, 3 * total * sizeof(Fr), hipMemcpyHostToDevice, sside));
     CPX_HIP(hipMemcpyAsync(side_.tasks.p, ht, nt * sizeof(MsmTask), hipMemcpyHostToDevice, sside));
     CPX_HIP(hipMemcpyAsync(side_.dst.p, hd, 2 * nt * sizeof(uint32_t), hipMemcpyHostToDevice, sside));
-    const size_t slices = (size_t)msm_tblw_slices((int)nt, 2, (int)ell), nsets = nt * 32 * slices;
+    const size_t slices = (size_t)msm_tblw_slices(opt_, (int)nt, 2, (int)ell), nsets = nt * 32 * slices;
     side_.conv.ensure(2 * nt * ell);   // per task: points and images
     side_.ttasks.ensure(nt);
     side_.digits.ensure(9 * nt * ell);
@@ -1009,15 +1010,15 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     side_.mid.ensure(nsets * reduce_mid_per_set());
     side_.part.ensure(nsets);
     launch_msm_endo(side_.tasks.p, (int)nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, sside, (int)slices);
-    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, (int)nsets, side_.mid.p, side_.part.p, sside, (int)B);
-    launch_msm_tail(side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, sside, nullptr, 0, (int)(2 * slices));
+    launch_reduce_sets(opt_, side_.raw.p, side_.rawslot.p, 0, (int)nsets, side_.mid.p, side_.part.p, sside, (int)B);
+    launch_msm_tail(opt_, side_.part.p, nullptr, side_.res.p, (int)nt, 16, 8, sside, nullptr, 0, (int)(2 * slices));
     launch_finalize(side_.res.p, (int)(2 * B), d_pp_.p, side_.dst.p, nullptr, sside);
   }
 
   // -- table stream: B_t = msm(T_b, vec_r), B_u = msm(U_b, vec_r) (same_multiscalar_argument.rs:81-82) right behind the tables of T and U
   {
     const size_t nt = 2 * B;
-    const int wpw = msm_tblw_windows_per_wave((int)nt), tslices = msm_tblw_slices((int)nt, wpw, (int)n);
+    const int wpw = msm_tblw_windows_per_wave(opt_, (int)nt), tslices = msm_tblw_slices(opt_, (int)nt, wpw, (int)n);
     const uint32_t parts = (uint32_t)(msm_tblw_parts(wpw) * tslices);
     const size_t b_scal = B * n * sizeof(Fr), b_tt = nt * sizeof(TblTask), b_blob = b_scal + b_tt + 3 * nt * sizeof(uint32_t);
     tab_.blob.ensure(b_blob);
@@ -1052,8 +1053,8 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipMemcpyAsync(tab_.blob.p, tab_.stage.p, b_blob, hipMemcpyHostToDevice, tab_.stream));
     const uint32_t* d_u32 = reinterpret_cast<const uint32_t*>(tab_.blob.p + b_scal + b_tt);
     launch_msm_tblw(reinterpret_cast<const TblTask*>(tab_.blob.p + b_scal), (int)nt, wpw, tab_.raw.p, tab_.rawslot.p, tab_.stream, tslices);
-    launch_reduce_sets(tab_.raw.p, tab_.rawslot.p, 0, (int)(nt * parts), tab_.mid.p, tab_.part.p, tab_.stream, (int)B);
-    launch_finalize_ranges(tab_.part.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, tab_.comp.p, tab_.stream);
+    launch_reduce_sets(opt_, tab_.raw.p, tab_.rawslot.p, 0, (int)(nt * parts), tab_.mid.p, tab_.part.p, tab_.stream, (int)B);
+    launch_finalize_ranges(opt_, tab_.part.p, d_u32, d_u32 + nt, (int)nt, d_pp_.p, d_u32 + 2 * nt, tab_.comp.p, tab_.stream);
     CPX_HIP(hipMemcpyAsync(tab_.hcomp.p, tab_.comp.p, nt * 48, hipMemcpyDeviceToHost, tab_.stream));
     CPX_HIP(hipEventRecord(tab_.ev_done, tab_.stream));
   }
@@ -1397,7 +1398,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     }
   }
 
-  if (getenv("CPX_TRACE")) {
+  if (opt_.trace) {
     const ProverState& s = st[0];
     trace_scalar("beta_sp", s.beta_sp.f);
     trace_scalar("alpha_sp", s.alpha_sp.f);
@@ -1478,7 +1479,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     return;
   }
 
-  TeamScope team(this, B);   // 2 ... 31 proofs: the host loops on spinning helper threads
+  TeamScope team(this, B);   // 2 ... device_min_batch - 1 (95) proofs: the host loops on spinning helper threads
   struct VState {
     Transcript tr{"curdleproofs"};
     bool bad = false;           // deserialisation failure
@@ -1558,7 +1559,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     CPX_HIP(hipMemcpyAsync(d_vin_.p, pts, npts * 48, hipMemcpyHostToDevice, stream_));
     CPX_HIP(hipMemcpyAsync(d_vdst_.p, dst, npts * 4, hipMemcpyHostToDevice, stream_));
     tick("k_decompress", 0, (double)npts);
-    launch_decompress(d_vin_.p, (int)npts, d_pp_.p, d_vdst_.p, d_status_.p, 1, stream_);
+    launch_decompress(opt_, d_vin_.p, (int)npts, d_pp_.p, d_vdst_.p, d_status_.p, 1, stream_);
     tock();
     CPX_HIP(hipMemcpyAsync(h_status_.p, d_status_.p, npts, hipMemcpyDeviceToHost, stream_));
     wait_side();
@@ -1829,7 +1830,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
         if (!st[p].bad) t += st[p].scal[0][i];
       crs_sum[i] = t;
     });
-    const int fix_wpw = msm_fix_windows_per_wave(1, fix_bits_);
+    const int fix_wpw = msm_fix_windows_per_wave(opt_, 1, fix_bits_);
     const int fix_parts = 256 / fix_bits_ / fix_wpw;
     d_scal_.ensure(N + n);
     d_big_idx_.ensure(N);
@@ -1886,9 +1887,9 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
       tock();
       reduce_sets(0, NT * 32, d_part_.p);
       tick("k_msm_tail", 0, (double)NT, true);
-      launch_msm_tail(d_part_.p, d_wsum_.p, nullptr, (int)NT, 16, 8, stream_, nullptr, 0, 2);                      // windows of a group
-      launch_msm_tail(d_wsum_.p, d_wsum_.p + NT16, nullptr, (int)(NT16 / 16), 16, 0, stream_);                     // 16 groups each
-      launch_msm_tail(d_wsum_.p + NT16, nullptr, d_res_.p, 1, (int)(NT16 / 16), 0, stream_, d_tpart_.p, fix_parts);   // + the fixed-base part
+      launch_msm_tail(opt_, d_part_.p, d_wsum_.p, nullptr, (int)NT, 16, 8, stream_, nullptr, 0, 2);                      // windows of a group
+      launch_msm_tail(opt_, d_wsum_.p, d_wsum_.p + NT16, nullptr, (int)(NT16 / 16), 16, 0, stream_);                     // 16 groups each
+      launch_msm_tail(opt_, d_wsum_.p + NT16, nullptr, d_res_.p, 1, (int)(NT16 / 16), 0, stream_, d_tpart_.p, fix_parts);   // + the fixed-base part
       tock();
       CPX_HIP(hipStreamSynchronize(stream_));   // mt (host) was copied asynchronously
     }
@@ -1910,9 +1911,9 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     for (size_t i = 0; i < NI; i++) all_idx[i] = (uint32_t)i;
     for (size_t j = 0; j < NM; j++) all_idx[NI + j] = (uint32_t)(NI + misc_idx[j]);
     const uint32_t* d_all = idx_list(all_idx);
-    const int fix_wpw = msm_fix_windows_per_wave((int)B, fix_bits_);
+    const int fix_wpw = msm_fix_windows_per_wave(opt_, (int)B, fix_bits_);
     const int fix_parts = 256 / fix_bits_ / fix_wpw;
-    const size_t slices = (size_t)msm_tblw_slices((int)B, 2, (int)NPT);   // a lone proof: several waves per window of the per-proof MSM
+    const size_t slices = (size_t)msm_tblw_slices(opt_, (int)B, 2, (int)NPT);   // a lone proof: several waves per window of the per-proof MSM
     const size_t total = B * (NPT + n);
     d_scal_.ensure(total);
     d_tasks_.ensure(B);
@@ -1953,7 +1954,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     tock();
     reduce_sets(0, B * 32 * slices, d_part_.p);
     tick("k_msm_tail", 0, (double)B);
-    launch_msm_tail(d_part_.p, nullptr, d_res_.p, (int)B, 16, 8, stream_, d_tpart_.p, fix_parts, (int)(2 * slices));
+    launch_msm_tail(opt_, d_part_.p, nullptr, d_res_.p, (int)B, 16, 8, stream_, d_tpart_.p, fix_parts, (int)(2 * slices));
     tock();
     tick("k_finalize", 0, (double)B);
     launch_finalize(d_res_.p, (int)B, nullptr, nullptr, d_comp_.p, stream_);

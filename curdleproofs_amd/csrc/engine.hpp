@@ -144,6 +144,10 @@ class Engine {
     host_threads_ = t;
     pool_.reset();
   }
+  // per-context tunables (kernels.h `Options`; cpx_ctx_set_option).  fix_bits takes effect at the next set_crs; a change invalidates
+  // the cached device plans (their task layouts depend on the kernel selection).
+  bool set_option(const char* key, long value);
+  bool get_option(const char* key, long* value) const { return cpx::get_option(opt_, key, value); }
   hipStream_t stream() const { return stream_; }
   void sync() { CPX_HIP(hipStreamSynchronize(stream_)); }
 
@@ -270,6 +274,7 @@ class Engine {
   void flush_timers();
   template <class F> void parallel_for(size_t n, F&& f);
   std::unique_ptr<SpinTeam> team_;
+  static std::atomic<int>& live_engines();   // engine contexts alive in this process (bounds the spin team)
   struct TeamScope {   // engages the spin team for a small batch's call
     SpinTeam* t = nullptr;
     TeamScope(Engine* e, size_t batch);
@@ -302,6 +307,7 @@ class Engine {
   uint32_t slot_index(size_t p, int s) const { return (uint32_t)(p * pp_stride_ + 4 * ell_ + s); }
 
   int device_;
+  Options opt_ = default_options();
   hipStream_t stream_ = nullptr;
   bool profiling_ = false;
   int host_threads_ = 0;

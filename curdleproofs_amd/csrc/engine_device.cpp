@@ -36,8 +36,8 @@ void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std:
   pl.nt = nt;
   pl.ntt = ntt;
   pl.nft = nft;
-  pl.fix_wpw = msm_fix_windows_per_wave((int)nft, fix_bits_);
-  pl.tbl_wpw = msm_tblw_windows_per_wave((int)ntt);
+  pl.fix_wpw = msm_fix_windows_per_wave(opt_, (int)nft, fix_bits_);
+  pl.tbl_wpw = msm_tblw_windows_per_wave(opt_, (int)ntt);
   const uint32_t fix_parts = (uint32_t)(256 / fix_bits_ / pl.fix_wpw), tbl_parts = (uint32_t)msm_tblw_parts(pl.tbl_wpw);
   std::vector<TblTask> ht(ntt);
   std::vector<FixTask> hf(nft);
@@ -112,7 +112,7 @@ void Engine::exec_plan(const TblPlan& pl, uint8_t* d_comp_registry) {
   reduce_sets(pl.fix_sets, pl.tbl_sets);
   const uint32_t* m = pl.meta.p;
   tick("k_finalize_ranges", 0, (double)pl.nt);
-  launch_finalize_ranges(d_tpart_.p, m, m + pl.nt, (int)pl.nt, d_pp_.p, m + 2 * pl.nt, d_comp_registry, stream_, pl.any_add ? m + 4 * pl.nt : nullptr, m + 3 * pl.nt);
+  launch_finalize_ranges(opt_, d_tpart_.p, m, m + pl.nt, (int)pl.nt, d_pp_.p, m + 2 * pl.nt, d_comp_registry, stream_, pl.any_add ? m + 4 * pl.nt : nullptr, m + 3 * pl.nt);
   tock();
 }
 
@@ -393,12 +393,12 @@ void Engine::enqueue_prove_device() {
   {
     const int nt = 2 * Bi;
     launch_msm_endo(side_.tasks.p, nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
-    launch_reduce_sets(side_.raw.p, side_.rawslot.p, 0, nt * 32, side_.mid.p, side_.part.p, side_.stream, Bi);
-    launch_msm_tail(side_.part.p, nullptr, side_.res.p, nt, 16, 8, side_.stream, nullptr, 0, 2);
+    launch_reduce_sets(opt_, side_.raw.p, side_.rawslot.p, 0, nt * 32, side_.mid.p, side_.part.p, side_.stream, Bi);
+    launch_msm_tail(opt_, side_.part.p, nullptr, side_.res.p, nt, 16, 8, side_.stream, nullptr, 0, 2);
     launch_finalize(side_.res.p, nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
   }
   tick("k_table_build", 0, (double)(B * NP));
-  launch_table_build(d_psrc_.p, NP, d_ptab_.p, Bi, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
+  launch_table_build(opt_, d_psrc_.p, NP, d_ptab_.p, Bi, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
   tock();
   CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_b, 0));   // vec_a and the transcript states
 
@@ -454,7 +454,7 @@ void Engine::batch_prove_device(const uint32_t* permutation, const uint8_t* k_in
   CPX_HIP(hipMemcpyAsync(proofs_out, dp.proofs.p, B * proof_size(), hipMemcpyDeviceToHost, stream_));
   wait_stream_blocking();
   flush_timers();
-  if (getenv("CPX_TRACE")) {   // debugging aid: the challenges and responses of proof 0, same format as the host-driven prover prints
+  if (opt_.trace) {   // debugging aid: the challenges and responses of proof 0, same format as the host-driven prover prints
     std::vector<Fr> sc(SC_COUNT);
     CPX_HIP(hipMemcpy(sc.data(), dp.sc.p, SC_COUNT * sizeof(Fr), hipMemcpyDeviceToHost));
     const char* names[SC_COUNT] = {"beta_sp", "alpha_sp", "-beta_g_inv", "alpha_g", "gprod", "beta_g", "beta_g_inv", "r_p", "z_ip", "alpha_i", "beta_i",
@@ -561,9 +561,9 @@ void Engine::prepare_device_verifier(size_t rand_stride) {
   for (size_t i = 0; i < NI; i++) all_idx[i] = (uint32_t)i;
   for (size_t j = 0; j < NM; j++) all_idx[NI + j] = (uint32_t)(NI + j);   // misc index j == slot j (SL_H .. SL_M, then the proof points)
   const uint32_t* d_all = idx_list(all_idx);
-  dv.fix_wpw = msm_fix_windows_per_wave((int)B, fix_bits_);
+  dv.fix_wpw = msm_fix_windows_per_wave(opt_, (int)B, fix_bits_);
   dv.fix_parts = 256 / fix_bits_ / dv.fix_wpw;
-  dv.fix_wpw1 = msm_fix_windows_per_wave(1, fix_bits_);
+  dv.fix_wpw1 = msm_fix_windows_per_wave(opt_, 1, fix_bits_);
   dv.fix_parts1 = 256 / fix_bits_ / dv.fix_wpw1;
   std::vector<MsmTask> mt(B);
   std::vector<FixTask> ft(B + 1);
@@ -617,7 +617,7 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
   launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side_.stream);
   CPX_HIP(hipEventRecord(dv.ev_b, side_.stream));
   tick("k_decompress", 0, (double)(B * NPP));
-  launch_decompress(dv.proofs.p, (int)(B * NPP), d_pp_.p, dv.dst.p, dv.status.p, 1, stream_, dv.src_off.p);
+  launch_decompress(opt_, dv.proofs.p, (int)(B * NPP), d_pp_.p, dv.dst.p, dv.status.p, 1, stream_, dv.src_off.p);
   tock();
   CPX_HIP(hipStreamWaitEvent(stream_, dv.ev_b, 0));
   // -- V1: transcript up to the grand-product beta; D and A' as bytes; the rest of the transcript and the scalars
@@ -643,9 +643,9 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
     tock();
     reduce_sets(0, NT * 32, d_part_.p);
     tick("k_msm_tail", 0, (double)NT, true);
-    launch_msm_tail(d_part_.p, d_wsum_.p, nullptr, (int)NT, 16, 8, stream_, nullptr, 0, 2);                               // windows of a group
-    launch_msm_tail(d_wsum_.p, d_wsum_.p + NT16, nullptr, (int)(NT16 / 16), 16, 0, stream_);                              // 16 groups each
-    launch_msm_tail(d_wsum_.p + NT16, nullptr, d_res_.p, 1, (int)(NT16 / 16), 0, stream_, d_tpart_.p, dv.fix_parts1);      // + the fixed-base part
+    launch_msm_tail(opt_, d_part_.p, d_wsum_.p, nullptr, (int)NT, 16, 8, stream_, nullptr, 0, 2);                               // windows of a group
+    launch_msm_tail(opt_, d_wsum_.p, d_wsum_.p + NT16, nullptr, (int)(NT16 / 16), 16, 0, stream_);                              // 16 groups each
+    launch_msm_tail(opt_, d_wsum_.p + NT16, nullptr, d_res_.p, 1, (int)(NT16 / 16), 0, stream_, d_tpart_.p, dv.fix_parts1);      // + the fixed-base part
     tock();
     CPX_HIP(hipMemcpyAsync(h_comp_.p, d_res_.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
     CPX_HIP(hipMemcpyAsync(h_u32_.p, dv.flags.p, B * 4, hipMemcpyDeviceToHost, stream_));
@@ -668,7 +668,7 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
   tock();
   reduce_sets(0, B * 32, d_part_.p);
   tick("k_msm_tail", 0, (double)B);
-  launch_msm_tail(d_part_.p, nullptr, d_res_.p, Bi, 16, 8, stream_, d_tpart_.p, dv.fix_parts, 2);
+  launch_msm_tail(opt_, d_part_.p, nullptr, d_res_.p, Bi, 16, 8, stream_, d_tpart_.p, dv.fix_parts, 2);
   tock();
   tick("k_finalize", 0, (double)B);
   launch_finalize(d_res_.p, Bi, nullptr, nullptr, d_comp_.p, stream_);

@@ -10,6 +10,9 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <algorithm>
+#include <cstdio>
+#include <sched.h>
 
 namespace cpx {
 
@@ -37,11 +40,15 @@ class WorkerPool {
   std::exception_ptr err_;
 };
 
-// A few helper threads that SPIN between jobs while engaged.  The host-driven path of a small batch (2 ... 31 proofs) runs a loop
+// A few helper threads that SPIN between jobs while engaged.  The host-driven path of a small batch (2 ... 95 proofs: below the `device_min_batch` option) runs a loop
 // over the proofs between every two MSM phases — 20-100 us of transcript and scalar work per proof, every ~0.3 ms, 40 times per
 // call: a sleeping pool wakes too slowly for that (tens of us per wake-up) and the loop run inline makes the call scale with the
 // batch (12.7 ms at 4 proofs against 6.8 ms at 1).  engage() at the start of the call, release() at its end; in between the
 // helpers poll an epoch counter.
+// Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max; containers on the MI355X hosts
+// see 256 logical CPUs and get 16).  Read once.
+inline size_t effective_host_cores();
+
 class SpinTeam {
  public:
   explicit SpinTeam(size_t helpers);
@@ -66,6 +73,22 @@ class SpinTeam {
   std::mutex err_mu_;
   std::exception_ptr err_;
 };
+
+inline size_t effective_host_cores() {
+  static const size_t cores = [] {
+    size_t c = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) c = std::min<size_t>(c, (size_t)CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+      long long quota = 0, period = 0;
+      if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) c = std::min<size_t>(c, (size_t)std::max<long long>(1, quota / period));
+      fclose(f);
+    }
+    return c;
+  }();
+  return cores;
+}
 
 inline WorkerPool::WorkerPool(size_t threads) {
   for (size_t i = 1; i < threads; i++) threads_.emplace_back([this] { worker(); });

@@ -8,6 +8,36 @@ namespace cpx {
 
 enum : uint32_t { MSM_SCALARS_CANONICAL = 1u };
 
+// Tunables of the launchers and of the host engine.  They belong to an engine context (cpx_ctx_set_option, include/cpx.h): two
+// contexts of one process may run different settings.  The environment (CPX_<NAME>) only provides the defaults a new context
+// starts from (default_options(), read once per process).  Keys are the lower-case field names.
+struct Options {
+  // kernel selection (kernels.hip); *_max: largest launch that still takes the latency (wave / quad per item) form of a kernel
+  long tail_wave_max = 256;
+  long tbw_min_waves = 2048;       // k_msm_tblw: smallest grid that still gets the widest window grouping
+  long tbw_wpw = 0;                // 2|4|8|16|32 pins the windows per wave of k_msm_tblw (0 = by grid size)
+  long tbw_lat_waves = 2048;
+  long tbw_slices = 0;             // 1|2|4 pins the point slices of the bucket-list MSM (0 = by grid size)
+  long reduce_wave_max = -1;       // -1 = by the batch in flight (16384 sets up to 512 proofs, 2048 above)
+  long fix_min_waves = 4096;
+  long fix_lat_waves = 2048;
+  long finalize_wave_max = 512;
+  long table_quad_max = 4096;
+  long decompress_quad_max = 2048;
+  // host engine (engine.cpp)
+  long fix_bits = 16;              // radix of the fixed-base CRS table of multiples: 16 (17.5 GB at ell = 252) or 8 (0.1 GB); read by set_crs
+  long device_min_batch = 96;      // batches of at least this many proofs run the whole protocol on the device
+  long spin_team = 1;              // 0: no spinning helper threads for small batches
+  long spin_team_threads = 8;
+  long inline_below = 16;          // host loops shorter than this run inline
+  long cu_mask = 1;                // 0: plain instead of CU-masked streams for the lone-proof prover
+  long trace = 0;                  // 1: print the challenges of proof 0 to stderr (debugging aid)
+  long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
+};
+const Options& default_options();                               // built-in defaults overridden by CPX_<NAME> environment variables
+bool set_option(Options& o, const char* key, long value);       // false: unknown key or value out of range
+bool get_option(const Options& o, const char* key, long* value);
+
 // Profiling hook: the next launches of the calling thread bind these events to the kernel's begin / end
 // (nullptr, nullptr = plain launches).
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
@@ -35,7 +65,7 @@ struct SmulTask {
 };
 
 // ---- table-backed MSM (no doubling tails) ----
-// Tables and partial sums are in the table kernels' representation (tarith.hpp: TAff / TJac, 28-bit limbs).
+// Tables and partial sums are in the table kernels' representation (g1_28.hpp: TAff / TJac, 28-bit limbs).
 // A table holds, for every base point P_i, 32 affine copies, copy-major (entry (c, i) at base + c*copy_stride + i):
 // 2^(8c) * P_i for c = 0..15 and z^2 * 2^(8(c-16)) * P_i = -phi(2^(8(c-16)) P_i) for c = 16..31.  A scalar is split as
 // k = +-(+-|t| + q z^2) (glv.hpp); every radix-256 window of |t| and of q has its own copy, so all window sums carry
@@ -59,10 +89,10 @@ struct TblTmp {   // table-build scratch: a Jacobian copy and the running produc
 };
 // single-wave work-groups owning wpw (2 .. 32) windows each: 32 / wpw waves per task, two raw sets per wave
 // -> partial sums d_part[task.pad + j], j < 64 / wpw
-int msm_tblw_windows_per_wave(int ntasks);
+int msm_tblw_windows_per_wave(const Options& o, int ntasks);
 int msm_tblw_parts(int wpw);   // waves (= partial sums) per task
 // slices > 1 (a few tasks in flight): that many waves share a task's points; a task then leaves slices * msm_tblw_parts(wpw) partial sums
-int msm_tblw_slices(int ntasks, int wpw, int max_n);   // max_n: points of the largest task
+int msm_tblw_slices(const Options& o, int ntasks, int wpw, int max_n);   // max_n: points of the largest task
 void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s, int slices = 1);
 // The MSM waves of k_msm_tblw / k_msm_fix leave their 64 lane accumulators as "raw sets" (raw_set_words() 32-bit words
 // each; tblw: 2 sets per wave, fix: 1) plus the partial-sum slot every set belongs to; launch_reduce_sets turns them
@@ -80,13 +110,13 @@ void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv
                      hipStream_t s, int slices = 1);
 // The first nplain sets are plain sums, the following nweighted ones bucket sets (lower / upper half alternating).
 // nproofs: how many proofs the batch in flight holds (0: unknown) — picks between the wave-per-set and the work-efficient kernels
-void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s,
+void launch_reduce_sets(const Options& o, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s,
                         int nproofs = 0);   // d_mid: reduce_mid_per_set() TJac per set
 // For `rows` rows of `npts` standard-form points (row r at d_src + r*src_row_stride) writes copies 0..C-1 of the
 // table (row r at d_table + r*row_stride).  d_tmp: rows*npts*(C-1) TblTmp scratch.
 // endo = false: copy c = 2^(256 c / C) P.   endo = true (the tables k_msm_tblw reads): copies 0..C/2-1 = 2^(8c) P and
 // copies C/2.. = their endomorphism images -phi(2^(8c) P) = z^2 2^(8c) P (glv.hpp) — half the doublings.
-void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
+void launch_table_build(const Options& o, const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
                         TblTmp* d_tmp, hipStream_t s);
 
 // ---- fixed-base MSM over a table of multiples (CRS bases) ----
@@ -102,7 +132,7 @@ struct FixTask {
   uint32_t flags;
   uint32_t out_first;       // first partial slot of this task; it writes W / wpw partials
 };
-int msm_fix_windows_per_wave(int ntasks, int cbits);
+int msm_fix_windows_per_wave(const Options& o, int ntasks, int cbits);
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TFix* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
 // k_msm_fix<16, 2> and k_msm_tblw<2, false> of one phase in ONE launch (a lone proof: neither fills the GPU)
 void launch_msm_fix_tblw(const FixTask* d_ftasks, int nftasks, const TFix* d_fix_tab, int nc, uint32_t* d_fraw, uint32_t* d_fraw_slot, const TblTask* d_ttasks,
@@ -112,7 +142,7 @@ void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, T
 // output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)
 // d_addends (optional): [n][3] indices into d_aff of affine points (results of earlier phases) to add to output o; ~0u = none
 // d_comp_index (optional): output o's compressed bytes go to d_comp + 48 * d_comp_index[o] instead of d_comp + 48 * o
-void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
+void launch_finalize_ranges(const Options& o, const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends = nullptr, const uint32_t* d_comp_index = nullptr);
 
 // ntasks MSMs: bucket accumulation -> d_wsum[ntasks*64] window sums (Jacobian, table representation) ...
@@ -123,7 +153,7 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_con
 // Exactly one of d_out (table representation) / d_out_std (standard form, last stage) is non-null.
 // d_extra (optional): extra_per_out further partial sums added to output t before it is written
 // dup: that many consecutive inputs share a weight (out[t] = sum_j 2^(shift*j) (in[(t*group+j)*dup] + ...)).
-void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra = nullptr,
+void launch_msm_tail(const Options& o, const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra = nullptr,
                      int extra_per_out = 0, int dup = 1);
 // Jacobian -> affine (+ optional scatter through dst_index) and optional 48-byte compressed form.
 // d_addend_index (optional): entry g != ~0u names a point of d_aff that is added to input g before it is normalised
@@ -135,7 +165,7 @@ void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, in
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
 // d_src_offset (optional): encoding i starts at byte d_src_offset[i] of d_in (points inside serialized proofs) instead of 48 i
-void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
+void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
                        const uint32_t* d_src_offset = nullptr);
 // Fr algebra of the prover's log rounds on device-resident vectors (kernels.hip: "Fr algebra of the log rounds"):
 // IPA vec [nproofs][4][n] = c | d | SG | SGp, out [nproofs][4 (n/2) + 2]; SameMSM vec [nproofs][2][n] = x | SM, out [nproofs][n];

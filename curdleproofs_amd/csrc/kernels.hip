@@ -14,7 +14,7 @@
 //   MsmAccumulator shared by many proofs (BASELINE config 5)                        -> k_msm_tblw<2, true> over groups of proofs
 //
 // Integer big-number work on the VALU; no MFMA — there is no dense contraction here.  Design notes:
-//  * every group operation runs on the carry-free 28-bit-limb "table form" (fp28.hpp / g1_28.hpp / tarith.hpp);
+//  * every group operation runs on the carry-free 28-bit-limb "table form" (fp28.hpp / g1_28.hpp);
 //    points enter a kernel through t_from_std and leave through t_to_std / t_jac_to_std;
 //  * MSM work-groups are single waves (no inter-wave barriers): lanes own buckets in registers and walk per-bucket
 //    lists sorted into LDS (k_msm_tblw) or digit rows staged in LDS (k_msm_fix, k_msm_accw), points are gathered from
@@ -26,6 +26,9 @@
 //    inversion, modinv30.hpp) instead of the reference's one inversion per point.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
+#include <cctype>
+#include <string>
 #include <hip/hip_ext.h>
 #include "g1.hpp"
 #include "g1_28.hpp"
@@ -92,7 +95,7 @@ __device__ __forceinline__ Fp block_batch_inverse(Fp z, Fp* buf) {
   return fe_mul(fe_mul(tinv, left), right);
 }
 
-// The same on the table form (tarith.hpp): 28-bit-limb lazy values.
+// The same on the table form (fp28.hpp): 28-bit-limb lazy values.
 __device__ __noinline__ TF t_inv_device(const TF& a) { return t_inv(a); }
 __device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
   const int tid = threadIdx.x, n = blockDim.x;
@@ -1438,6 +1441,67 @@ __global__ __launch_bounds__(256) void k_bench_f28mul(Fp* data, int iters) {
 // instead of bracketing it on the stream, which would include queueing behind another engine's kernels.
 static thread_local hipEvent_t tl_ev_start = nullptr, tl_ev_stop = nullptr;
 static thread_local int tl_launches = 0;
+
+// ---- options (kernels.h) ----
+namespace {
+struct OptField {
+  const char* key;
+  long Options::*field;
+  long lo, hi;
+};
+const OptField kOptFields[] = {
+    {"tail_wave_max", &Options::tail_wave_max, 0, 1L << 30},     {"tbw_min_waves", &Options::tbw_min_waves, 0, 1L << 30},
+    {"tbw_wpw", &Options::tbw_wpw, 0, 32},                       {"tbw_lat_waves", &Options::tbw_lat_waves, 0, 1L << 30},
+    {"tbw_slices", &Options::tbw_slices, 0, 4},                  {"reduce_wave_max", &Options::reduce_wave_max, -1, 1L << 30},
+    {"fix_min_waves", &Options::fix_min_waves, 0, 1L << 30},     {"fix_lat_waves", &Options::fix_lat_waves, 0, 1L << 30},
+    {"finalize_wave_max", &Options::finalize_wave_max, 0, 1L << 30}, {"table_quad_max", &Options::table_quad_max, 0, 1L << 30},
+    {"decompress_quad_max", &Options::decompress_quad_max, 0, 1L << 30}, {"fix_bits", &Options::fix_bits, 8, 16},
+    {"device_min_batch", &Options::device_min_batch, 1, 1L << 30}, {"spin_team", &Options::spin_team, 0, 1},
+    {"spin_team_threads", &Options::spin_team_threads, 1, 256},  {"inline_below", &Options::inline_below, 0, 1L << 30},
+    {"cu_mask", &Options::cu_mask, 0, 1},                        {"trace", &Options::trace, 0, 1},
+    {"bench_field", &Options::bench_field, 12, 28},
+};
+bool option_value_ok(const OptField& f, long v) {
+  if (v < f.lo || v > f.hi) return false;
+  if (!strcmp(f.key, "tbw_wpw")) return v == 0 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32;
+  if (!strcmp(f.key, "tbw_slices")) return v == 0 || v == 1 || v == 2 || v == 4;
+  if (!strcmp(f.key, "fix_bits")) return v == 8 || v == 16;
+  return true;
+}
+}  // namespace
+bool set_option(Options& o, const char* key, long value) {
+  if (!key) return false;
+  for (const OptField& f : kOptFields)
+    if (!strcmp(f.key, key)) {
+      if (!option_value_ok(f, value)) return false;
+      o.*(f.field) = value;
+      return true;
+    }
+  return false;
+}
+bool get_option(const Options& o, const char* key, long* value) {
+  if (!key) return false;
+  for (const OptField& f : kOptFields)
+    if (!strcmp(f.key, key)) {
+      if (value) *value = o.*(f.field);
+      return true;
+    }
+  return false;
+}
+const Options& default_options() {
+  static const Options defaults = [] {   // the environment is read ONCE per process and only seeds new contexts
+    Options o;
+    for (const OptField& f : kOptFields) {
+      std::string name = "CPX_";
+      for (const char* c = f.key; *c; c++) name += (char)toupper((unsigned char)*c);
+      const char* e = getenv(name.c_str());
+      if (!e && !strcmp(f.key, "device_min_batch")) e = getenv("CPX_DEVICE_TRANSCRIPT_MIN_BATCH");   // former name
+      if (e && *e) (void)set_option(o, f.key, atol(e));   // an out-of-range value keeps the built-in default
+    }
+    return o;
+  }();
+  return defaults;
+}
 void set_launch_events(hipEvent_t start, hipEvent_t stop) {
   tl_ev_start = start;
   tl_ev_stop = stop;
@@ -1461,12 +1525,10 @@ void launch_msm_accum(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_con
   }
   CPX_LAUNCH(k_msm_accw, dim3(ntasks * 8), dim3(64), ACW_LDS, s, d_tasks, d_conv, d_wsum);
 }
-void launch_msm_tail(const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra, int extra_per_out, int dup) {
+void launch_msm_tail(const Options& o, const TJac* d_in, TJac* d_out, Jac* d_out_std, int nout, int group, int shift, hipStream_t s, const TJac* d_extra, int extra_per_out,
+                     int dup) {
   if (nout <= 0) return;
-  static const long wave_max = [] {   // CPX_TAIL_WAVE_MAX moves the switch-over (tests reach both forms with small inputs)
-    const char* e = getenv("CPX_TAIL_WAVE_MAX");
-    return e ? atol(e) : 256L;
-  }();
+  const long wave_max = o.tail_wave_max;   // moves the switch-over (tests reach both forms with small inputs)
   if (nout <= wave_max && shift > 0 && group <= 16 && dup >= 1 && (dup & (dup - 1)) == 0 && extra_per_out <= 64 &&
       group * dup + extra_per_out <= 255) {   // a few outputs: wave per output, windows shifted side by side
     const size_t lds = (size_t)(group * dup + extra_per_out + 1) * sizeof(TAcc);
@@ -1489,41 +1551,25 @@ void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv
   }
   CPX_LAUNCH((k_msm_tblw<2, true>), dim3(ntasks * 16 * slices), dim3(64), TBW_LDS, s, d_ttasks, d_raw, d_raw_slot, slices);
 }
-int msm_tblw_windows_per_wave(int ntasks) {
+int msm_tblw_windows_per_wave(const Options& o, int ntasks) {
   // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2);
   // a task takes 32 / wpw waves, each of which leaves two raw sets (-> 64 / wpw partial sums per task)
-  static const long min_waves = [] {
-    const char* e = getenv("CPX_TBW_MIN_WAVES");
-    return e ? atol(e) : 2048L;
-  }();
-  static const int forced = [] {   // CPX_TBW_WPW=2|4|8|16|32 pins the grouping (tests exercise every instantiation)
-    const char* e = getenv("CPX_TBW_WPW");
-    const int v = e ? atoi(e) : 0;
-    return (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ? v : 0;
-  }();
-  if (forced) return forced;
+  const long min_waves = o.tbw_min_waves;
+  if (o.tbw_wpw) return (int)o.tbw_wpw;   // 2|4|8|16|32 pins the grouping (tests exercise every instantiation)
   for (int wpw = 32; wpw > 8; wpw >>= 1)
     if ((long)ntasks * (TBW_WINDOWS / wpw) >= min_waves) return wpw;
   // a few proofs in flight: latency matters, so spread a task over as many (short) waves as the GPU can hold at once
-  static const long lat_waves = [] {   // CPX_TBW_LAT_WAVES
-    const char* e = getenv("CPX_TBW_LAT_WAVES");
-    return e ? atol(e) : 2048L;
-  }();
+  const long lat_waves = o.tbw_lat_waves;
   if ((long)ntasks * 16 <= lat_waves) return 2;
   if ((long)ntasks * 8 <= lat_waves) return 4;
   return 8;
 }
 int msm_tblw_parts(int wpw) { return 64 / wpw; }
-int msm_tblw_slices(int ntasks, int wpw, int max_n) {
+int msm_tblw_slices(const Options& o, int ntasks, int wpw, int max_n) {
   // waves per task over its points: only when the GPU would otherwise stand almost empty (a lone proof: 16 waves per task) and a
   // slice keeps >= 256 points — below that the longest of a wave's 128 bucket lists no longer shrinks with the slice (a lane adds
   // max, not mean, and 64 points leave lists of 0..6), while every slice costs two more sets to reduce
-  static const int forced = [] {   // CPX_TBW_SLICES=1|2|4 pins it
-    const char* e = getenv("CPX_TBW_SLICES");
-    const int v = e ? atoi(e) : 0;
-    return (v == 1 || v == 2 || v == 4) ? v : 0;
-  }();
-  if (forced) return forced;
+  if (o.tbw_slices) return (int)o.tbw_slices;   // 1|2|4 pins it
   if (wpw != 2) return 1;
   const long waves = (long)ntasks * 16;
   int s = waves * 4 <= 1024 ? 4 : waves * 2 <= 1024 ? 2 : 1;
@@ -1543,18 +1589,16 @@ void launch_msm_tblw(const TblTask* d_tasks, int ntasks, int wpw, uint32_t* d_ra
 }
 size_t raw_set_words() { return RAW_SET_WORDS; }
 size_t reduce_mid_per_set() { return (MID_PER_SET * sizeof(TAcc) + sizeof(TJac) - 1) / sizeof(TJac); }
-void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s, int nproofs) {
+void launch_reduce_sets(const Options& o, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s,
+                        int nproofs) {
   const int nsets = nplain + nweighted;
   if (nsets <= 0) return;
-  // CPX_REDUCE_WAVE_MAX / CPX_FINALIZE_WAVE_MAX move the switch-over between the latency (wave per item) and the
+  // reduce_wave_max / finalize_wave_max move the switch-over between the latency (wave per item) and the
   // throughput instantiations, so that tests reach the throughput kernels with small batches.
   // The wave form spends ~4x the lane time of the work-efficient form: it pays while the GPU is not full — up to 16384 sets when
   // at most 512 proofs are in flight (64 ... 512 proofs per pass: +5-9 %); a large batch (several contexts keep the GPU busy) keeps
   // it for launches of at most 2048 sets (at 16384 for every batch size the bench lost 3 %)
-  static const long forced = [] {
-    const char* e = getenv("CPX_REDUCE_WAVE_MAX");
-    return e ? atol(e) : -1L;
-  }();
+  const long forced = o.reduce_wave_max;
   const long wave_max = forced >= 0 ? forced : (nproofs > 0 && nproofs <= 512 ? 16384L : 2048L);
   if (nsets <= wave_max) {   // a few proofs: wave per set, both kinds in one launch
     CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), QP_ENTRIES * sizeof(TAcc), s, d_raw, d_raw_slot, nplain, d_part);
@@ -1573,17 +1617,11 @@ void launch_reduce_sets(const uint32_t* d_raw, const uint32_t* d_raw_slot, int n
     CPX_LAUNCH(k_reduce_groups<true>, dim3((nweighted + 63) / 64), block, 0, s, mid_w, d_raw_slot + nplain, nweighted, d_part);
   }
 }
-int msm_fix_windows_per_wave(int ntasks, int cbits) {
+int msm_fix_windows_per_wave(const Options& o, int ntasks, int cbits) {
   const int w = 256 / cbits;
-  static const long min_waves = [] {
-    const char* e = getenv("CPX_FIX_MIN_WAVES");
-    return e ? atol(e) : 4096L;   // two waves per SIMD
-  }();
+  const long min_waves = o.fix_min_waves;   // default: two waves per SIMD
   if ((long)ntasks * (w / 16) >= min_waves) return 16;
-  static const long lat_waves = [] {   // CPX_FIX_LAT_WAVES: up to how many waves the short-wave forms may launch
-    const char* e = getenv("CPX_FIX_LAT_WAVES");
-    return e ? atol(e) : 2048L;
-  }();
+  const long lat_waves = o.fix_lat_waves;   // up to how many waves the short-wave forms may launch
   if (cbits == 16) {   // a few proofs in flight: more, shorter waves per task
     if ((long)ntasks * 8 <= lat_waves) return 2;
     if ((long)ntasks * 4 <= lat_waves) return 4;
@@ -1614,30 +1652,24 @@ void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, T
   if (cbits == 16) CPX_LAUNCH(k_fix_build<16>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
   else CPX_LAUNCH(k_fix_build<8>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
 }
-void launch_finalize_ranges(const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
+void launch_finalize_ranges(const Options& o, const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends, const uint32_t* d_comp_index) {
   if (n <= 0) return;
-  static const long wave_max = [] {
-    const char* e = getenv("CPX_FINALIZE_WAVE_MAX");
-    return e ? atol(e) : 512L;
-  }();
+  const long wave_max = o.finalize_wave_max;
   if (n <= wave_max) {   // a few proofs: wave per request (tree over the partial sums)
     CPX_LAUNCH(k_finalize_ranges_wave, dim3(n), dim3(64), 256 * sizeof(TAcc), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
     return;
   }
   CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
 }
-void launch_table_build(const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
+void launch_table_build(const Options& o, const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
                         TblTmp* d_tmp, hipStream_t s) {
   const long total = (long)rows * npts;
   if (total <= 0) return;
   // single-wave work-groups: a 256-thread group of this 241-VGPR kernel only ever got one group per CU (38 ms against 19 ms per
   // 2048 proofs); one inversion per 64 bases instead of per 256 costs ~5 % of a wave's time
   constexpr int blk = 64;
-  static const long quad_max = [] {   // CPX_TABLE_QUAD_MAX moves the switch-over (tests reach both forms with small inputs)
-    const char* e = getenv("CPX_TABLE_QUAD_MAX");
-    return e ? atol(e) : 4096L;
-  }();
+  const long quad_max = o.table_quad_max;   // moves the switch-over (tests reach both forms with small inputs)
   const int real = endo ? copies / 2 : copies;
   if (total <= quad_max && real - 1 <= 4 * TBQ_CHUNK) {   // a few rows: quad per base point
     const size_t lds = (2 * 64 + TBQ_CHUNK * 64) * sizeof(TF) + TBQ_CHUNK * 64 * sizeof(TJac);
@@ -1666,13 +1698,10 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
   const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 18 * SMUL_THREADS * sizeof(uint32_t);
   CPX_LAUNCH(k_smul, dim3((unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS)), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
 }
-void launch_decompress(const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
+void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
                        const uint32_t* d_src_offset) {
   if (n <= 0) return;
-  static const long quad_max = [] {   // CPX_DECOMPRESS_QUAD_MAX moves the switch-over (tests reach both forms with small inputs)
-    const char* e = getenv("CPX_DECOMPRESS_QUAD_MAX");
-    return e ? atol(e) : 2048L;
-  }();
+  const long quad_max = o.decompress_quad_max;   // moves the switch-over (tests reach both forms with small inputs)
   if (n <= quad_max && check_subgroup) {   // a few points: quad per point
     CPX_LAUNCH(k_decompress_quad, dim3((n + 15) / 16), dim3(64), 16 * 3 * sizeof(TAcc), s, d_in, n, d_out, d_dst_index, d_status, check_subgroup, d_src_offset);
     return;

@@ -86,7 +86,6 @@ def generate_whisk_shuffle_proof(ctx, pre_trackers, permutation=None, k=None, ve
     post, proof = _out(ell * 2 * G1POINT_SIZE), _out(whisk_shuffle_proof_size(ctx))
     perm = (ctypes.c_uint32 * ell)(*permutation)
     _check(ctx, ctx._L.cpx_whisk_generate_shuffle_proof(ctx._h, _in(_cat(pre_trackers)), perm, _in(k), _in(vec_m_blinders), _in(rand), post, proof))
-    ctx.batch = 1
     pb = bytes(post)
     return [WhiskTracker(pb[96 * i:96 * i + 48], pb[96 * i + 48:96 * i + 96]) for i in range(ell)], bytes(proof)
 
@@ -105,7 +104,6 @@ def is_valid_whisk_shuffle_proof(ctx, pre_trackers, post_trackers, whisk_shuffle
     valid = ctypes.c_int(0)
     _check(ctx, ctx._L.cpx_whisk_is_valid_shuffle_proof(ctx._h, _in(_cat(pre_trackers)), _in(_cat(post_trackers)), _in(whisk_shuffle_proof_bytes), _in(rand),
                                                         ctypes.byref(valid)))
-    ctx.batch = 1
     return bool(valid.value)
 
 

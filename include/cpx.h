@@ -46,6 +46,15 @@ void cpx_ctx_destroy(cpx_ctx* ctx);
 const char* cpx_last_error(const cpx_ctx* ctx); /* message of the last failing call on this ctx    */
 int cpx_device_count(void);
 
+/* Per-context tunables (kernel selection thresholds, radix of the fixed-base table, batch size from which the protocol runs on the
+ * device, ...): key = one of the names listed in curdleproofs_amd/csrc/kernels.h `struct Options` ("fix_bits", "device_min_batch",
+ * "tbw_wpw", "reduce_wave_max", ...).  A new context starts from the built-in defaults, overridden by CPX_<KEY> environment
+ * variables read once per process; everything after that goes through these calls and concerns this context only.  Results never
+ * depend on an option (tests/test_gpu_parity.py::test_engine_variants_stay_bit_exact), only speed does.  "fix_bits" takes effect at
+ * the next cpx_ctx_set_crs.  Unknown key / value out of range -> CPX_ERR_ARG. */
+int cpx_ctx_set_option(cpx_ctx* ctx, const char* key, long long value);
+int cpx_ctx_get_option(const cpx_ctx* ctx, const char* key, long long* value);
+
 /* Optional: page-locked host buffers.  Any host memory may be passed to the calls below; buffers obtained here let the batch calls
  * move their inputs / outputs by asynchronous DMA (no staging copies, transfers overlap the kernels of other contexts). */
 void* cpx_host_alloc(size_t bytes);
@@ -59,6 +68,7 @@ void cpx_host_free(void* p);
 int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points, size_t n_points);
 int cpx_crs_sums(const cpx_ctx* ctx, uint8_t g_sum[96], uint8_t h_sum[96]);
 size_t cpx_proof_size(const cpx_ctx* ctx); /* 48*(18+10*log2(ell+4)) + 32*7, e.g. 4928 at ell = 252 */
+size_t cpx_batch_size(const cpx_ctx* ctx); /* instances currently loaded (cpx_batch_load, or 1 after a cpx_whisk_*_shuffle_proof call); 0 = none */
 
 /* ---- tier 0: the reference's MSM funnel and the loops that bypass it ------------------------- */
 /* util.rs:19-22 `msm(points: &[G1Affine], scalars: &[Fr]) -> G1Projective` */

@@ -454,16 +454,17 @@ def test_not_power_of_two_is_an_error(ctx, orc):
 
 
 @pytest.mark.parametrize("wpw", [2, 4, 8, 16, 32])
-def test_table_msm_window_groupings_reproduce_kat(wpw):
+def test_table_msm_window_groupings_reproduce_kat(wpw, orc, whisk_kat, oracle_vectors):
     # k_msm_tblw<WPW>: the launcher picks the windows-per-wave grouping from the grid size, so small batches only
-    # reach WPW = 8.  Pin the other instantiations (fresh process: the choice is read once) on the reference KAT.
-    import subprocess
-    import sys
-    env = dict(os.environ, CPX_TBW_WPW=str(wpw))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_prove_matches_reference_kat_ell124 or test_prove_verify_ell252_batch"],
-                       env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # reach WPW = 8.  Pin the other instantiations (a context of its own with the option set) on the reference KAT.
+    import curdleproofs_amd as cpx
+    c = cpx.Context(0, options={"tbw_wpw": wpw})
+    try:
+        assert c.get_option("tbw_wpw") == wpw
+        test_prove_matches_reference_kat_ell124(c, orc, whisk_kat)
+        test_prove_verify_ell252_batch(c, orc, oracle_vectors)
+    finally:
+        c.close()
 
 
 def test_fused_batch_verifier_config5(ctx, orc):
@@ -522,43 +523,80 @@ def test_fused_batch_verifier_many_points(ctx, orc, ell, nproofs):
 # a batch of a few proofs reaches.  THROUGHPUT_ENV moves every switch-over so that small batches run exactly those
 # instantiations (kernels.hip: msm_fix_windows_per_wave, msm_tblw_windows_per_wave, launch_reduce_sets,
 # launch_finalize_ranges, launch_msm_tail).
-THROUGHPUT_ENV = {"CPX_FIX_MIN_WAVES": "1", "CPX_TBW_WPW": "32", "CPX_REDUCE_WAVE_MAX": "0", "CPX_FINALIZE_WAVE_MAX": "0", "CPX_TAIL_WAVE_MAX": "0", "CPX_TABLE_QUAD_MAX": "0", "CPX_DECOMPRESS_QUAD_MAX": "0"}
+THROUGHPUT = {"fix_min_waves": 1, "tbw_wpw": 32, "reduce_wave_max": 0, "finalize_wave_max": 0, "tail_wave_max": 0, "table_quad_max": 0, "decompress_quad_max": 0}
+VARIANTS = {
+    "fix8": {"fix_bits": 8},
+    "device_resident": {"device_min_batch": 1},
+    "host_driven": {"device_min_batch": 1000000},
+    "throughput_kernels": THROUGHPUT,
+    "throughput_kernels_device_resident": dict(THROUGHPUT, device_min_batch=1),
+    "four_point_slices_host_driven": {"tbw_slices": 4, "device_min_batch": 1000000},
+    "two_point_slices_thread_tail": {"tbw_slices": 2, "tail_wave_max": 0},
+    "plain_streams_wave_kernels_everywhere": {"cu_mask": 0, "reduce_wave_max": 1000000, "finalize_wave_max": 1000000},
+}
 
 
-@pytest.mark.parametrize("env", [{"CPX_FIX_BITS": "8"}, {"CPX_DEVICE_MIN_BATCH": "1"}, {"CPX_DEVICE_MIN_BATCH": "1000000"}, THROUGHPUT_ENV,
-                                 dict(THROUGHPUT_ENV, CPX_DEVICE_MIN_BATCH="1"),
-                                 {"CPX_TBW_SLICES": "4", "CPX_DEVICE_MIN_BATCH": "1000000"}, {"CPX_TBW_SLICES": "2", "CPX_TAIL_WAVE_MAX": "0"},
-                                 {"CPX_CU_MASK": "0", "CPX_REDUCE_WAVE_MAX": "1000000", "CPX_FINALIZE_WAVE_MAX": "1000000"}],
-                         ids=["fix8", "device_resident", "host_driven", "throughput_kernels", "throughput_kernels_device_resident",
-                              "four_point_slices_host_driven", "two_point_slices_thread_tail", "plain_streams_wave_kernels_everywhere"])
-def test_engine_variants_stay_bit_exact(env):
+def _variant_checks(c, orc, whisk_kat, oracle_vectors):
+    test_prove_matches_reference_kat_ell124(c, orc, whisk_kat)
+    test_verify_rejects_mutated_instances(c, orc)
+    test_fused_batch_verifier_config5(c, orc)
+    test_prove_verify_ell252_batch(c, orc, oracle_vectors)
+    test_same_scalar_relations_are_checked(c, orc)
+    test_prove_verify_batch40_ell28(c, orc)
+    test_verify_rejects_corrupted_proof_bytes(c, orc)
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_engine_variants_stay_bit_exact(name, orc, whisk_kat, oracle_vectors):
     # the 8-bit fixed-base table, the device-resident protocol (step kernels of protocol.hip; normally used from 96 proofs per
     # batch on) forced on single proofs, the host-driven protocol forced on a batch of 40, and the throughput instantiations
     # of the MSM / reduction / finalisation kernels, the point slices of the bucket-list MSM (msm_tblw_slices: by default only
     # tasks of >= 512 points of a lone proof are sliced) and the latency kernels forced onto every batch size
-    # are alternative engine configurations; all must reproduce the reference
+    # are alternative engine configurations, selected per context through cpx_ctx_set_option; all must reproduce the reference
     # KAT (whisk.rs:416-456), the oracle's bytes at ell = 28 / 252 and the oracle's verdicts
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
-                        "test_prove_matches_reference_kat_ell124 or test_verify_rejects_mutated_instances or test_fused_batch_verifier_config5 "
-                        "or test_prove_verify_ell252_batch or test_same_scalar_relations_are_checked or test_prove_verify_batch40_ell28 "
-                        "or test_verify_rejects_corrupted_proof_bytes"],
-                       env=dict(os.environ, **env), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "7 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    import curdleproofs_amd as cpx
+    c = cpx.Context(0, options=VARIANTS[name])
+    try:
+        for k, v in VARIANTS[name].items():
+            assert c.get_option(k) == v
+        _variant_checks(c, orc, whisk_kat, oracle_vectors)
+    finally:
+        c.close()
+
+
+def test_options_are_per_context_and_validated(ctx):
+    """cpx_ctx_set_option: unknown keys and out-of-range values are argument errors; an option set on one context does not leak
+    into another one (the environment only seeds the defaults)."""
+    import curdleproofs_amd as cpx
+    other = cpx.Context(0)
+    try:
+        before = ctx.get_option("device_min_batch")
+        other.set_option("device_min_batch", before + 5)
+        assert ctx.get_option("device_min_batch") == before and other.get_option("device_min_batch") == before + 5
+        for key, value in (("no_such_option", 1), ("fix_bits", 12), ("tbw_wpw", 3), ("tbw_slices", 3), ("device_min_batch", 0)):
+            with pytest.raises(cpx.CpxError) as e:
+                other.set_option(key, value)
+            assert e.value.code == cpx.CPX_ERR_ARG
+    finally:
+        other.close()
 
 
 def _proof_offsets(ell):
     """byte offsets inside CurdleproofsProof::serialize (curdleproofs.rs:300-310 and the sub-proofs' serialisers)"""
     L = (ell + 4).bit_length() - 1
     o = 9 * 48                   # A cm_T(2) cm_U(2) R S | B | C
-    off = {"r_p": o}
+    off = {"A": 0, "cm_T_T1": 48, "cm_T_T2": 96, "cm_U_T1": 144, "cm_U_T2": 192, "R": 240, "S": 288, "B": 336, "C": 384, "r_p": o}
+    off["B_c"], off["B_d"] = o + 32, o + 80
+    off["L_C"], off["R_C"], off["L_D"], off["R_D"] = (o + 128 + q * L * 48 for q in range(4))
     o += 32 + (2 + 4 * L) * 48   # B_c B_d L_C R_C L_D R_D
     off["c"], off["d"] = o, o + 32
     o += 64
     off["cm_A_T1"], off["cm_A_T2"], off["cm_B_T1"], off["cm_B_T2"] = o, o + 48, o + 96, o + 144
     o += 4 * 48
     off["z_k"], off["z_t"], off["z_u"] = o, o + 32, o + 64
+    off["B_a"], off["B_t"], off["B_u"] = o + 96, o + 144, o + 192
+    off["L_A"], off["L_T"], off["L_U"] = (o + 96 + (3 + q * L) * 48 for q in range(3))
+    off["R_A"], off["R_T"], off["R_U"] = (o + 96 + (3 + (3 + q) * L) * 48 for q in range(3))
     o += 96 + (3 + 6 * L) * 48
     off["x"] = o
     assert o + 32 == 48 * (18 + 10 * L) + 32 * 7
@@ -612,6 +650,152 @@ def test_same_scalar_relations_are_checked(ctx, orc):
     bad[off["z_k"]:off["z_k"] + 32] = ((zk + 1) % 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001).to_bytes(32, "little")
     assert oracle_verdict(1, bytes(bad)) == 0
     assert ctx.verify_batch([proofs[0], bytes(bad), proofs[2], proofs[3]], vrand) == [cpx.CPX_OK, cpx.CPX_ERR_VERIFY, cpx.CPX_OK, cpx.CPX_OK]
+
+
+@pytest.mark.parametrize("copies", [1, 97], ids=["host_driven", "device_resident"])
+def test_single_field_negatives_of_every_sub_argument(ctx, orc, copies):
+    """The reference's sub-argument negatives — a wrong inner product (inner_product_argument.rs:432-446), a wrong grand product
+    and a wrong `B` (grand_product_argument.rs:316-373) — at the level this boundary sees them: ONE field of a valid serialized proof
+    replaced by another valid encoding (a canonical scalar / a subgroup point), everything else untouched.  r_p (GrandProduct), c, d
+    (IPA), x (SameMSM), z_k (SameScalar), and one point of every sub-proof: B (SamePerm), C (GrandProduct), B_c, L_C[1], R_D[0] (IPA),
+    cm_A.T_2 (SameScalar), B_a, L_T[0], R_U[last] (SameMSM), A / cm_T.T_1 / R (top level).  Verdicts of the per-proof verifier must equal
+    the oracle's (all VerificationError), and the fused verifier must reject a batch holding one such proof — on the host-driven
+    path (one proof per call) and the device-resident one (the mutated proof inside a batch of 97)."""
+    import curdleproofs_amd as cpx
+    ell = 28
+    L = 5
+    crs = orc.generate_crs_points(ell)
+    ctx.set_crs(ell, crs)
+    inst = orc.make_instance(ell, 77, crs)
+    good = inst["proof"]
+    cat = lambda key: inst[key] * copies
+    ctx.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+    vrand = inst["verifier_rand"] * copies
+    frand = orc.rng(818).fr(12 * copies)
+    assert ctx.verify_batch([good] * copies, vrand) == [cpx.CPX_OK] * copies
+    assert ctx.verify_batch_fused([good] * copies, frand)
+    off = _proof_offsets(ell)
+    rng = orc.rng(717)
+    scalar = orc.fr_to_canonical_bytes(rng.fr(1))
+    point = orc.g1_compress(rng.g1_affine(1))
+    fields = [("r_p", 0, scalar), ("c", 0, scalar), ("d", 0, scalar), ("x", 0, scalar), ("z_k", 0, scalar),
+              ("A", 0, point), ("cm_T_T1", 0, point), ("R", 0, point), ("B", 0, point), ("C", 0, point), ("B_c", 0, point), ("L_C", 1, point),
+              ("R_D", 0, point), ("cm_A_T2", 0, point), ("B_a", 0, point), ("L_T", 0, point), ("R_U", L - 1, point)]
+    victim = copies // 2
+    for field, j, repl in fields:
+        o = off[field] + 48 * j
+        assert good[o:o + len(repl)] != repl
+        bad = good[:o] + repl + good[o + len(repl):]
+        want = orc.verify(ell, crs, inst["vec_R"], inst["vec_S"], inst["vec_T"], inst["vec_U"], inst["M"], bad, inst["verifier_rand"])
+        assert want == 0, (field, want)      # the reference's tests expect VerificationError for each of these
+        proofs = [good] * copies
+        proofs[victim] = bad
+        expect = [cpx.CPX_OK] * copies
+        expect[victim] = cpx.CPX_ERR_VERIFY
+        assert ctx.verify_batch(proofs, vrand) == expect, field
+        assert not ctx.verify_batch_fused(proofs, frand), field
+    # the identity in place of a proof point is a valid encoding too (curdleproofs.rs:312-323 deserialises it): still a wrong proof
+    o = off["L_D"]
+    bad = good[:o] + bytes([0xc0]) + bytes(47) + good[o + 48:]
+    want = orc.verify(ell, crs, inst["vec_R"], inst["vec_S"], inst["vec_T"], inst["vec_U"], inst["M"], bad, inst["verifier_rand"])
+    proofs = [good] * copies
+    proofs[victim] = bad
+    got = ctx.verify_batch(proofs, vrand)
+    assert want == 0 and got[victim] == cpx.CPX_ERR_VERIFY and got.count(cpx.CPX_OK) == copies - 1
+
+
+def test_crs_switch_at_equal_ell_on_the_device_path(orc):
+    """Two different CRS of the same ell on one context, batches large enough for the device-resident protocol: the cached device
+    plans embed the compressed H and table addresses of the CRS they were built for, so set_crs must drop them (a new table
+    allocation of the same size may land on the same addresses).  Proof bytes and verdicts against the oracle under both CRS,
+    in the order first -> second -> first."""
+    import curdleproofs_amd as cpx
+    ell, nb = 28, 100
+    crs_a = orc.generate_crs_points(ell)
+    crs_b = orc.rng(31337).g1_affine(ell + 7)
+    assert crs_a != crs_b
+    c = cpx.Context(0)
+    try:
+        for crs in (crs_a, crs_b, crs_a):
+            c.set_crs(ell, crs)
+            insts = [orc.make_instance(ell, 300 + s, crs) for s in range(4)]
+            insts = [insts[i % 4] for i in range(nb)]
+            cat = lambda key: b"".join(i[key] for i in insts)
+            c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+            proofs = c.prove_batch([x for i in insts for x in i["permutation"]], cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+            assert [p == i["proof"] for p, i in zip(proofs, insts)] == [True] * nb
+            assert c.verify_batch(proofs, cat("verifier_rand")) == [cpx.CPX_OK] * nb
+            assert c.verify_batch_fused(proofs, orc.rng(5).fr(12 * nb))
+    finally:
+        c.close()
+
+
+def test_headline_shape_1024_proofs_ell252_every_proof_matches_oracle(orc):
+    """BASELINE configs[3] at its literal shape — 1024 independent instances at ell = 252, instance i from StdRng(i) — on ONE GPU the
+    way bench.py drives it: two engine contexts x 512 proofs from two host threads at once, default options (k_msm_fix<16, 16>,
+    k_msm_tblw<32, false>, the thread-per-group reductions, the device-resident protocol).  EVERY proof must equal the oracle's
+    bytes and every verdict the oracle's (three deliberately wrong proofs per context); then configs[4]'s batched verifier over the
+    same 1024 proofs: the two contexts' partial sums add up to the identity for the valid batch and do not once wrong proofs are
+    in it (curdleproofs.rs:385-471 + msm_accumulator.rs:38-68 at the headline size)."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import curdleproofs_amd as cpx
+    ell, K, N = 252, 2, 1024
+    ncpu = min(len(os.sched_getaffinity(0)), os.cpu_count() or 8, 64)
+    crs = orc.generate_crs_points(ell)
+    with ThreadPoolExecutor(ncpu) as ex:   # the oracle is a C library behind ctypes (the GIL is released): ~0.7 s per instance and core
+        insts = list(ex.map(lambda s: orc.make_instance(ell, s, crs), range(N)))
+    assert all(i["verdict"] == 1 for i in insts)
+    per = N // K
+    errors = []
+    partials, partials_bad = [None] * K, [None] * K
+
+    def run(k):
+        try:
+            c = cpx.Context(0)
+            c.set_crs(ell, crs)
+            mine = insts[k * per:(k + 1) * per]
+            cat = lambda key: b"".join(i[key] for i in mine)
+            c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+            proofs = c.prove_batch([x for i in mine for x in i["permutation"]], cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+            wrong = [j for j, (i, p) in enumerate(zip(mine, proofs)) if p != i["proof"]]
+            if wrong:
+                errors.append("context %d: %d of %d proofs differ from the oracle's, first at index %d" % (k, len(wrong), per, wrong[0]))
+            good = [i["proof"] for i in mine]
+            bad = list(good)
+            bad[5] = good[6]                                                        # a neighbour's proof
+            bad[per // 2] = good[per // 2][48:96] + good[per // 2][:48] + good[per // 2][96:]   # two points swapped
+            last = bytearray(good[per - 1])
+            last[-1] ^= 0x01                                                        # the last scalar changed
+            bad[per - 1] = bytes(last)
+            got = c.verify_batch(bad, cat("verifier_rand"))
+            want = [cpx.CPX_OK] * per
+            for j in (5, per // 2, per - 1):
+                x = mine[j]
+                o = orc.verify(ell, crs, x["vec_R"], x["vec_S"], x["vec_T"], x["vec_U"], x["M"], bad[j], x["verifier_rand"])
+                want[j] = {1: cpx.CPX_OK, 0: cpx.CPX_ERR_VERIFY, -1: cpx.CPX_ERR_DESERIALIZE}[o]
+            if got != want:
+                errors.append("context %d: verdicts differ at %s" % (k, [j for j in range(per) if got[j] != want[j]][:8]))
+            if c.verify_batch(good, cat("verifier_rand")) != [cpx.CPX_OK] * per:
+                errors.append("context %d: a valid proof was rejected" % k)
+            frand = orc.rng(9100 + k).fr(12 * per)
+            partials[k] = c.verify_batch_fused_partial(good, frand)
+            partials_bad[k] = c.verify_batch_fused_partial(bad, frand) if k == 1 else partials[k]
+            c.close()
+        except Exception as e:   # surfaced below
+            errors.append("context %d: %r" % (k, e))
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    c = cpx.Context(0)
+    assert all(b == 0 for _, b in partials)
+    assert c.sum_jac(b"".join(p for p, _ in partials))[1], "partial sums of 1024 valid ell=252 proofs must add up to the identity"
+    assert not c.sum_jac(b"".join(p for p, _ in partials_bad))[1]
+    c.close()
 
 
 def test_verifier_rejects_degenerate_random_factors(ctx, orc):

@@ -100,6 +100,7 @@ def test_whisk_shuffle_proof_reference_kat(ctx, orc, whisk_kat):
         whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, bytes(48) + proof[48:], rand=vrand)
     with pytest.raises(whisk.SerializationError):
         whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, proof[:-32] + b"\xff" * 32, rand=vrand)
+    assert ctx.batch == 1        # the engine holds the one instance of the failed call, and the Python mirror reads it from the library
     with pytest.raises(whisk.SerializationError):
         whisk.generate_whisk_shuffle_proof(ctx, bad_tr, permutation=perm, k=k, vec_m_blinders=mb, rand=rand)
     # CSPRNG-drawn witnesses: a fresh proof verifies, and differs from the KAT
@@ -141,6 +142,16 @@ def test_crs_hex_json_roundtrip(ctx, orc):
     bad = dict(obj, G_t="0x" + "00" * 48)                 # not a compressed encoding
     with pytest.raises(whisk.SerializationError):
         crsmod.crs_from_hex(c2, bad)
-    bad = dict(obj, G_sum=obj["H_sum"])                   # sums that do not belong to the vectors
-    with pytest.raises(ValueError):
+    bad = dict(obj, H="0x " + obj["H"][4:] + " ")          # blanks inside the hex: hex::decode refuses them (bytes.fromhex would not)
+    with pytest.raises(whisk.SerializationError):
         crsmod.crs_from_hex(c2, bad)
+    # sums that do not belong to the vectors: refused BEFORE anything is loaded — a fresh context stays without a CRS,
+    # a context that held one keeps it
+    other = orc.rng(8).g1_affine(ell + 7)
+    c3 = cpx.Context(0)
+    c3.set_crs(ell, other)
+    bad = dict(obj, G_sum=obj["H_sum"])
+    for c in (cpx.Context(0), c3):
+        with pytest.raises(ValueError):
+            crsmod.crs_from_hex(c, bad)
+    assert c3.crs_sums() == orc.crs_sums(ell, other) and c3.crs_points == other

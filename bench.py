@@ -250,6 +250,8 @@ def main():
                     "kernels) run beside the other's MSM waves")
     ap.add_argument("--no-extra-shapes", action="store_true", help="skip the extra keys: throughput at BASELINE's literal batch shapes (128 / 1024 proofs per "
                     "GPU), ell=1020 throughput and the all-cores CPU baseline")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option for every context (cpx_ctx_set_option), e.g. "
+                    "--opt late_rounds=0 for an A/B run")
     args = ap.parse_args()
 
     # --gpus N without a launcher around us: start the N ranks ourselves (one process per GPU, the same command line the
@@ -308,7 +310,8 @@ def main():
     import threading
     ell, B, K = args.ell, args.batch, max(1, args.ctxs)
     assert B % K == 0, "--batch must be a multiple of --ctxs"
-    ctxs = [cpx.Context(local_rank) for _ in range(K)]          # raises without a GPU: no CPU fallback
+    engine_opts = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.opt}
+    ctxs = [cpx.Context(local_rank, options=engine_opts) for _ in range(K)]          # raises without a GPU: no CPU fallback
     # host worker threads per context: the cores of the node divided over ranks x contexts (all ranks share one node)
     host_threads = args.host_threads or max(2, min(24, effective_cores() // (world * K)))
     for c in ctxs:

@@ -234,11 +234,26 @@ class Engine {
     DevBuf<uint8_t> slotcomp, proofs;
     TblPlan p1, p2, p3;
     std::vector<std::unique_ptr<TblPlan>> ipa, smsm;
+    // the last log rounds on materialised folded bases (late.hip; options late_rounds, late_min_batch)
+    struct Late {
+      bool on = false;
+      int m = 16;
+      size_t j0 = 0;                    // first late round
+      DevBuf<TJac> jac;                 // [LATE_FAMILIES][B][m] materialised points
+      DevBuf<TAff> tab;                 // [LATE_FAMILIES][B][m][late_tab_entries()] their small multiples
+      DevBuf<TJac> part, extra;         // window-group partial sums of a round's outputs [6 B][slices]; the IPA rounds' CRS terms [4 B]
+      const uint32_t* h_col = nullptr;
+      DevBuf<uint32_t> meta;            // iota | ones | compressed-bytes slots of every late round's outputs
+      std::vector<LateRound> ipa, smsm;
+      std::vector<size_t> ipa_comp, smsm_comp;   // offsets of a round's slot list inside meta
+      const uint32_t* gb_cols = nullptr;
+    } late;
     const uint32_t* side_cols = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   };
   DevProver dprove_;
   void enqueue_prove_device();
+  void exec_late_round(const LateRound& r, size_t comp_off, const char* what);
   struct DevVerifier {
     std::vector<const void*> signature;
     VerifyDev dev;

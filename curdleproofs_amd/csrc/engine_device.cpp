@@ -116,6 +116,31 @@ void Engine::exec_plan(const TblPlan& pl, uint8_t* d_comp_registry) {
   tock();
 }
 
+// One late round: lane-per-output Straus MSMs over the materialised points, then the usual finalisation (affine, compressed bytes
+// into the slot registry; nothing reads these points in affine form again)
+void Engine::exec_late_round(const LateRound& r0, size_t comp_off, const char* what) {
+  LateRound r = r0;
+  const DevProver::Late& lt = dprove_.late;
+  r.out = lt.part.p;
+  const int nreq = r.total / r.slices, hm = r.m / 2, Bi = r.nproofs;
+  const double pairs = (double)nreq * hm;
+  tick(what, 128.0 * pairs, pairs);
+  launch_late_msm(r, stream_);
+  tock();
+  const bool ipa = r.nout == 4;
+  if (ipa) {   // beta <c_L, d_R> H and beta <c_R, d_L> H (inner_product_argument.rs:152,158) from the table of multiples: the extras of L_C, R_C
+    launch_late_fix(d_rout_.p + hm, r.scal_proof_stride, lt.h_col, 1, 1, fixtab(), fix_bits_, (int)nc(), lt.extra.p, 4, Bi, stream_);
+    launch_late_fix(d_rout_.p + 3 * hm + 1, r.scal_proof_stride, lt.h_col, 1, 1, fixtab(), fix_bits_, (int)nc(), lt.extra.p + 2, 4, Bi, stream_);
+  }
+  tick("k_msm_tail", 0, (double)nreq);
+  launch_msm_tail(opt_, lt.part.p, d_tpart_.p, nullptr, nreq, r.slices, 128 / r.slices, stream_, ipa ? lt.extra.p : nullptr, ipa ? 1 : 0);
+  tock();
+  const uint32_t* meta = lt.meta.p;
+  tick("k_finalize_ranges", 0, (double)nreq);
+  launch_finalize_ranges(opt_, d_tpart_.p, meta, meta + 6 * B_, nreq, nullptr, nullptr, dprove_.slotcomp.p, stream_, nullptr, meta + comp_off);
+  tock();
+}
+
 // ---------------------------------------------------------------- prover
 // (Re)builds everything that depends only on the shape of the loaded batch: device buffers, the ProveDev view, the task
 // descriptors of every phase and of the side stream.
@@ -278,7 +303,17 @@ void Engine::prepare_device_prover() {
   dp.ipa.clear();
   dp.smsm.clear();
   const size_t hn = n / 2, per = 4 * hn + 2;
+  // the last four rounds of a large batch work on 16 materialised folded bases per family instead (late.hip)
+  DevProver::Late& lt = dp.late;
+  lt.m = 16;
+  lt.on = opt_.late_rounds == 4 && L >= 5 && B >= (size_t)opt_.late_min_batch && late_supported((int)n, lt.m) && 3 * lt.m <= 64;
+  lt.j0 = lt.on ? L - 4 : L;
   for (size_t j = 0; j < L; j++) {
+    if (j >= lt.j0) {   // placeholders: exec_late_round takes these rounds
+      dp.ipa.emplace_back(nullptr);
+      dp.smsm.emplace_back(nullptr);
+      continue;
+    }
     const size_t half = n >> (j + 1);
     std::vector<uint32_t> hi, lo, ghi, glo;
     for (size_t k = 0; k < n; k++) {
@@ -322,6 +357,64 @@ void Engine::prepare_device_prover() {
     dp.smsm.emplace_back(new TblPlan());
     build_plan(*dp.smsm.back(), reqs, ci);
   }
+  if (lt.on) {
+    const int m = lt.m, hm = m / 2;
+    const size_t BM = B * (size_t)m, ent = late_tab_entries();
+    lt.jac.ensure((size_t)LATE_FAMILIES * BM);
+    lt.tab.ensure((size_t)LATE_FAMILIES * BM * ent);
+    lt.gb_cols = iGb;
+    lt.h_col = iH;
+    lt.part.ensure(6 * B * (size_t)opt_.late_slices);
+    lt.extra.ensure(4 * B);
+    CPX_HIP(hipMemset(lt.extra.p, 0, 4 * B * sizeof(TJac)));   // all-zero = the identity: the outputs without a CRS term keep it
+    lt.ipa.clear();
+    lt.smsm.clear();
+    lt.ipa_comp.clear();
+    lt.smsm_comp.clear();
+    std::vector<uint32_t> meta(2 * 6 * B);
+    for (size_t g = 0; g < 6 * B; g++) {
+      meta[g] = (uint32_t)g;      // request g = partial sum g
+      meta[6 * B + g] = 1;
+    }
+    for (int r = 0; r < 4; r++) {
+      const int j = (int)lt.j0 + r;
+      LateRound a{};
+      a.m = m;
+      a.half = m >> (r + 1);
+      a.nproofs = (int)B;
+      a.slices = (int)opt_.late_slices;
+      a.tab = lt.tab.p;
+      a.scal = d_rout_.p;
+      // inner_product_argument.rs:150-163: L_C = <c_L, G_R> + beta <c_L, d_R> H, L_D = <d_R, G'_L>, R_C = <c_R, G_L> + beta <c_R, d_L> H,
+      // R_D = <d_L, G'_R>; scalar rows as k_ipa_round_scalars lays them out for m active elements
+      a.nout = 4;
+      a.total = (int)(4 * B) * a.slices;
+      a.scal_proof_stride = (uint32_t)(4 * hm + 2);
+      a.o[0] = LateOut{LATE_F_G, 1, 0u};                          // (+ the H terms at scalar offsets hm and 3 hm + 1: exec_late_round)
+      a.o[1] = LateOut{LATE_F_GP, 0, (uint32_t)(hm + 1)};
+      a.o[2] = LateOut{LATE_F_G, 0, (uint32_t)(2 * hm + 1)};
+      a.o[3] = LateOut{LATE_F_GP, 1, (uint32_t)(3 * hm + 2)};
+      lt.ipa.push_back(a);
+      lt.ipa_comp.push_back(meta.size());
+      for (size_t p = 0; p < B; p++)
+        for (int s : {sm.LC(j), sm.LD(j), sm.RC(j), sm.RD(j)}) meta.push_back(cidx(p, s));
+      // same_multiscalar_argument.rs:104-112: L_A, L_T, L_U = <x_L, {G_b, T_b, U_b}_R>, R_* = <x_R, {..}_L>
+      a.nout = 6;
+      a.total = (int)(6 * B) * a.slices;
+      a.scal_proof_stride = (uint32_t)(2 * hm);
+      const int fam[3] = {LATE_F_GB, LATE_F_T, LATE_F_U};
+      for (int q = 0; q < 3; q++) {
+        a.o[q] = LateOut{fam[q], 1, 0u};
+        a.o[3 + q] = LateOut{fam[q], 0, (uint32_t)hm};
+      }
+      lt.smsm.push_back(a);
+      lt.smsm_comp.push_back(meta.size());
+      for (size_t p = 0; p < B; p++)
+        for (int s : {sm.LA(j), sm.LT(j), sm.LU(j), sm.RA(j), sm.RT(j), sm.RU(j)}) meta.push_back(cidx(p, s));
+    }
+    lt.meta.ensure(meta.size());
+    CPX_HIP(hipMemcpy(lt.meta.p, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   // -- side stream: R = a x vec_R, S = a x vec_S (curdleproofs.rs:112-113) and the four T_2 = s * {R, S} + r * H
   //    scalar multiplications (curdleproofs.rs:115-116, same_scalar_argument.rs:60-61)
   {
@@ -362,8 +455,11 @@ void Engine::prepare_device_prover() {
     upd(dp.p1);
     upd(dp.p2);
     upd(dp.p3);
-    for (auto& pl : dp.ipa) upd(*pl);
-    for (auto& pl : dp.smsm) upd(*pl);
+    for (auto& pl : dp.ipa)
+      if (pl) upd(*pl);
+    for (auto& pl : dp.smsm)
+      if (pl) upd(*pl);
+    if (lt.on) max_parts = std::max(max_parts, 6 * B);
     d_tpart_.ensure(max_parts);
     ensure_raw_sets(max_sets);
     d_tbltmp_.ensure(B * NP * (size_t)(copies_ / 2 - 1));
@@ -416,9 +512,29 @@ void Engine::enqueue_prove_device() {
   launch_ps_gprod(d, Bi, stream_);
   exec_plan(dp.p3, dp.slotcomp.p);
   launch_ps_ipa_setup(d, Bi, stream_);
-  // -- IPA rounds (inner_product_argument.rs:150-186 in all-MSM form)
+  // -- IPA rounds (inner_product_argument.rs:150-186 in all-MSM form; the last four of a large batch on materialised folded
+  //    bases: late.hip)
+  const DevProver::Late& lt = dp.late;
+  const size_t BM = B * (size_t)lt.m;
   for (size_t j = 0; j < L; j++) {
     const int half = (int)(n >> (j + 1));
+    if (lt.on && j == lt.j0) {   // G^(j0) and G'^(j0) from the table of multiples (fold coefficients S_G, S_G' = u o S^-1), their small multiples
+      tick("k_late_fix", 128.0 * 2 * n * B, (double)(2 * n * B));
+      launch_late_fix(d_rvec_.p + 2 * n, 4 * n, nullptr, (int)n, lt.m, fixtab(), fix_bits_, (int)nc(), lt.jac.p + LATE_F_G * BM, (size_t)lt.m, Bi, stream_);
+      tock();
+      launch_late_fix(d_rvec_.p + 3 * n, 4 * n, nullptr, (int)n, lt.m, fixtab(), fix_bits_, (int)nc(), lt.jac.p + LATE_F_GP * BM, (size_t)lt.m, Bi, stream_);
+      tick("k_late_tables", 0, (double)(2 * BM));
+      launch_late_tables(lt.jac.p + LATE_F_G * BM, lt.tab.p + LATE_F_G * BM * late_tab_entries(), d_tbltmp_.p, (int)(2 * BM), stream_);
+      tock();
+      launch_late_restart(d_rvec_.p, (int)n, lt.m, Bi, stream_);
+    }
+    if (lt.on && j >= lt.j0) {
+      launch_ipa_round_scalars(d_rvec_.p, Bi, (int)n, half, d_rbeta_.p, d_rout_.p, stream_, lt.m);
+      exec_late_round(lt.ipa[j - lt.j0], lt.ipa_comp[j - lt.j0], "k_late_msm");
+      launch_ps_ipa_round(d, Bi, (int)j, stream_);
+      launch_ipa_round_fold(d_rvec_.p, Bi, (int)n, half, d_rgam_.p, stream_, lt.m);
+      continue;
+    }
     launch_ipa_round_scalars(d_rvec_.p, Bi, (int)n, half, d_rbeta_.p, d_rout_.p, stream_);
     exec_plan(*dp.ipa[j], dp.slotcomp.p);
     launch_ps_ipa_round(d, Bi, (int)j, stream_);
@@ -429,6 +545,22 @@ void Engine::enqueue_prove_device() {
   launch_ps_smsm_setup(d, Bi, stream_);
   for (size_t j = 0; j < L; j++) {
     const int half = (int)(n >> (j + 1));
+    if (lt.on && j == lt.j0) {   // T_b^(j0), U_b^(j0), G_b^(j0): one shared digit sequence per proof (fold coefficients S_M)
+      tick("k_late_uniform", 128.0 * 3 * n * B, (double)(3 * n * B));
+      launch_late_uniform(dp.rvec2.p + n, 2 * n, d_ptab_.p, (size_t)copies_ * NP, (int)NP, ctab(), (int)nc(), lt.gb_cols, (int)n, lt.m, 3, lt.jac.p + LATE_F_T * BM, BM, Bi,
+                          stream_);
+      tock();
+      tick("k_late_tables", 0, (double)(3 * BM));
+      launch_late_tables(lt.jac.p + LATE_F_T * BM, lt.tab.p + LATE_F_T * BM * late_tab_entries(), d_tbltmp_.p, (int)(3 * BM), stream_);
+      tock();
+    }
+    if (lt.on && j >= lt.j0) {
+      launch_smsm_round_scalars(dp.rvec2.p, Bi, (int)n, half, d_rout_.p, stream_, lt.m);
+      exec_late_round(lt.smsm[j - lt.j0], lt.smsm_comp[j - lt.j0], "k_late_msm");
+      launch_ps_smsm_round(d, Bi, (int)j, stream_);
+      launch_smsm_round_fold(dp.rvec2.p, Bi, (int)n, half, d_rgam_.p, stream_, lt.m);
+      continue;
+    }
     launch_smsm_round_scalars(dp.rvec2.p, Bi, (int)n, half, d_rout_.p, stream_);
     exec_plan(*dp.smsm[j], dp.slotcomp.p);
     launch_ps_smsm_round(d, Bi, (int)j, stream_);

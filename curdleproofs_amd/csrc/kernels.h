@@ -32,6 +32,9 @@ struct Options {
   long inline_below = 16;          // host loops shorter than this run inline
   long cu_mask = 1;                // 0: plain instead of CU-masked streams for the lone-proof prover
   long trace = 0;                  // 1: print the challenges of proof 0 to stderr (debugging aid)
+  long late_rounds = 4;            // 4: the last four log rounds of a large batch run on materialised folded bases (late.hip); 0: all-MSM everywhere
+  long late_min_batch = 1024;      // ... for batches of at least this many proofs (the lane-per-output kernels need a full GPU to pay)
+  long late_slices = 8;            // lanes per cross term of a late round (1, 2, 4, 8): 15.3 k proofs/s at 8, 14.9 k at 4 and 2, 14.3 k at 1
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
 };
 const Options& default_options();                               // built-in defaults overridden by CPX_<NAME> environment variables
@@ -42,6 +45,7 @@ bool get_option(const Options& o, const char* key, long* value);
 // (nullptr, nullptr = plain launches).
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 int launches_since_set();
+void take_launch_events(hipEvent_t* start, hipEvent_t* stop);   // for launchers outside kernels.hip (late.hip): the pending events, counted as a launch
 
 // One multi-scalar multiplication  sum_i scalars[i] * bases[idx ? idx[i] : i],  i < n.
 // All pointers are device pointers.  Scalars are Fr in Montgomery form unless flagged canonical.
@@ -170,13 +174,45 @@ void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out,
 // Fr algebra of the prover's log rounds on device-resident vectors (kernels.hip: "Fr algebra of the log rounds"):
 // IPA vec [nproofs][4][n] = c | d | SG | SGp, out [nproofs][4 (n/2) + 2]; SameMSM vec [nproofs][2][n] = x | SM, out [nproofs][n];
 // gam [nproofs][2] = gamma, gamma^-1
-void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s);
-void launch_ipa_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s);
-void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr* d_out, hipStream_t s);
-void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s);
+// active (0 = n): the leading elements the round still works on — m for the late rounds on materialised bases (late.hip), which
+// restart with unit fold coefficients inside the first m entries; the output rows then hold 4 (active/2) + 2 resp. active scalars
+void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s, int active = 0);
+void launch_ipa_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s, int active = 0);
+void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr* d_out, hipStream_t s, int active = 0);
+void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s, int active = 0);
 // transcript prefix of every proof: absorbs the compressed instance ([nproofs][4*ell*48] + [nproofs][48] for M), draws vec_a;
 // d_state: [nproofs][27] u64 (25 STROBE lanes, pos, pos_begin), d_vec_a: [nproofs][ell] Fr
 void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s);
+// ---- late log rounds of the batch prover on materialised folded bases (late.hip) ----
+// Families of materialised points, per proof [LATE_FAMILIES][m]: G, G' = u o G (IPA), G_b, T_b, U_b (SameMSM)
+enum { LATE_F_G = 0, LATE_F_GP, LATE_F_T, LATE_F_U, LATE_F_GB, LATE_FAMILIES };   // layout [family][proof][m]
+struct LateOut {
+  int fam, hi;              // family; 1: the points whose index has bit `half` set, 0: clear
+  uint32_t scal_off;        // the output's m/2 scalars inside the proof's scalar row
+};
+struct LateRound {
+  int m, half, nout, total;           // total = nproofs * nout * slices lanes
+  int nproofs, slices;                // slices (1, 2, 4, 8): lanes per output, each taking 32 / slices of the 4-bit windows
+  LateOut o[6];
+  const Fr* scal;                     // [nproofs][scal_proof_stride]
+  uint32_t scal_proof_stride;
+  const TAff* tab;                    // [LATE_FAMILIES][nproofs][m][late_tab_entries()]
+  TJac* out;                          // [total]: partial sums, slice j of an output carries the weight 2^(128 / slices * j)
+};
+size_t late_tab_entries();            // table entries per materialised point (8 multiples + their 8 endomorphism images)
+size_t late_tmp_per_lane();           // TblTmp scratch entries per point of launch_late_tables (rounded up to 64 points)
+bool late_supported(int n, int m);
+// out[p * ostride + i] = sum_t scal[p * sstride + t m + i] * CRS column (cols ? cols[t m + i] : t m + i),  i < m
+void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, int n, int m, const TFix* d_fix_tab, int cbits, int nc, TJac* d_out, size_t ostride,
+                     int nproofs, hipStream_t s);
+// out[f * fstride + p * m + i] = sum_t sm[p * sstride + t m] * F_(t m + i) for the families f < nfam: T_b, U_b (per-proof 32-copy tables,
+// row M | T_b | U_b, NP columns) and G_b (CRS copies d_ctab, nc columns, column map d_gb_cols)
+void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, size_t ptab_proof_stride, int NP, const TAff* d_ctab, int nc, const uint32_t* d_gb_cols, int n,
+                         int m, int nfam, TJac* d_out, size_t fstride, int nproofs, hipStream_t s);
+void launch_late_tables(const TJac* d_jac, TAff* d_tab, TblTmp* d_tmp, int npoints, hipStream_t s);
+void launch_late_msm(const LateRound& r, hipStream_t s);
+void launch_late_restart(Fr* d_vec, int n, int m, int nproofs, hipStream_t s);
+
 void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s);
 void launch_bench_fpmul(Fp* d_data, int blocks, int iters, hipStream_t s);
 void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s);

@@ -39,6 +39,7 @@
 #include "recode.hpp"
 #include "glv.hpp"
 #include "kernels.h"
+#include "block_inverse.hpp"
 
 namespace cpx {
 
@@ -51,82 +52,6 @@ __device__ __forceinline__ void aff_compress_store(const Aff& a, uint8_t* out) {
   o[0] = make_uint4(w[0], w[1], w[2], w[3]);
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
   o[2] = make_uint4(w[8], w[9], w[10], w[11]);
-}
-
-// ------------------------------------------------------------------ inversion on device
-// One inversion per work-group by batched division steps (modinv30.hpp): ~0.05 ms of single-wave latency instead of
-// the ~0.25 ms of the binary Euclidean algorithm or the ~0.55 ms of Fermat's a^(p-2) (571 dependent products);
-// callers amortise it over a whole work-group (batch inversion below).
-__device__ __noinline__ Fp fp_inv_device(const Fp& a) { return fe_inv_divsteps(a); }
-
-// In-work-group batch inversion.  Every thread passes its z (any value; zero is treated as 1 and
-// returns an unspecified value the caller must ignore).  `buf` holds 2 * blockDim.x Fp values.
-// Inclusive Hillis-Steele product scans from both ends, one inversion by wave 0.
-__device__ __forceinline__ Fp block_batch_inverse(Fp z, Fp* buf) {
-  const int tid = threadIdx.x, n = blockDim.x;
-  if (z.is_zero()) z = Fp::one();
-  Fp* pre = buf;        // inclusive prefix products
-  Fp* suf = buf + n;    // inclusive suffix products
-  Fp p = z, s = z;
-  pre[tid] = p;
-  suf[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < n; off <<= 1) {
-    Fp pl, sr;
-    const bool hp = tid >= off, hs = tid + off < n;
-    if (hp) pl = pre[tid - off];
-    if (hs) sr = suf[tid + off];
-    __syncthreads();
-    if (hp) p = fe_mul(p, pl);
-    if (hs) s = fe_mul(s, sr);
-    pre[tid] = p;
-    suf[tid] = s;
-    __syncthreads();
-  }
-  // z_i^-1 = total^-1 * pre[i-1] * suf[i+1]
-  const Fp left = (tid > 0) ? pre[tid - 1] : Fp::one();
-  const Fp right = (tid + 1 < n) ? suf[tid + 1] : Fp::one();
-  Fp tinv = Fp::one();
-  if (tid < 64) tinv = fp_inv_device(pre[n - 1]);   // one wave; its lanes compute it redundantly
-  __syncthreads();                                  // all reads of pre/suf are done
-  if (tid == 0) pre[0] = tinv;
-  __syncthreads();
-  tinv = pre[0];
-  return fe_mul(fe_mul(tinv, left), right);
-}
-
-// The same on the table form (fp28.hpp): 28-bit-limb lazy values.
-__device__ __noinline__ TF t_inv_device(const TF& a) { return t_inv(a); }
-__device__ __forceinline__ TF t_block_batch_inverse(TF z, TF* buf) {
-  const int tid = threadIdx.x, n = blockDim.x;
-  if (t_is_zero_raw(z)) z = t_one();
-  TF* pre = buf;
-  TF* suf = buf + n;
-  TF p = z, s = z;
-  pre[tid] = p;
-  suf[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < n; off <<= 1) {
-    TF pl, sr;
-    const bool hp = tid >= off, hs = tid + off < n;
-    if (hp) pl = pre[tid - off];
-    if (hs) sr = suf[tid + off];
-    __syncthreads();
-    if (hp) p = t_mul(p, pl);
-    if (hs) s = t_mul(s, sr);
-    pre[tid] = p;
-    suf[tid] = s;
-    __syncthreads();
-  }
-  const TF left = (tid > 0) ? pre[tid - 1] : t_one();
-  const TF right = (tid + 1 < n) ? suf[tid + 1] : t_one();
-  TF tinv = t_one();
-  if (tid < 64) tinv = t_inv_device(pre[n - 1]);
-  __syncthreads();
-  if (tid == 0) pre[0] = tinv;
-  __syncthreads();
-  tinv = pre[0];
-  return t_mul(t_mul(tinv, left), right);
 }
 
 // ------------------------------------------------------------------ MSM over arbitrary bases: bucket accumulation
@@ -1260,13 +1185,15 @@ __global__ __launch_bounds__(64) void k_sum_jac(const Jac* __restrict__ in, int 
 //
 // IPA (inner_product_argument.rs:150-186 in all-MSM form).  vec: [B][4][n] = c | d | SG | SGp.
 // out per proof: [ L_C scalars (n/2), beta<c_L,d_R> | L_D (n/2) | R_C (n/2), beta<c_R,d_L> | R_D (n/2) ]
-__global__ __launch_bounds__(128) void k_ipa_round_scalars(const Fr* __restrict__ vec, int n, int half, const Fr* __restrict__ beta, Fr* __restrict__ out) {
+// (n = the elements the round still works on: the full length, or m for the late rounds on materialised bases (late.hip), which
+// restart the fold coefficients at 1 inside the first m entries; stride = the allocated length of every sub-vector)
+__global__ __launch_bounds__(128) void k_ipa_round_scalars(const Fr* __restrict__ vec, int stride, int n, int half, const Fr* __restrict__ beta, Fr* __restrict__ out) {
   __shared__ Fr red[2][128];
   const int p = blockIdx.x, hn = n / 2;
-  const Fr* c = vec + (size_t)p * 4 * n;
-  const Fr* d = c + n;
-  const Fr* SG = d + n;
-  const Fr* SGp = SG + n;
+  const Fr* c = vec + (size_t)p * 4 * stride;
+  const Fr* d = c + stride;
+  const Fr* SG = d + stride;
+  const Fr* SGp = SG + stride;
   Fr* o = out + (size_t)p * (4 * hn + 2);
   Fr ip1 = Fr::zero(), ip2 = Fr::zero();
   for (int t = threadIdx.x; t < hn; t += blockDim.x) {
@@ -1297,12 +1224,12 @@ __global__ __launch_bounds__(128) void k_ipa_round_scalars(const Fr* __restrict_
   }
 }
 // gam: [B][2] = gamma, gamma^-1.  c_L += gamma^-1 c_R, d_L += gamma d_R, SG[hi] *= gamma, SGp[hi] *= gamma^-1
-__global__ __launch_bounds__(128) void k_ipa_round_fold(Fr* __restrict__ vec, int n, int half, const Fr* __restrict__ gam) {
+__global__ __launch_bounds__(128) void k_ipa_round_fold(Fr* __restrict__ vec, int stride, int n, int half, const Fr* __restrict__ gam) {
   const int p = blockIdx.x, hn = n / 2;
-  Fr* c = vec + (size_t)p * 4 * n;
-  Fr* d = c + n;
-  Fr* SG = d + n;
-  Fr* SGp = SG + n;
+  Fr* c = vec + (size_t)p * 4 * stride;
+  Fr* d = c + stride;
+  Fr* SG = d + stride;
+  Fr* SGp = SG + stride;
   const Fr g = gam[2 * p], gi = gam[2 * p + 1];
   for (int i = threadIdx.x; i < half; i += blockDim.x) {
     c[i] = fe_add(c[i], fe_mul(gi, c[half + i]));
@@ -1316,10 +1243,10 @@ __global__ __launch_bounds__(128) void k_ipa_round_fold(Fr* __restrict__ vec, in
 }
 // SameMSM (same_multiscalar_argument.rs:99-136 in all-MSM form).  vec: [B][2][n] = x | SM.
 // out per proof: [ L_* scalars (n/2) | R_* scalars (n/2) ]
-__global__ __launch_bounds__(128) void k_smsm_round_scalars(const Fr* __restrict__ vec, int n, int half, Fr* __restrict__ out) {
+__global__ __launch_bounds__(128) void k_smsm_round_scalars(const Fr* __restrict__ vec, int stride, int n, int half, Fr* __restrict__ out) {
   const int p = blockIdx.x, hn = n / 2;
-  const Fr* x = vec + (size_t)p * 2 * n;
-  const Fr* SM = x + n;
+  const Fr* x = vec + (size_t)p * 2 * stride;
+  const Fr* SM = x + stride;
   Fr* o = out + (size_t)p * 2 * hn;
   for (int t = threadIdx.x; t < hn; t += blockDim.x) {
     const int kl = (t / half) * 2 * half + (t % half), kh = kl + half;
@@ -1328,10 +1255,10 @@ __global__ __launch_bounds__(128) void k_smsm_round_scalars(const Fr* __restrict
   }
 }
 // gam: [B][2] = gamma, gamma^-1.  x_L += gamma^-1 x_R, SM[hi] *= gamma
-__global__ __launch_bounds__(128) void k_smsm_round_fold(Fr* __restrict__ vec, int n, int half, const Fr* __restrict__ gam) {
+__global__ __launch_bounds__(128) void k_smsm_round_fold(Fr* __restrict__ vec, int stride, int n, int half, const Fr* __restrict__ gam) {
   const int p = blockIdx.x, hn = n / 2;
-  Fr* x = vec + (size_t)p * 2 * n;
-  Fr* SM = x + n;
+  Fr* x = vec + (size_t)p * 2 * stride;
+  Fr* SM = x + stride;
   const Fr g = gam[2 * p], gi = gam[2 * p + 1];
   for (int i = threadIdx.x; i < half; i += blockDim.x) x[i] = fe_add(x[i], fe_mul(gi, x[half + i]));
   for (int t = threadIdx.x; t < hn; t += blockDim.x) {
@@ -1460,12 +1387,16 @@ const OptField kOptFields[] = {
     {"spin_team_threads", &Options::spin_team_threads, 1, 256},  {"inline_below", &Options::inline_below, 0, 1L << 30},
     {"cu_mask", &Options::cu_mask, 0, 1},                        {"trace", &Options::trace, 0, 1},
     {"bench_field", &Options::bench_field, 12, 28},
+    {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
+    {"late_slices", &Options::late_slices, 1, 8},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;
   if (!strcmp(f.key, "tbw_wpw")) return v == 0 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32;
   if (!strcmp(f.key, "tbw_slices")) return v == 0 || v == 1 || v == 2 || v == 4;
   if (!strcmp(f.key, "fix_bits")) return v == 8 || v == 16;
+  if (!strcmp(f.key, "late_rounds")) return v == 0 || v == 4;
+  if (!strcmp(f.key, "late_slices")) return v == 1 || v == 2 || v == 4 || v == 8;
   return true;
 }
 }  // namespace
@@ -1508,6 +1439,11 @@ void set_launch_events(hipEvent_t start, hipEvent_t stop) {
   tl_launches = 0;
 }
 int launches_since_set() { return tl_launches; }
+void take_launch_events(hipEvent_t* start, hipEvent_t* stop) {
+  tl_launches++;
+  *start = tl_ev_start;
+  *stop = tl_ev_stop;
+}
 #define CPX_LAUNCH(kern, grid, block, lds, stream, ...)                                                   \
   do {                                                                                                    \
     tl_launches++;                                                                                        \
@@ -1708,17 +1644,17 @@ void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out,
   }
   CPX_LAUNCH(k_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in, n, d_out, d_dst_index, d_status, check_subgroup, d_src_offset);
 }
-void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s) {
-  if (nproofs > 0) CPX_LAUNCH(k_ipa_round_scalars, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_beta, d_out);
+void launch_ipa_round_scalars(const Fr* d_vec, int nproofs, int n, int half, const Fr* d_beta, Fr* d_out, hipStream_t s, int active) {
+  if (nproofs > 0) CPX_LAUNCH(k_ipa_round_scalars, dim3(nproofs), dim3(128), 0, s, d_vec, n, active > 0 ? active : n, half, d_beta, d_out);
 }
-void launch_ipa_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s) {
-  if (nproofs > 0) CPX_LAUNCH(k_ipa_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_gam);
+void launch_ipa_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s, int active) {
+  if (nproofs > 0) CPX_LAUNCH(k_ipa_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, active > 0 ? active : n, half, d_gam);
 }
-void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr* d_out, hipStream_t s) {
-  if (nproofs > 0) CPX_LAUNCH(k_smsm_round_scalars, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_out);
+void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr* d_out, hipStream_t s, int active) {
+  if (nproofs > 0) CPX_LAUNCH(k_smsm_round_scalars, dim3(nproofs), dim3(128), 0, s, d_vec, n, active > 0 ? active : n, half, d_out);
 }
-void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s) {
-  if (nproofs > 0) CPX_LAUNCH(k_smsm_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, half, d_gam);
+void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s, int active) {
+  if (nproofs > 0) CPX_LAUNCH(k_smsm_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, active > 0 ? active : n, half, d_gam);
 }
 void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s) {
   if (nproofs <= 0) return;

@@ -533,6 +533,13 @@ VARIANTS = {
     "four_point_slices_host_driven": {"tbw_slices": 4, "device_min_batch": 1000000},
     "two_point_slices_thread_tail": {"tbw_slices": 2, "tail_wave_max": 0},
     "plain_streams_wave_kernels_everywhere": {"cu_mask": 0, "reduce_wave_max": 1000000, "finalize_wave_max": 1000000},
+    # the last four log rounds on materialised folded bases (late.hip: k_late_fix, k_late_uniform, k_late_tables, k_late_msm), which only
+    # batches of >= late_min_batch proofs take by default, forced onto single proofs and small batches; and switched off
+    "late_rounds_on_small_batches": {"late_min_batch": 1, "device_min_batch": 1},
+    "late_rounds_on_small_batches_fix8": {"late_min_batch": 1, "device_min_batch": 1, "fix_bits": 8},
+    "late_rounds_one_lane_per_output": {"late_min_batch": 1, "device_min_batch": 1, "late_slices": 1},
+    "late_rounds_eight_lanes_per_output": {"late_min_batch": 1, "device_min_batch": 1, "late_slices": 8, "tail_wave_max": 0},
+    "late_rounds_off": {"late_rounds": 0, "device_min_batch": 1},
 }
 
 
@@ -560,6 +567,20 @@ def test_engine_variants_stay_bit_exact(name, orc, whisk_kat, oracle_vectors):
         for k, v in VARIANTS[name].items():
             assert c.get_option(k) == v
         _variant_checks(c, orc, whisk_kat, oracle_vectors)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("ell,seeds", [(28, [0, 1, 2]), (60, [0, 1]), (1020, [0])])
+def test_late_rounds_on_materialised_bases_other_sizes(orc, oracle_vectors, ell, seeds):
+    """late.hip at the sizes the variant checks do not reach: ell = 28 (n = 32: two points per materialised base, first late round
+    = round 1), ell = 60, ell = 1020 (64 points per materialised base, 2048-entry digit lists).  Bytes == oracle."""
+    import curdleproofs_amd as cpx
+    c = cpx.Context(0, options={"late_min_batch": 1, "device_min_batch": 1})
+    try:
+        crs, insts, proofs = _prove_and_check(c, orc, ell, seeds)
+        if str(ell) in oracle_vectors:
+            assert hashlib.sha256(proofs[0]).hexdigest() == oracle_vectors[str(ell)]["proof_sha256"]
     finally:
         c.close()
 

@@ -441,11 +441,14 @@ def main():
         avg_ms = st["ms"] / max(st["launches"], 1)
         bytes_per_launch = st["alg_bytes"] / max(st["launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs)
             import glob
             with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.json")))[-1]) as f:   # the newest round's PMC passes
                 hc = json.load(f).get("cpx::" + dom)   # per instantiation, as rocprofv3 names it
+            traffic_src = ("not measured in this run: HBM bytes per launch from the committed rocprofv3 PMC passes %s (separate FETCH_SIZE / WRITE_SIZE runs of "
+                           "scripts/collect_profiles.sh at commit %s)" % (os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.json")))[-1]),
+                                                                           hc.get("commit", "?") if hc else "?"))
             if hc and hc["batch_per_gpu"] == B and hc.get("engine_contexts_per_gpu", 1) == K:
                 # counters are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)
                 traffic = (2.0 * hc["FETCH_SIZE"]["total"] / hc["FETCH_SIZE"]["dispatches"]
@@ -453,7 +456,7 @@ def main():
         except Exception:
             traffic = None
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=traffic, avg_launch_ms=avg_ms, launches=st["launches"], alg_bytes_per_launch=bytes_per_launch,
+                        traffic=traffic, traffic_source=traffic_src, avg_launch_ms=avg_ms, launches=st["launches"], alg_bytes_per_launch=bytes_per_launch,
                         units_per_launch=st["units"] / max(st["launches"], 1),
                         # every launch of this process (warm-up + timed region + the isolated pass): the population
                         # `rocprofv3 --kernel-trace --stats` averages over when it wraps this command
@@ -502,6 +505,42 @@ def main():
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
                    vs_readme_i7_8550u=value / README_I7_PROOFS_PER_S, roofline=roofline)
+        # BASELINE configs[4] (the batched verifier) on this GPU, driver-visible: context 0 still holds its share of the timed batch
+        # (4096 proofs at the default shape) and the proofs of the last pass; ONE accumulated check over all of them, verdict included
+        # (cpx_batch_verify_fused + cpx_g1_sum_jac; with N GPUs the 144-byte partial sums are all-gathered first: --fused-verify)
+        if world == 1 and not args.no_extra_shapes:
+            from curdleproofs_amd import params as pr_
+            c0 = ctxs[0]
+            nb5 = B // K
+            frand = c0.marshal(pr_.random_fr_wire(random.Random(55), 12 * nb5))
+            def fused_once():
+                part, bad = c0.verify_batch_fused_partial(proofs[0], frand)
+                return bad == 0 and c0.sum_jac(part)[1]
+            ok5 = fused_once()   # warm-up (plans, buffers)
+            c0.set_profiling(True)
+            c0.reset_stats()
+            reps5 = 0
+            t0 = time.perf_counter()
+            while reps5 < 3 or (time.perf_counter() - t0 < 1.0 and reps5 < 20):
+                ok5 = fused_once() and ok5
+                reps5 += 1
+            dt5 = time.perf_counter() - t0
+            st5 = c0.stat("k_msm_tblw<2, true>")
+            c0.set_profiling(False)
+            bad_proofs = bytearray(bytes(proofs[0]))
+            bad_proofs[48:96], bad_proofs[0:48] = bad_proofs[0:48], bad_proofs[48:96]      # proof 0 with two points swapped: the batch must be refused
+            part_bad, nbad_bad = c0.verify_batch_fused_partial(bytes(bad_proofs), frand)
+            rejects = not (nbad_bad == 0 and c0.sum_jac(part_bad)[1])
+            npts5 = nb5 * (4 * ell + 6 + 18 + 10 * L)
+            mm5 = st5["units"] * 32 * 255.0 / 256 * PROD_PER_ADD / (st5["ms"] * 1e-3) if st5["ms"] else 0.0
+            out["config5"] = dict(metric="shuffle proofs/sec checked by the batched verifier (BASELINE configs[4]) at ell=%d" % ell, value=nb5 * reps5 / dt5, unit="proofs/s",
+                                  proofs_per_check=nb5, ms_per_check=1e3 * dt5 / reps5, checks=reps5, all_verified=bool(ok5), rejects_a_batch_with_one_wrong_proof=bool(rejects),
+                                  points_in_the_accumulated_msm=npts5 + ell + 4, algorithmic_bytes_per_check=128.0 * (npts5 + ell + 4),
+                                  kernel="k_msm_tblw<2, true>", kernel_ms_per_check=st5["ms"] / max(reps5, 1),
+                                  valu=dict(achieved=mm5, peak=peak_mm, frac=mm5 / peak_mm if peak_mm else None, unit="381-bit modular products/s"),
+                                  hbm=dict(achieved=128.0 * st5["units"] / (st5["ms"] * 1e-3) / 1e9 if st5["ms"] else None, peak=HBM_PEAK_GBS, unit="GB/s"),
+                                  note="one engine context alone on the GPU, proofs and instances resident in HBM, 12 random factors per proof uploaded per check; "
+                                       "the oracle has no batched verifier: cpu_verify_per_proof is its per-proof verifier")
         # BASELINE configs[1]: the same instance shape as ONE proof (latency, not throughput): instance 0 alone on context 0
         AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
         c0, n_ = ctxs[0], ell + 4
@@ -541,7 +580,7 @@ def main():
                                                "(the per-GPU share on 8 GPUs) and 1024 proofs on one GPU" % ell, **shapes)
             if ell == 252:   # BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
                 try:
-                    e3, b3 = 1020, 256
+                    e3, b3 = 1020, 1024   # enough proofs to fill the GPU (256 proofs per pass under-reported the path: 1.6 k against 2.5+ k proofs/s)
                     d3 = synth_batch(c0, e3, b3, seed=4321)
                     c0.load_batch(d3["vec_R"], d3["vec_S"], d3["vec_T"], d3["vec_U"], d3["M"])
                     a3 = [c0.marshal(d3[k_]) for k_ in ("perms", "k", "mbl", "prand", "vrand")]
@@ -559,6 +598,10 @@ def main():
                     out["ell_1020"] = dict(value=None, error=repr(e))
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ell, data, bytes(proofs[0])[:psz_bench])
+            if "config5" in out:
+                vs = out["cpu_baseline"]["verify_s"]
+                out["config5"]["cpu_verify_per_proof"] = dict(value=1.0 / vs, unit="proofs/s", cores=1, kind="port",
+                                                              sample="CurdleproofsProof::verify of instance 0, oracle/ single thread, %.4f s each" % vs)
             if not args.no_extra_shapes:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ell, data)
         else:

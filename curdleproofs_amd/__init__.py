@@ -51,7 +51,7 @@ _lib = None
 
 EXPORTS = [
     "cpx_host_alloc", "cpx_host_free", "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_option", "cpx_ctx_get_option", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size", "cpx_batch_size",
-    "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress",
+    "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress", "cpx_g1_decompress_status",
     "cpx_accum_new", "cpx_accum_free", "cpx_accum_check", "cpx_accum_verify",
     "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify", "cpx_batch_verify_fused", "cpx_g1_sum_jac",
     "cpx_whisk_generate_shuffle_proof", "cpx_whisk_is_valid_shuffle_proof", "cpx_whisk_generate_tracker_proof", "cpx_whisk_is_valid_tracker_proof",
@@ -94,6 +94,7 @@ def load_library():
     L.cpx_g1_scale.argtypes = [vp, vp, vp, sz, sz, vp]
     L.cpx_g1_normalize.argtypes = [vp, vp, sz, vp, vp]
     L.cpx_g1_decompress.argtypes = [vp, vp, sz, vp, ci]
+    L.cpx_g1_decompress_status.argtypes = [vp, vp, sz, vp, ci, vp]
     L.cpx_accum_new.argtypes = [vp, ctypes.POINTER(vp)]
     L.cpx_accum_free.argtypes = [vp]
     L.cpx_accum_free.restype = None
@@ -270,6 +271,13 @@ class Context:
         o = _out(AFF * n)
         self._check(self._L.cpx_g1_decompress(self._h, _in(comp), n, o, 1 if check_subgroup else 0))
         return bytes(o)[: AFF * n]
+
+    def decompress_status(self, comp, check_subgroup=True):
+        """per-point form: (affine points, list of status bytes: 0 ok, 1 malformed / not on the curve, 2 not in the subgroup)"""
+        n = len(comp) // 48
+        o, st = _out(AFF * n), _out(n)
+        self._check(self._L.cpx_g1_decompress_status(self._h, _in(comp), n, o, 1 if check_subgroup else 0, st))
+        return bytes(o)[: AFF * n], list(bytes(st)[:n])
 
     # ---- tier 2 ----
     def load_batch(self, vec_R, vec_S, vec_T, vec_U, M):

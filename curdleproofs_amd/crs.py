@@ -63,3 +63,50 @@ def crs_to_json(ctx):
 
 def crs_from_json(ctx, text):
     return crs_from_hex(ctx, json.loads(text))
+
+
+# ---- hash-to-curve CRS: /root/reference/tests/crs.rs:13-52 `generate_random_points` -------------------------------------
+COFACTOR = 0x396c8c005555e1568c00aaab0000aaab   # |E(Fp)| / r: `mul_by_cofactor` multiplies by the full cofactor (not h_eff)
+CRS_EXTRA_POINTS = 3                             # crs.rs: H, G_t, G_u
+
+
+def generate_random_points(ctx, num_points, seed):
+    """Try-and-increment hash to the curve, as the reference's CRS ceremony test does it: for increment = 0, 1, ...
+    hash = SHA-256(seed || be64(increment)); x = the integer whose 64-bit limbs 0..3 are the big-endian words of the hash
+    (`BigInteger384::new([u64; 6])`, limbs 4 and 5 zero); if x^3 + 4 is a square keep `get_point_from_x_unchecked(x, false)` (the
+    smaller y) times the cofactor, provided it lies in the subgroup.  Returns (num_points affine points of 96 bytes, increments
+    consumed).  The hashing is host work (hashlib); square roots, cofactor multiplication and the subgroup test run on the
+    GPU in batches of candidates through the C-ABI: cpx_g1_decompress_status, cpx_g1_scale, cpx_g1_normalize."""
+    import hashlib
+    seed = seed.encode() if isinstance(seed, str) else bytes(seed)
+    h_wire = whisk.pr.fr_to_wire(COFACTOR)          # the cofactor as a scalar (< r): cpx_g1_scale's plain double-and-add holds on all of E(Fp)
+    points, increment = [], 0
+    while len(points) < num_points:
+        batch = max(16, 2 * (num_points - len(points)) + 8)      # about half of the candidates have a square root
+        cands = []
+        for inc in range(increment, increment + batch):
+            hsh = hashlib.sha256(seed + inc.to_bytes(8, "big")).digest()
+            x = sum(int.from_bytes(hsh[8 * i:8 * i + 8], "big") << (64 * i) for i in range(4))
+            cands.append(bytes([0x80 | (x >> 376)]) + (x & ((1 << 376) - 1)).to_bytes(47, "big"))   # compressed, sort flag clear = smaller y
+        aff, status = ctx.decompress_status(b"".join(cands), check_subgroup=False)
+        hits = [j for j in range(batch) if status[j] == 0]
+        scaled = ctx.scale(b"".join(aff[AFF * j:AFF * (j + 1)] for j in hits), h_wire) if hits else b""
+        one = whisk.pr.fp_to_wire(1)
+        jac = b"".join(scaled[AFF * t:AFF * (t + 1)] + (bytes(48) if scaled[AFF * t:AFF * (t + 1)] == bytes(AFF) else one) for t in range(len(hits)))
+        comp = ctx.normalize(jac, compressed=True)[1] if hits else b""
+        in_group = ctx.decompress_status(comp, check_subgroup=True)[1] if hits else []   # is_in_correct_subgroup_assuming_on_curve
+        for t, j in enumerate(hits):
+            if in_group[t] == 0:
+                points.append(scaled[AFF * t:AFF * (t + 1)])
+                if len(points) == num_points:
+                    return b"".join(points), increment + j + 1
+        increment += batch
+    return b"".join(points), increment
+
+
+def crs_from_seed(ctx, ell, seed):
+    """tests/crs.rs:54-66: `CurdleproofsCrs::from_points(ell, generate_random_points(n + CRS_EXTRA_POINTS, seed))` loaded into ctx;
+    returns the number of hash attempts"""
+    pts, attempts = generate_random_points(ctx, ell + N_BLINDERS + CRS_EXTRA_POINTS, seed)
+    ctx.set_crs(ell, pts)
+    return attempts

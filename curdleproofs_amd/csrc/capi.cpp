@@ -172,6 +172,11 @@ int cpx_g1_decompress(cpx_ctx* ctx, const uint8_t* compressed, size_t n, uint8_t
   return guarded(ctx, [&] { return ctx->eng->decompress(compressed, n, out_affine, check_subgroup); });
 }
 
+int cpx_g1_decompress_status(cpx_ctx* ctx, const uint8_t* compressed, size_t n, uint8_t* out_affine, int check_subgroup, uint8_t* status) {
+  if (n && (!compressed || !out_affine || !status)) return CPX_ERR_ARG;
+  return guarded(ctx, [&] { return ctx->eng->decompress(compressed, n, out_affine, check_subgroup, status); });
+}
+
 int cpx_accum_new(cpx_ctx* ctx, cpx_accum** out) {
   if (!ctx || !ctx->eng || !out) return CPX_ERR_ARG;
   cpx_accum* a = new (std::nothrow) cpx_accum();

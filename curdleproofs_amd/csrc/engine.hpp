@@ -114,7 +114,7 @@ class Engine {
   void fold(uint8_t* PL, const uint8_t* PR, const uint8_t* gamma, size_t half);                        // IPA / SameMSM folds
   void scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_stride, size_t n, uint8_t* out);  // G' rescale / k*R
   void normalize(const uint8_t* jac, size_t n, uint8_t* out_aff, uint8_t* out_comp);                   // normalize_batch (+compress)
-  int decompress(const uint8_t* comp, size_t n, uint8_t* out_aff, int check_subgroup);                 // whisk.rs:318-320
+  int decompress(const uint8_t* comp, size_t n, uint8_t* out_aff, int check_subgroup, uint8_t* status_out = nullptr);   // whisk.rs:318-320
 
   // ---- tier 2: batches of whole proofs, instance data resident in HBM ----
   void batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M);

@@ -86,6 +86,12 @@ int cpx_g1_normalize(cpx_ctx* ctx, const uint8_t* jac /* n*144 */, size_t n, uin
 /* whisk.rs:318-320 `from_bytes_g1affine` = deserialize_compressed with on-curve + subgroup validation */
 int cpx_g1_decompress(cpx_ctx* ctx, const uint8_t* compressed /* n*48 */, size_t n, uint8_t* out_affine /* n*96 */, int check_subgroup);
 
+/* The same with one verdict per point instead of one for the call: status[i] = 0 ok (out_affine[i] valid), 1 malformed encoding or x
+ * not on the curve, 2 on the curve but outside the order-r subgroup.  Returns CPX_OK whatever the verdicts are.  This is the
+ * device square root behind a try-and-increment hash to the curve: tests/crs.rs:13-52 `generate_random_points` maps a hash to x and
+ * keeps `get_point_from_x_unchecked(x, false)` when it exists (curdleproofs_amd/crs.py::generate_random_points). */
+int cpx_g1_decompress_status(cpx_ctx* ctx, const uint8_t* compressed /* n*48 */, size_t n, uint8_t* out_affine /* n*96 */, int check_subgroup, uint8_t* status /* n */);
+
 /* ---- tier 1: msm_accumulator.rs:22-68 `MsmAccumulator` -------------------------------------- */
 typedef struct cpx_accum cpx_accum;
 int cpx_accum_new(cpx_ctx* ctx, cpx_accum** out);

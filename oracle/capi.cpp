@@ -7,6 +7,7 @@
 //   affine point   96 B  = x || y           (identity = 96 zero bytes; (0,0) is not on the curve)
 //   Jacobian point 144 B = X || Y || Z      (identity = Z == 0)
 #include "protocol.h"
+#include "sha256.h"
 #include <chrono>
 
 using namespace orc;
@@ -254,6 +255,35 @@ void orc_generate_crs_points(size_t ell, uint8_t* out) {
   StdRng rng(0);
   for (size_t i = 0; i < ell + N_BLINDERS + CRS_EXTRA_POINTS; i++) aff_to_wire(g1_to_affine(rand_g1(rng)), out + 96 * i);
 }
+// /root/reference/tests/crs.rs:13-52 `generate_random_points(num_points, seed)`: try-and-increment hash to the curve.
+//   hash = SHA-256(seed || be64(increment)); x = the integer whose four low 64-bit limbs are the big-endian words of the hash
+//   (limb i = hash[8i..8i+8], limbs 4 and 5 zero: `BigInteger384::new(x)`, `Fp384::new` converts it to Montgomery form);
+//   `get_point_from_x_unchecked(x, false)`: the point with the lexicographically smaller y, if x^3 + 4 is a square;
+//   `mul_by_cofactor()` (the full cofactor h, not h_eff), kept if in the subgroup (always; the identity would pass too).
+// Returns the number of increments consumed (the reference's second tuple element).
+uint64_t orc_hash_to_curve_points(const uint8_t* seed, size_t seed_len, size_t num_points, uint8_t* out) {
+  static const uint64_t COFACTOR[2] = {0x8c00aaab0000aaabULL, 0x396c8c005555e156ULL};
+  uint64_t increment = 0;
+  size_t found = 0;
+  std::vector<uint8_t> msg(seed, seed + seed_len);
+  msg.resize(seed_len + 8);
+  while (found != num_points) {
+    for (int i = 0; i < 8; i++) msg[seed_len + i] = (uint8_t)(increment >> (56 - 8 * i));
+    uint8_t h[32];
+    sha256(msg.data(), msg.size(), h);
+    uint64_t x[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 8; j++) x[i] = (x[i] << 8) | h[8 * i + j];
+    G1Aff p;
+    if (g1_point_from_x(Fp::from_canonical(x), false, &p)) {   // x < 2^256 < p
+      const G1Aff z = g1_to_affine(g1_mul_limbs(G1::from_affine(p), COFACTOR, 2));
+      if (g1_in_subgroup(z)) aff_to_wire(z, out + 96 * found++);
+    }
+    increment++;
+  }
+  return increment;
+}
+void orc_sha256(const uint8_t* msg, size_t len, uint8_t out[32]) { sha256(msg, len, out); }
 // G_sum, H_sum of crs.rs:46-47 (96 B each)
 void orc_crs_sums(size_t ell, const uint8_t* crs_points, uint8_t* g_sum, uint8_t* h_sum) {
   Crs crs;

@@ -287,6 +287,19 @@ class Oracle:
         self.lib.orc_generate_crs_points(ell, o)
         return bytes(o)
 
+    def hash_to_curve_points(self, num_points, seed):
+        """/root/reference/tests/crs.rs:13-52 generate_random_points: (points as 96-byte affine records, increments consumed)"""
+        o = _buf(AFF * num_points)
+        self.lib.orc_hash_to_curve_points.restype = ctypes.c_uint64
+        s = seed.encode() if isinstance(seed, str) else bytes(seed)
+        inc = self.lib.orc_hash_to_curve_points(_cb(s), ctypes.c_size_t(len(s)), ctypes.c_size_t(num_points), o)
+        return bytes(o), inc
+
+    def sha256(self, msg):
+        o = _buf(32)
+        self.lib.orc_sha256(_cb(msg), ctypes.c_size_t(len(msg)), o)
+        return bytes(o)
+
     def crs_sums(self, ell, crs_points):
         g, h = _buf(AFF), _buf(AFF)
         self.lib.orc_crs_sums(ell, _cb(crs_points), g, h)

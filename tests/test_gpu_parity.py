@@ -910,10 +910,13 @@ def test_large_batch_four_contexts_every_proof_matches_oracle(orc):
     assert not c.sum_jac(b"".join(p for p, _ in partials_bad))[1]
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("fused", [False, True], ids=["prove_verify", "config5_fused_verify"])
+def test_bench_two_ranks_on_one_gpu(fused):
     """`python bench.py --gpus 2` end to end on real hardware: bench.py starts its two ranks itself (torch.distributed.run), both
     ranks share GPU 0 (CPX_BENCH_DEVICE) and meet over gloo (RCCL refuses two ranks on one device), every rank proves and verifies its
-    own batch, rank 0 prints ONE line with n_gpus = 2 and the whole-job rate.  Small shapes: this checks the plumbing, not the speed."""
+    own batch, rank 0 prints ONE line with n_gpus = 2 and the whole-job rate.  With --fused-verify: BASELINE configs[4] across ranks —
+    every rank's partial sum of ONE accumulated check, the all-gather of the 148-byte payloads (dist.all_gather_partials) and the
+    identity test on every rank.  Small shapes: this checks the plumbing, not the speed."""
     import json
     import subprocess
     import sys
@@ -922,7 +925,8 @@ def test_bench_two_ranks_on_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ell", "28", "--batch", "128", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-extra-shapes"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-extra-shapes"] + (["--fused-verify"] if fused else []), env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -930,6 +934,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["all_verified"] is True and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 256 and d["config"]["batch_per_gpu"] == 128
     assert abs(d["value"] - 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert ("batched verifier" in d["metric"]) == fused
 
 
 @pytest.mark.parametrize("copies", [1, 97], ids=["host_driven", "device_resident"])

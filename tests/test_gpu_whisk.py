@@ -155,3 +155,44 @@ def test_crs_hex_json_roundtrip(ctx, orc):
         with pytest.raises(ValueError):
             crsmod.crs_from_hex(c, bad)
     assert c3.crs_sums() == orc.crs_sums(ell, other) and c3.crs_points == other
+
+
+@pytest.mark.parametrize("n", [128, 8])
+def test_hash_to_curve_crs_matches_oracle(ctx, orc, n):
+    """tests/crs.rs:54-98 ethereum_crs_128_seed / ethereum_crs_8_seed: n + 3 points hashed to the curve from the reference's seed string,
+    on the product API (SHA-256 on the host, square roots / cofactor multiplication / subgroup test on the GPU) against the oracle's
+    restatement.  No reference-held vector exists for these points: oracle-pinned only (the oracle is itself checked against an
+    independent big-integer restatement in tests/test_oracle_kat.py)."""
+    from curdleproofs_amd import crs as crsmod
+    seed = "nankokita_no_kakurenbo"
+    want, want_inc = orc.hash_to_curve_points(n + 3, seed)
+    got, got_inc = crsmod.generate_random_points(ctx, n + 3, seed)
+    assert got_inc == want_inc
+    assert got == want
+    ell = n - 4
+    assert crsmod.crs_from_seed(ctx, ell, seed) == want_inc
+    assert ctx.crs_points == want and ctx.crs_sums() == orc.crs_sums(ell, want)
+    obj = crsmod.crs_to_hex(ctx)                                # CurdleproofsCrsHex of the seeded CRS (what the reference test prints)
+    assert obj["vec_G"][0] == "0x" + orc.g1_compress(want[:96]).hex() and len(obj["vec_G"]) == ell
+
+
+def test_hash_to_curve_crs_whisk_round_trip(ctx, orc):
+    """tests/crs.rs:100-114 `test_crs`: trackers from StdRng(0), a Whisk shuffle proof under the seeded CRS (n = 128), verified; the
+    proof bytes must equal the oracle's prover on the same draws and the oracle's verifier must accept them."""
+    from curdleproofs_amd import crs as crsmod, whisk
+    ell = 124
+    crsmod.crs_from_seed(ctx, ell, "nankokita_no_kakurenbo")
+    crs = ctx.crs_points
+    rng, pre = _kat_inputs(ctx, orc)
+    perm, k, mb = rng.shuffle(ell), rng.fr(1), rng.fr(4)
+    rand = rng.fr(3 * (ell + 4) + 9)
+    post, proof = whisk.generate_whisk_shuffle_proof(ctx, pre, permutation=perm, k=k, vec_m_blinders=mb, rand=rand)
+    vrand = rng.fr(8)
+    assert whisk.is_valid_whisk_shuffle_proof(ctx, pre, post, proof, rand=vrand)
+    cat = lambda ts: b"".join(t.to_bytes() for t in ts)
+    assert orc.is_valid_whisk_shuffle_proof(ell, crs, cat(pre), cat(post), proof, vrand) == 1
+    vec_R = b"".join(orc.g1_decompress(t.r_G) for t in pre)
+    vec_S = b"".join(orc.g1_decompress(t.k_r_G) for t in pre)
+    vec_T, vec_U, M = orc.shuffle_permute_and_commit_input(ell, crs, vec_R, vec_S, perm, k, mb)
+    assert proof == orc.g1_compress_jac(M) + orc.prove(ell, crs, vec_R, vec_S, vec_T, vec_U, M, perm, k, mb, rand)
+    assert not whisk.is_valid_whisk_shuffle_proof(ctx, pre, [post[1], post[0]] + post[2:], proof, rand=vrand)

@@ -120,3 +120,62 @@ def test_oracle_whisk_entry_points_with_explicit_draws(orc, whisk_kat):
     assert v == 1 and orc.is_valid_whisk_shuffle_proof(124, crs, pre, post, sproof, vr) == 1
     assert orc.is_valid_whisk_shuffle_proof(124, crs, post, pre, sproof, vr) == 0
     assert orc.is_valid_whisk_shuffle_proof(124, crs, pre, post, bytes(48) + sproof[48:], vr) == -1
+
+
+def test_sha256_matches_hashlib(orc):
+    import hashlib
+    for msg in (b"", b"abc", b"nankokita_no_kakurenbo" + (7).to_bytes(8, "big"), bytes(range(256)) * 3, b"x" * 55, b"y" * 56, b"z" * 64):
+        assert orc.sha256(msg) == hashlib.sha256(msg).digest()
+
+
+def test_hash_to_curve_points_match_an_independent_big_integer_restatement(orc):
+    """/root/reference/tests/crs.rs:13-52 with the reference's seed string.  The reference holds no vector for these points (the test
+    prints them), so the oracle's restatement is pinned here against a second, independent one over Python integers: SHA-256 from
+    hashlib, x from the four big-endian words as little-endian limbs, y = the smaller square root of x^3 + 4, times the full cofactor."""
+    import hashlib
+    p = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    h = 0x396c8c005555e1568c00aaab0000aaab
+    seed = b"nankokita_no_kakurenbo"
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    def mul(P, k):
+        R = None
+        for bit in bin(k)[2:]:
+            R = add(R, R)
+            if bit == "1":
+                R = add(R, P)
+        return R
+
+    want, inc = [], 0
+    while len(want) < 5:
+        d = hashlib.sha256(seed + inc.to_bytes(8, "big")).digest()
+        x = sum(int.from_bytes(d[8 * i:8 * i + 8], "big") << (64 * i) for i in range(4))
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        inc += 1
+        if y * y % p != rhs:
+            continue
+        want.append(mul((x, min(y, p - y)), h))
+    got, got_inc = orc.hash_to_curve_points(5, seed.decode())
+    assert got_inc == inc
+    R = 1 << 384
+    for i, (x, y) in enumerate(want):
+        rec = got[96 * i:96 * (i + 1)]
+        gx = int.from_bytes(rec[:48], "little") * pow(R, -1, p) % p      # wire = Montgomery limbs
+        gy = int.from_bytes(rec[48:], "little") * pow(R, -1, p) % p
+        assert (gx, gy) == (x, y), i
+        assert orc.g1_on_curve(rec) and orc.g1_in_subgroup(rec)

@@ -104,7 +104,7 @@ CPX_HD F28 f28_neg(const F28& a) {
 // a * 2^k for tiny k (limbs < 2^28 -> < 2^31 for k <= 3 before the carry pass; the top limb stays small)
 template <int K> CPX_HD F28 f28_shl(const F28& a) {
   F28 r;
-  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = a.v[i] << K;
+  CPX_UNROLL for (int i = 0; i < 14; i++) r.v[i] = a.v[i] * (int32_t)(1 << K);   // (a multiplication: shifting a negative limb left is undefined before C++20; same instruction)
   f28_normalize(r);
   return r;
 }

@@ -306,7 +306,7 @@ void Engine::prepare_device_prover() {
   // the last four rounds of a large batch work on 16 materialised folded bases per family instead (late.hip)
   DevProver::Late& lt = dp.late;
   lt.m = 16;
-  lt.on = opt_.late_rounds == 4 && L >= 5 && B >= (size_t)opt_.late_min_batch && late_supported((int)n, lt.m) && 3 * lt.m <= 64;
+  lt.on = opt_.late_rounds == 4 && L >= 5 && B >= (size_t)opt_.late_min_batch && late_supported((int)n, lt.m) && 4 * lt.m <= 64;
   lt.j0 = lt.on ? L - 4 : L;
   for (size_t j = 0; j < L; j++) {
     if (j >= lt.j0) {   // placeholders: exec_late_round takes these rounds
@@ -546,10 +546,12 @@ void Engine::enqueue_prove_device() {
   for (size_t j = 0; j < L; j++) {
     const int half = (int)(n >> (j + 1));
     if (lt.on && j == lt.j0) {   // T_b^(j0), U_b^(j0), G_b^(j0): one shared digit sequence per proof (fold coefficients S_M)
-      tick("k_late_uniform", 128.0 * 3 * n * B, (double)(3 * n * B));
-      launch_late_uniform(dp.rvec2.p + n, 2 * n, d_ptab_.p, (size_t)copies_ * NP, (int)NP, ctab(), (int)nc(), lt.gb_cols, (int)n, lt.m, 3, lt.jac.p + LATE_F_T * BM, BM, Bi,
-                          stream_);
+      // (T_b, U_b with two lanes per output fill a wave; G_b then comes from the table of multiples like G and G')
+      tick("k_late_uniform", 128.0 * 2 * n * B, (double)(2 * n * B));
+      launch_late_uniform(dp.rvec2.p + n, 2 * n, d_ptab_.p, (size_t)copies_ * NP, (int)NP, ctab(), (int)nc(), lt.gb_cols, (int)n, lt.m, 2, 2, lt.jac.p + LATE_F_T * BM, BM,
+                          Bi, stream_);
       tock();
+      launch_late_fix(dp.rvec2.p + n, 2 * n, lt.gb_cols, (int)n, lt.m, fixtab(), fix_bits_, (int)nc(), lt.jac.p + LATE_F_GB * BM, (size_t)lt.m, Bi, stream_);
       tick("k_late_tables", 0, (double)(3 * BM));
       launch_late_tables(lt.jac.p + LATE_F_T * BM, lt.tab.p + LATE_F_T * BM * late_tab_entries(), d_tbltmp_.p, (int)(3 * BM), stream_);
       tock();

@@ -33,7 +33,7 @@ struct Options {
   long cu_mask = 1;                // 0: plain instead of CU-masked streams for the lone-proof prover
   long trace = 0;                  // 1: print the challenges of proof 0 to stderr (debugging aid)
   long late_rounds = 4;            // 4: the last four log rounds of a large batch run on materialised folded bases (late.hip); 0: all-MSM everywhere
-  long late_min_batch = 1024;      // ... for batches of at least this many proofs (the lane-per-output kernels need a full GPU to pay)
+  long late_min_batch = 2048;      // ... for batches of at least this many proofs (the lane-per-output kernels need a full GPU to pay)
   long late_slices = 8;            // lanes per cross term of a late round (1, 2, 4, 8): 15.3 k proofs/s at 8, 14.9 k at 4 and 2, 14.3 k at 1
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
 };
@@ -208,7 +208,7 @@ void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, i
 // out[f * fstride + p * m + i] = sum_t sm[p * sstride + t m] * F_(t m + i) for the families f < nfam: T_b, U_b (per-proof 32-copy tables,
 // row M | T_b | U_b, NP columns) and G_b (CRS copies d_ctab, nc columns, column map d_gb_cols)
 void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, size_t ptab_proof_stride, int NP, const TAff* d_ctab, int nc, const uint32_t* d_gb_cols, int n,
-                         int m, int nfam, TJac* d_out, size_t fstride, int nproofs, hipStream_t s);
+                         int m, int nfam, int split, TJac* d_out, size_t fstride, int nproofs, hipStream_t s);   // split: lanes per output (nfam * m * split <= 64)
 void launch_late_tables(const TJac* d_jac, TAff* d_tab, TblTmp* d_tmp, int npoints, hipStream_t s);
 void launch_late_msm(const LateRound& r, hipStream_t s);
 void launch_late_restart(Fr* d_vec, int n, int m, int nproofs, hipStream_t s);

@@ -204,24 +204,38 @@ __device__ __forceinline__ TAcc raw_load(const uint32_t* __restrict__ set, int l
 // reduction, 5110 multiply-adds, against 5817 for the Jacobian 11M + 5S plus two products per input for the conversion; only the
 // partial sum a set ends in is converted.)
 constexpr int MID_PER_SET = 16;   // TAcc entries of `mid` per set: 8 groups x {S, W}
+// a lane's parked accumulator in LDS, word-interleaved by lane (word w of lane l at [w * 64 + l]: conflict-free)
+__device__ __forceinline__ void lds_park(uint32_t* __restrict__ buf, int lane, const TAcc& a) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&a);
+  CPX_UNROLL for (int i = 0; i < ACC_WORDS; i++) buf[i * 64 + lane] = w[i];
+}
+__device__ __forceinline__ TAcc lds_unpark(const uint32_t* __restrict__ buf, int lane) {
+  TAcc a;
+  uint32_t* w = reinterpret_cast<uint32_t*>(&a);
+  CPX_UNROLL for (int i = 0; i < ACC_WORDS; i++) w[i] = buf[i * 64 + lane];
+  return a;
+}
 template <bool WEIGHTED> __global__ __launch_bounds__(64, 2) void k_reduce_sets(const uint32_t* __restrict__ raw, int nsets, TAcc* __restrict__ mid) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
+  __shared__ uint32_t park[WEIGHTED ? ACC_WORDS * 64 : 1];
+  const int t = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
   if (t >= nsets * 8) return;
   const int set = t >> 3, g = t & 7;
   const uint32_t* rs = raw + (size_t)set * RAW_SET_WORDS;
-  // the weighted running sum W waits in its output slot between its additions (two XYZZ sums live in registers beside the
-  // operands of an addition are 300 VGPRs: one wave per SIMD instead of two)
+  // the weighted running sum W waits in LDS between its additions (two XYZZ sums live in registers beside the operands of an
+  // addition are 300 VGPRs: one wave per SIMD instead of two; until round 3 it waited in its global output slot: a round trip
+  // to HBM inside every step of the dependent chain)
   TAcc run = raw_load(rs, g * 8 + 7);
-  TAcc* const wslot = mid + (size_t)t * 2 + 1;
-  if (WEIGHTED) *wslot = run;
+  if (WEIGHTED) lds_park(park, lane, run);
   for (int j = 6; j >= 0; j--) {
     run = t_acc_add(run, raw_load(rs, g * 8 + j));
-    if (WEIGHTED) *wslot = t_acc_add(*wslot, run);
+    if (WEIGHTED) lds_park(park, lane, t_acc_add(lds_unpark(park, lane), run));
   }
   mid[(size_t)t * (WEIGHTED ? 2 : 1)] = run;
+  if (WEIGHTED) mid[(size_t)t * 2 + 1] = lds_unpark(park, lane);
 }
 template <bool WEIGHTED> __global__ __launch_bounds__(64, 2) void k_reduce_groups(TAcc* __restrict__ mid, const uint32_t* __restrict__ slot, int nsets,
                                                                               TJac* __restrict__ part) {
+  __shared__ uint32_t park[WEIGHTED ? ACC_WORDS * 64 : 1];
   const int set = blockIdx.x * 64 + threadIdx.x;
   if (set >= nsets) return;
   const TAcc* m = mid + (size_t)set * 8 * (WEIGHTED ? 2 : 1);
@@ -231,22 +245,23 @@ template <bool WEIGHTED> __global__ __launch_bounds__(64, 2) void k_reduce_group
     part[slot[set]] = t_acc_to_jac(run);
     return;
   }
-  // (v waits in the slot of S_7, which is dead once it has been read, while run is being updated: see k_reduce_sets)
-  TAcc* const vslot = mid + (size_t)set * 16 + 2 * 7;
+  // (v waits in LDS while run is being updated: see k_reduce_sets)
+  const int lane = threadIdx.x;
   TAcc run = m[2 * 7];                          // S_7
+  lds_park(park, lane, run);
   for (int k = 6; k >= 1; k--) {
     run = t_acc_add(run, m[2 * k]);
-    *vslot = t_acc_add(*vslot, run);
+    lds_park(park, lane, t_acc_add(lds_unpark(park, lane), run));
   }
-  run = t_acc_add(run, m[0]);                   // run = sum_g S_g, *vslot = sum_g g S_g
-  TAcc v = *vslot;
+  run = t_acc_add(run, m[0]);                   // run = sum_g S_g, parked = sum_g g S_g
+  TAcc v = lds_unpark(park, lane);
   if (set & 1) {                                // upper half of the magnitudes: + 64 sum_g S_g, parked while v is finished
     for (int d = 0; d < 6; d++) run = t_acc_dbl(run);
-    *vslot = run;
+    lds_park(park, lane, run);
   }
   for (int d = 0; d < 3; d++) v = t_acc_dbl(v); // 8 v
   for (int k = 0; k < 8; k++) v = t_acc_add(v, m[2 * k + 1]);
-  if (set & 1) v = t_acc_add(v, *vslot);
+  if (set & 1) v = t_acc_add(v, lds_unpark(park, lane));
   part[slot[set]] = t_acc_to_jac(v);
 }
 

@@ -83,7 +83,7 @@ template <int CB> __global__ __launch_bounds__(64, 2) void k_late_fix(const Fr* 
 constexpr int LU_MAX_T = 128;                       // n / m <= 128
 __global__ __launch_bounds__(64, 2) void k_late_uniform(const Fr* __restrict__ sm, size_t sstride, const TAff* __restrict__ ptab, size_t ptab_proof_stride, int NP,
                                                         const TAff* __restrict__ ctab, int nc, const uint32_t* __restrict__ gb_cols, int n, int m, int nfam,
-                                                        TJac* __restrict__ out, size_t fstride) {
+                                                        int split, TJac* __restrict__ out, size_t fstride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int nt = n / m, nent = 32 * nt;
   TAcc* total = reinterpret_cast<TAcc*>(smem);                                    // [64]
@@ -136,8 +136,12 @@ __global__ __launch_bounds__(64, 2) void k_late_uniform(const Fr* __restrict__ s
     }
   }
   __syncthreads();
-  const int fam = lane / m, i = lane % m;
-  const bool live = fam < nfam;
+  // lane = (sub * nfam + fam) * m + i: `split` lanes share an output, lane `sub` taking every split-th entry of every magnitude level
+  // with a running sum and a total of its own (sum_b b B_b is linear in the buckets); the totals are added at the end.  With two
+  // families (T_b, U_b: G_b then comes from the table of multiples) and split = 2 all 64 lanes work: 256 + 128 additions deep
+  // instead of 512 + 128 on 48 lanes.
+  const int fam = (lane / m) % nfam, sub = lane / (m * nfam), i = lane % m;
+  const bool live = sub < split;
   // where this lane's copy-0 points live and how far apart the copies are
   const TAff* base = nullptr;
   size_t cstride = 0;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(64, 2) void k_late_uniform(const Fr* __restrict__ s
   for (int b = 128; b >= 1; b--) {
     const uint32_t c = cnt[b];
     if (live) {
-      for (uint32_t e = pos; e < pos + c; e++) {
+      for (uint32_t e = pos + (uint32_t)sub; e < pos + c; e += (uint32_t)split) {
         const uint32_t en = list[e];
         const uint32_t k = (en >> 6) * (uint32_t)m + (uint32_t)i;
         const TAff q = base[(size_t)((en >> 1) & 31u) * cstride + (fam < 2 ? k : gb_cols[k])];
@@ -166,7 +170,12 @@ __global__ __launch_bounds__(64, 2) void k_late_uniform(const Fr* __restrict__ s
     }
     pos += c;
   }
-  if (live) out[(size_t)fam * fstride + (size_t)p * m + i] = t_acc_to_jac(total[lane]);
+  __syncthreads();
+  if (live && sub == 0) {
+    TAcc sum = total[lane];
+    for (int s2 = 1; s2 < split; s2++) sum = t_acc_add(sum, total[lane + s2 * nfam * m]);
+    out[(size_t)fam * fstride + (size_t)p * m + i] = t_acc_to_jac(sum);
+  }
 }
 
 // ------------------------------------------------------------------ 2. small multiples of the materialised points
@@ -311,11 +320,11 @@ void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, i
   else LATE_LAUNCH(k_late_fix<8>, dim3((total + 63) / 64), dim3(64), 0, s, d_scal, sstride, d_cols, n, m, d_fix_tab, nc, d_out, ostride, total);
 }
 void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, size_t ptab_proof_stride, int NP, const TAff* d_ctab, int nc, const uint32_t* d_gb_cols, int n,
-                         int m, int nfam, TJac* d_out, size_t fstride, int nproofs, hipStream_t s) {
-  if (nproofs <= 0) return;
+                         int m, int nfam, int split, TJac* d_out, size_t fstride, int nproofs, hipStream_t s) {
+  if (nproofs <= 0 || nfam * m * split > 64) return;
   const int nent = 32 * (n / m);
   const size_t lds = 64 * sizeof(TAcc) + (size_t)((nent + 1) & ~1) * 2 + 2 * 132 * 4;
-  LATE_LAUNCH(k_late_uniform, dim3(nproofs), dim3(64), lds, s, d_sm, sstride, d_ptab, ptab_proof_stride, NP, d_ctab, nc, d_gb_cols, n, m, nfam, d_out, fstride);
+  LATE_LAUNCH(k_late_uniform, dim3(nproofs), dim3(64), lds, s, d_sm, sstride, d_ptab, ptab_proof_stride, NP, d_ctab, nc, d_gb_cols, n, m, nfam, split, d_out, fstride);
 }
 void launch_late_tables(const TJac* d_jac, TAff* d_tab, TblTmp* d_tmp, int npoints, hipStream_t s) {
   if (npoints <= 0) return;

@@ -4,7 +4,7 @@
 # PMC passes are separate runs (no traces together with --pmc).  The HBM counter pass runs first because bench.py reads
 # profiles/${RND}_hbm_counters.json for roofline.traffic.
 set -x
-RND=${RND:-r02}
+RND=${RND:-r03}
 R=$PWD
 O=$R/gpurun_out/prof
 mkdir -p $O
@@ -12,7 +12,7 @@ python bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc2 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc3 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc3.log 2>&1
-python $R/scripts/hbm_counters.py $O/${RND}_hbm_counters.json 8192 2 $(find /tmp/pmc2 -name "*counter_collection.csv" | head -1) $(find /tmp/pmc3 -name "*counter_collection.csv" | head -1) > $O/${RND}_hbm_counters.txt 2>&1
+python $R/scripts/hbm_counters.py $O/${RND}_hbm_counters.json 16384 2 $(find /tmp/pmc2 -name "*counter_collection.csv" | head -1) $(find /tmp/pmc3 -name "*counter_collection.csv" | head -1) > $O/${RND}_hbm_counters.txt 2>&1
 cp $O/${RND}_hbm_counters.json $R/profiles/${RND}_hbm_counters.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc1 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc1.log 2>&1
 python $R/scripts/pmc_summary.py $(find /tmp/pmc1 -name "*counter_collection.csv" | head -1) $O/${RND}_pmc_sq.md > /dev/null

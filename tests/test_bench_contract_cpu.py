@@ -1,5 +1,6 @@
-"""The committed bench line (profiles/r01_bench.json, produced by `python bench.py` on an MI355X) carries every field
+"""The newest committed bench line (profiles/rNN_bench.json, produced by `python bench.py` on an MI355X) carries every field
 of the driver's contract, and bench.py's command line accepts the driver's flags."""
+import glob
 import json
 import os
 import subprocess
@@ -9,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench.json")) as f:
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")))[-1]
+    with open(newest) as f:
         d = json.loads(f.read())
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)
@@ -28,6 +30,11 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
     assert d["all_verified"] is True and c["gpu_proof_bit_exact"] is True
+    if os.path.basename(newest) >= "r03_bench.json":   # round 3 on: the batched verifier (BASELINE configs[4]) is part of the default line
+        c5 = d["config5"]
+        assert c5["all_verified"] is True and c5["rejects_a_batch_with_one_wrong_proof"] is True and c5["proofs_per_check"] >= 4096
+        assert 0 < c5["valu"]["frac"] < 1 and c5["cpu_verify_per_proof"]["kind"] == "port"
+        assert "traffic_source" in r
 
 
 def test_bench_cli_accepts_driver_flags():

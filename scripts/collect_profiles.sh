@@ -12,7 +12,7 @@ python bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc2 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc3 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc3.log 2>&1
-python $R/scripts/hbm_counters.py $O/${RND}_hbm_counters.json 16384 2 $(find /tmp/pmc2 -name "*counter_collection.csv" | head -1) $(find /tmp/pmc3 -name "*counter_collection.csv" | head -1) > $O/${RND}_hbm_counters.txt 2>&1
+python $R/scripts/hbm_counters.py $O/${RND}_hbm_counters.json 16384 2 $(find /tmp/pmc2 -name "*counter_collection.csv" | head -1) $(find /tmp/pmc3 -name "*counter_collection.csv" | head -1) ${COMMIT:-unknown} > $O/${RND}_hbm_counters.txt 2>&1
 cp $O/${RND}_hbm_counters.json $R/profiles/${RND}_hbm_counters.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pmc1 -- python $R/bench.py --no-cpu-baseline --no-extra-shapes --synth-cache /tmp/synth.pkl --steps 1 --warmup 0 > $O/pmc1.log 2>&1
 python $R/scripts/pmc_summary.py $(find /tmp/pmc1 -name "*counter_collection.csv" | head -1) $O/${RND}_pmc_sq.md > /dev/null
@@ -21,13 +21,17 @@ cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/${RND}_kernel_stats.cs
 grep -o '{"metric.*' $O/kt.log | head -1 > $O/${RND}_bench_under_rocprof.json   # the bench line of the SAME process the kernel statistics come from
 python $R/scripts/gpu_busy.py $(find /tmp/kt -name "*kernel_trace.csv" | head -1) after_last=k_fix_build from_first=k_compress > $O/${RND}_gpu_busy.txt 2>&1
 cd $R
-python bench.py --synth-cache /tmp/synth.pkl > $O/bench_default.log 2>&1
+python $R/scripts/kernel_stats_md.py $O/${RND}_kernel_stats.csv > $O/${RND}_kernel_stats.md 2>/dev/null
+python bench.py --synth-cache /tmp/synth.pkl --steps 10 --warmup 2 > $O/bench_default.log 2>&1
 tail -1 $O/bench_default.log > $O/${RND}_bench.json
 python bench.py --fused-verify --synth-cache /tmp/synth.pkl 2>/dev/null | tail -1 > $O/${RND}_bench_config5.json
+# one engine context alone (4096 and 8192 proofs per pass): uncontended kernel durations, what a pass consists of
+python bench.py --synth-cache /tmp/synth.pkl --no-cpu-baseline --no-extra-shapes --ctxs 1 --batch 8192 --steps 4 2>/dev/null | tail -1 > $O/${RND}_bench_one_context.json
+python bench.py --synth-cache /tmp/synth.pkl --no-cpu-baseline --no-extra-shapes --opt late_rounds=0 --steps 6 2>/dev/null | tail -1 > $O/${RND}_bench_late_rounds_off.json
 python scripts/single_proof_latency.py > $O/${RND}_single_proof_latency.txt 2>&1
 # the lone-proof timeline (which kernel a lone proof waits for, launch by launch) and the micro-benchmarks behind the latency kernels
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/scripts/single_proof_timeline.py run > /dev/null 2>&1; python $R/scripts/single_proof_timeline.py report /tmp/tl > $O/${RND}_single_proof_timeline.txt 2>&1 )
-for m in quad_micro lat_micro place_micro keccak_micro; do
+for m in ${MICRO:-}; do   # MICRO="quad_micro lat_micro place_micro keccak_micro" to rerun the micro-benchmarks (unchanged since r02)
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I curdleproofs_amd/csrc scripts/micro/$m.hip -o /tmp/$m > /dev/null 2>&1 && timeout 120 /tmp/$m > $O/${RND}_$m.txt 2>&1
 done
 python scripts/shape_sweep.py 128 2>&1 | tail -1 > $O/${RND}_shape_128.txt

@@ -2,7 +2,7 @@
 """Merges rocprofv3 --pmc passes (FETCH_SIZE in one run, WRITE_SIZE in another: counter_collection.csv each) into
 profiles/<name>.json: per kernel, counter totals (KiB) and dispatch counts, tagged with the bench configuration so
 bench.py only uses them for the matching workload.
-Usage: hbm_counters.py out.json batch_per_gpu engine_contexts fetch.csv write.csv"""
+Usage: hbm_counters.py out.json batch_per_gpu engine_contexts fetch.csv write.csv [commit]"""
 import csv
 import json
 import sys
@@ -21,12 +21,12 @@ def load(path, counter):
     return {k: dict(total=tot[k], dispatches=len(disp[k])) for k in tot}
 
 
-def main(out, batch, ctxs, fetch_csv, write_csv):
+def main(out, batch, ctxs, fetch_csv, write_csv, commit="unknown"):
     fe, wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     res = {}
     for k in sorted(set(fe) | set(wr)):
         if k in fe and k in wr:
-            res[k] = dict(FETCH_SIZE=fe[k], WRITE_SIZE=wr[k], batch_per_gpu=int(batch), engine_contexts_per_gpu=int(ctxs))
+            res[k] = dict(FETCH_SIZE=fe[k], WRITE_SIZE=wr[k], batch_per_gpu=int(batch), engine_contexts_per_gpu=int(ctxs), commit=commit)
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     for k, v in res.items():
@@ -36,4 +36,4 @@ def main(out, batch, ctxs, fetch_csv, write_csv):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])

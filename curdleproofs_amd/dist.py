@@ -18,7 +18,7 @@ def partition(n_items, world, rank):
 
 def max_over_ranks(value, dist=None, device="cpu"):
     """Max of a python float over all ranks (the bench contract's max-over-ranks step time)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(value)
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
@@ -28,7 +28,7 @@ def max_over_ranks(value, dist=None, device="cpu"):
 
 def gather_lists(local_list, dist=None):
     """Concatenate per-rank python lists in rank order on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return list(local_list)
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, list(local_list))
@@ -46,8 +46,8 @@ def all_gather_partials(partial_jac, n_invalid, dist=None, device="cpu"):
     payload is 148 bytes per rank, so the step is latency-bound."""
     if len(partial_jac) != JAC_BYTES:
         raise ValueError("partial sum must be one 144-byte Jacobian point")
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return bytes(partial_jac), int(n_invalid)
+    if dist is None or not dist.is_initialized():   # (an initialised group of ONE rank still goes through the collective: the
+        return bytes(partial_jac), int(n_invalid)    # single-GPU test of the RCCL path, tests/test_gpu_parity.py)
     import torch
     payload = bytes(partial_jac) + int(n_invalid).to_bytes(4, "little")
     mine = torch.tensor(list(payload), dtype=torch.uint8, device=device)

@@ -910,6 +910,57 @@ def test_large_batch_four_contexts_every_proof_matches_oracle(orc):
     assert not c.sum_jac(b"".join(p for p, _ in partials_bad))[1]
 
 
+RCCL_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import curdleproofs_amd as cpx
+from curdleproofs_amd.dist import max_over_ranks, all_gather_partials, fused_verify_all_ranks
+from tests.oracle_lib import Oracle
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # nccl == RCCL on ROCm
+orc = Oracle()
+ell = 28
+crs = orc.generate_crs_points(ell)
+insts = [orc.make_instance(ell, 40 + s, crs) for s in range(3)]
+cat = lambda key: b"".join(i[key] for i in insts)
+c = cpx.Context(0)
+c.set_crs(ell, crs)
+c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+proofs = [i["proof"] for i in insts]
+rand = orc.rng(3).fr(12 * 3)
+dist.barrier()
+tmax = max_over_ranks(1.25, dist, "cuda")                      # ncclAllReduce(MAX) on a device tensor: the bench's timing step
+part, bad = c.verify_batch_fused_partial(proofs, rand)
+parts, bad_total = all_gather_partials(part, bad, dist, "cuda")   # ncclAllGather of the 148-byte payload on device tensors
+ok = fused_verify_all_ranks(c, proofs, rand, dist, "cuda")
+wrong = fused_verify_all_ranks(c, [proofs[1], proofs[0], proofs[2]], rand, dist, "cuda")
+print(json.dumps(dict(backend=dist.get_backend(), tmax=tmax, same=parts == part, bad=bad_total, ok=bool(ok), wrong=bool(wrong))))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_collectives_of_the_fused_verifier_run_on_the_gpu(tmp_path):
+    """The exchange step of BASELINE configs[4] and the bench's timing reduction through backend "nccl" (= RCCL) on device tensors.
+    A 1-GPU box cannot host two RCCL ranks (RCCL refuses two ranks on one device), so the communicator has ONE rank: the same
+    ncclAllGather / ncclAllReduce calls on the same tensors as at N > 1, executed on the MI355X (the N = 2 data flow itself is
+    covered over gloo: tests/test_distributed_cpu.py and test_bench_two_ranks_on_one_gpu)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == dict(backend="nccl", tmax=1.25, same=True, bad=0, ok=True, wrong=False)
+
+
 @pytest.mark.parametrize("fused", [False, True], ids=["prove_verify", "config5_fused_verify"])
 def test_bench_two_ranks_on_one_gpu(fused):
     """`python bench.py --gpus 2` end to end on real hardware: bench.py starts its two ranks itself (torch.distributed.run), both

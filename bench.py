@@ -471,7 +471,7 @@ def main():
         # under one reduction: 3542 multiply-adds = 9.04 products of 392 (rounds 1-2 of this build counted 11, the Jacobian 7M + 4S,
         # for an addition that cost 9.5: their fractions read 16 % too high).
         PROD_PER_ADD = 3542.0 / 392.0
-        mulmods_per_point = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * PROD_PER_ADD,
+        mulmods_per_point = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": (14 if dom.startswith("k_msm_fix<19") else 16) * PROD_PER_ADD,
                              "k_smul": 0.0}[dom.split("<")[0]]
         ctxs[0].set_option("bench_field", 28)
         peak_mm = ctxs[0].bench_fpmul(2048, 1000, 2)
@@ -481,7 +481,8 @@ def main():
                                 note="kernel time is measured with all engine contexts sharing the GPU, so it includes the other contexts' kernels; "
                                      "'isolated' repeats the measurement with one context running alone after the timed region")
         if iso:   # every MSM kernel, one context alone: point-scalar pairs, additions x their product equivalents against the measured peak
-            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": 16 * PROD_PER_ADD}
+            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11,
+                        "k_msm_fix": (14 if any(k.startswith("k_msm_fix<19") for k in iso) else 16) * PROD_PER_ADD}
             roofline["valu"]["isolated_by_kernel"] = {
                 k: dict(pairs_per_proof=v["units"] / (B // K), ms_per_proof_batch=v["ms"],
                         frac=(v["units"] * per_pair[k.split("<")[0]] / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None,

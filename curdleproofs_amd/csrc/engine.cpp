@@ -306,7 +306,7 @@ void Engine::run_tbl_phase(const std::vector<TblReq>& reqs, std::vector<uint8_t>
     nft_total += (is_crs(r.seg0) ? 1 : 0) + (is_crs(r.seg1) ? 1 : 0);
   }
   const int fix_wpw = fix ? msm_fix_windows_per_wave(opt_, (int)nft_total, fix_bits_) : 16;
-  const uint32_t fix_parts = fix ? (uint32_t)(256 / fix_bits_ / fix_wpw) : 0;
+  const uint32_t fix_parts = fix ? (uint32_t)msm_fix_parts(fix_bits_, fix_wpw) : 0;
   const int tbl_wpw = msm_tblw_windows_per_wave(opt_, (int)ntt_total);   // windows per wave of the shifted-table kernel
   uint32_t tbl_max_n = 0;
   for (const TblReq& r : reqs)
@@ -500,14 +500,18 @@ void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
     std::lock_guard<std::mutex> lk(reg_mu);
     const size_t NC = nc();
     int want_fix = fix_bits_cfg_;
-    if (want_fix == 16) {   // 15 GB at ell = 252, 60 GB at ell = 1020: fall back to the radix-2^8 table (0.1 GB / 0.4 GB) when HBM is short
+    // 19 bits: 14 windows x 2^18 multiples = 122 GB at ell = 252 (leave room for the batches: at most 45 % of the HBM); 16 bits: 17.5 GB
+    // at ell = 252, 70 GB at ell = 1020; fall back 19 -> 16 -> 8 (0.1 GB / 0.4 GB) when HBM is short
+    for (int cand : {19, 16}) {
+      if (want_fix != cand) continue;
       size_t free_b = 0, total_b = 0;
       CPX_HIP(hipMemGetInfo(&free_b, &total_b));
-      const size_t need = (size_t)16 * ((size_t)1 << 15) * NC * sizeof(TFix) + (size_t)(16 * NC + 63) * 256 * sizeof(TblTmp);
+      const size_t Wc = (size_t)msm_fix_windows(cand), segs = cand == 19 ? 8 : 1;
+      const size_t need = Wc * ((size_t)1 << (cand - 1)) * NC * sizeof(TFix) + (Wc * NC * segs + 63) * 256 * sizeof(TblTmp);
       bool have = false;   // an existing shared table costs nothing
       for (auto& w : registry)
-        if (auto sp = w.lock()) have |= sp->device == device_ && sp->fix_bits == 16 && sp->key.size() == (ell + 7) * sizeof(Aff) && !memcmp(sp->key.data(), points, sp->key.size());
-      if (!have && need + (need >> 3) > free_b) want_fix = 8;
+        if (auto sp = w.lock()) have |= sp->device == device_ && sp->fix_bits == cand && sp->key.size() == (ell + 7) * sizeof(Aff) && !memcmp(sp->key.data(), points, sp->key.size());
+      if (!have && (need + (need >> 3) > free_b || (cand == 19 && need > total_b / 20 * 9))) want_fix = cand == 19 ? 16 : 8;
     }
     fix_bits_ = want_fix;
     std::vector<uint8_t> key(points, points + (ell + 7) * sizeof(Aff));
@@ -540,16 +544,17 @@ void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
       CPX_HIP(hipStreamSynchronize(stream_));
       if (want_fix) {
         // multiples m * 2^(c w) * P, m <= 2^(c-1): shifted copies first, then the multiples
-        const int W = 256 / want_fix;
+        const int W = msm_fix_windows(want_fix);
         const size_t M = size_t(1) << (want_fix - 1);
         DevBuf<TAff> d_shift;
         d_shift.ensure((size_t)W * NC);
-        launch_table_build(opt_, d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, false, tmp.p, stream_);
+        launch_table_build(opt_, d_row.p, 0, d_shift.p, 1, 0, (int)NC, (int)NC, W, false, tmp.p, stream_, want_fix);   // copy w = 2^(want_fix w) P
         tab->fixtab.ensure((size_t)W * M * NC);
         const int chunk = (int)std::min<size_t>(256, M);
-        const size_t threads = ((size_t)W * NC + 63) / 64 * 64;
+        const int segs = want_fix == 19 ? 8 : 1;   // 2^18 multiples per (window, base): eight threads of 2^15 each
+        const size_t threads = ((size_t)W * NC * segs + 63) / 64 * 64;
         tmp.ensure(threads * chunk);
-        launch_fix_build(d_shift.p, (int)NC, want_fix, tab->fixtab.p, tmp.p, chunk, stream_);
+        launch_fix_build(d_shift.p, (int)NC, want_fix, tab->fixtab.p, tmp.p, chunk, stream_, segs);
         CPX_HIP(hipStreamSynchronize(stream_));
       }
       registry.push_back(tab);
@@ -1835,7 +1840,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
       crs_sum[i] = t;
     });
     const int fix_wpw = msm_fix_windows_per_wave(opt_, 1, fix_bits_);
-    const int fix_parts = 256 / fix_bits_ / fix_wpw;
+    const int fix_parts = msm_fix_parts(fix_bits_, fix_wpw);
     d_scal_.ensure(N + n);
     d_big_idx_.ensure(N);
     d_tpart_.ensure(fix_parts);
@@ -1916,7 +1921,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     for (size_t j = 0; j < NM; j++) all_idx[NI + j] = (uint32_t)(NI + misc_idx[j]);
     const uint32_t* d_all = idx_list(all_idx);
     const int fix_wpw = msm_fix_windows_per_wave(opt_, (int)B, fix_bits_);
-    const int fix_parts = 256 / fix_bits_ / fix_wpw;
+    const int fix_parts = msm_fix_parts(fix_bits_, fix_wpw);
     const size_t slices = (size_t)msm_tblw_slices(opt_, (int)B, 2, (int)NPT);   // a lone proof: several waves per window of the per-proof MSM
     const size_t total = B * (NPT + n);
     d_scal_.ensure(total);

@@ -79,6 +79,7 @@ struct KernelStat {
 
 // kernel names as rocprofv3 reports the template instantiations (statistics keys)
 inline const char* fix_kernel_name(int bits, int wpw) {
+  if (bits == 19) return "k_msm_fix<19, 7>";
   if (bits == 16) return wpw == 16 ? "k_msm_fix<16, 16>" : wpw == 8 ? "k_msm_fix<16, 8>" : wpw == 4 ? "k_msm_fix<16, 4>" : "k_msm_fix<16, 2>";
   return wpw == 16 ? "k_msm_fix<8, 16>" : "k_msm_fix<8, 8>";
 }

@@ -38,7 +38,7 @@ void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std:
   pl.nft = nft;
   pl.fix_wpw = msm_fix_windows_per_wave(opt_, (int)nft, fix_bits_);
   pl.tbl_wpw = msm_tblw_windows_per_wave(opt_, (int)ntt);
-  const uint32_t fix_parts = (uint32_t)(256 / fix_bits_ / pl.fix_wpw), tbl_parts = (uint32_t)msm_tblw_parts(pl.tbl_wpw);
+  const uint32_t fix_parts = (uint32_t)msm_fix_parts(fix_bits_, pl.fix_wpw), tbl_parts = (uint32_t)msm_tblw_parts(pl.tbl_wpw);
   std::vector<TblTask> ht(ntt);
   std::vector<FixTask> hf(nft);
   std::vector<uint32_t> meta(7 * nt);   // pfirst | pcount | dst | comp_index | addends[3]
@@ -696,9 +696,9 @@ void Engine::prepare_device_verifier(size_t rand_stride) {
   for (size_t j = 0; j < NM; j++) all_idx[NI + j] = (uint32_t)(NI + j);   // misc index j == slot j (SL_H .. SL_M, then the proof points)
   const uint32_t* d_all = idx_list(all_idx);
   dv.fix_wpw = msm_fix_windows_per_wave(opt_, (int)B, fix_bits_);
-  dv.fix_parts = 256 / fix_bits_ / dv.fix_wpw;
+  dv.fix_parts = msm_fix_parts(fix_bits_, dv.fix_wpw);
   dv.fix_wpw1 = msm_fix_windows_per_wave(opt_, 1, fix_bits_);
-  dv.fix_parts1 = 256 / fix_bits_ / dv.fix_wpw1;
+  dv.fix_parts1 = msm_fix_parts(fix_bits_, dv.fix_wpw1);
   std::vector<MsmTask> mt(B);
   std::vector<FixTask> ft(B + 1);
   std::vector<uint32_t> gi(B * NPT);

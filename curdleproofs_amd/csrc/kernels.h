@@ -25,7 +25,7 @@ struct Options {
   long table_quad_max = 4096;
   long decompress_quad_max = 2048;
   // host engine (engine.cpp)
-  long fix_bits = 16;              // radix of the fixed-base CRS table of multiples: 16 (17.5 GB at ell = 252) or 8 (0.1 GB); read by set_crs
+  long fix_bits = 16;              // radix of the fixed-base CRS table of multiples: 16 (17.5 GB at ell = 252), 8 (0.1 GB) or 19 (14 windows, 122 GB); read by set_crs
   long device_min_batch = 96;      // batches of at least this many proofs run the whole protocol on the device
   long spin_team = 1;              // 0: no spinning helper threads for small batches
   long spin_team_threads = 8;
@@ -121,7 +121,7 @@ void launch_reduce_sets(const Options& o, const uint32_t* d_raw, const uint32_t*
 // endo = false: copy c = 2^(256 c / C) P.   endo = true (the tables k_msm_tblw reads): copies 0..C/2-1 = 2^(8c) P and
 // copies C/2.. = their endomorphism images -phi(2^(8c) P) = z^2 2^(8c) P (glv.hpp) — half the doublings.
 void launch_table_build(const Options& o, const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
-                        TblTmp* d_tmp, hipStream_t s);
+                        TblTmp* d_tmp, hipStream_t s, int step_bits = 0);   // step_bits > 0: copy c = 2^(step_bits c) P whatever the copy count
 
 // ---- fixed-base MSM over a table of multiples (CRS bases) ----
 // fix_tab[(w*M + (m-1))*nc + i] = m * 2^(c*w) * P_i  (affine), w < W = 256/c windows, m = 1..M = 2^(c-1), i < nc.
@@ -137,12 +137,14 @@ struct FixTask {
   uint32_t out_first;       // first partial slot of this task; it writes W / wpw partials
 };
 int msm_fix_windows_per_wave(const Options& o, int ntasks, int cbits);
+int msm_fix_windows(int cbits);          // ceil(256 / cbits): 32, 16 or (cbits = 19) 14
+int msm_fix_parts(int cbits, int wpw);   // waves (= plain raw sets = partial sums) per task
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TFix* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s);
 // k_msm_fix<16, 2> and k_msm_tblw<2, false> of one phase in ONE launch (a lone proof: neither fills the GPU)
 void launch_msm_fix_tblw(const FixTask* d_ftasks, int nftasks, const TFix* d_fix_tab, int nc, uint32_t* d_fraw, uint32_t* d_fraw_slot, const TblTask* d_ttasks,
                          int nttasks, int slices, uint32_t* d_traw, uint32_t* d_traw_slot, hipStream_t s);
 // shifted copies (from launch_table_build with 256/c copies) -> table of multiples; d_tmp: threads * chunk TblTmp
-void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s);
+void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s, int segs = 1);   // d_tmp: segs x threads x chunk
 // output o = sum of partials [first[o], first[o] + count[o]) -> standard form, normalised + compressed (+ optional affine scatter)
 // d_addends (optional): [n][3] indices into d_aff of affine points (results of earlier phases) to add to output o; ~0u = none
 // d_comp_index (optional): output o's compressed bytes go to d_comp + 48 * d_comp_index[o] instead of d_comp + 48 * o

@@ -527,18 +527,23 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
 constexpr int FIX_CHUNK = 256;
 
 // signed radix-2^c digits (c = 8 or 16) of a canonical scalar; writes the NW digits of windows [w0, w0+NW)
-template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint32_t* k, int w0, int16_t* out, int stride) {
-  constexpr int W = 256 / CB;
+// (CB = 19: 14 windows cover 266 bits, chunks straddle words; digits need 32 bits)
+template <int CB> struct FixDigit { typedef int16_t type; };
+template <> struct FixDigit<19> { typedef int32_t type; };
+template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint32_t* k, int w0, typename FixDigit<CB>::type* out, int stride) {
+  constexpr int W = (256 + CB - 1) / CB;
   constexpr uint32_t HALF = 1u << (CB - 1), FULL = 1u << CB;
   uint32_t carry = 0;
   for (int w = 0; w < W; w++) {
-    const uint32_t chunk = (k[(w * CB) >> 5] >> ((w * CB) & 31)) & (FULL - 1);
+    const int bit = w * CB, wd = bit >> 5;
+    const uint64_t two = (uint64_t)k[wd] | ((uint64_t)(wd + 1 < 8 ? k[wd + 1] : 0u) << 32);
+    const uint32_t chunk = (uint32_t)(two >> (bit & 31)) & (FULL - 1);
     const uint32_t v = chunk + carry;
     // digits in [-2^(c-1), 2^(c-1) - 1]: |d| <= 2^(c-1) indexes the table, and -2^15 still fits int16_t.
     // No carry leaves the top window: scalars are < r < 2^255, so the top chunk is < 2^(c-1) - 1.
     const int d = (v >= HALF) ? (int)v - (int)FULL : (int)v;
     carry = (v >= HALF) ? 1u : 0u;
-    if (w >= w0 && w < w0 + NW) out[(w - w0) * stride] = (int16_t)d;
+    if (w >= w0 && w < w0 + NW) out[(w - w0) * stride] = (typename FixDigit<CB>::type)d;
   }
 }
 
@@ -547,15 +552,18 @@ template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint3
 // per wave double the number of waves when the launch would not fill the GPU otherwise.
 template <int CB, int FIX_WPW> __device__ __forceinline__ void msm_fix_body(const FixTask* __restrict__ tasks, const TFix* __restrict__ tab, int nc,
                                                                           uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot, const uint32_t bid) {
-  constexpr int W = 256 / CB, WG = W / FIX_WPW;    // waves per task
-  constexpr int LPW = 64 / FIX_WPW;                // lanes (point slices) per window
+  constexpr int W = (256 + CB - 1) / CB, WG = W / FIX_WPW;    // waves per task
+  constexpr int LPW = 64 / FIX_WPW;                // lanes (point slices) per window (CB = 19: 7 windows x 9 slices, lane 63 idles)
   constexpr uint32_t M = 1u << (CB - 1);
+  static_assert(W % FIX_WPW == 0, "whole waves per task");
+  typedef typename FixDigit<CB>::type DT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  int16_t* digits = reinterpret_cast<int16_t*>(smem);   // [FIX_WPW][FIX_CHUNK]
+  DT* digits = reinterpret_cast<DT*>(smem);   // [FIX_WPW][FIX_CHUNK]
   const FixTask task = tasks[bid / WG];
   const int wg = bid % WG;
   const int lane = threadIdx.x;
-  const int wl = lane / LPW, sl = lane % LPW;
+  const bool working = lane < FIX_WPW * LPW;
+  const int wl = working ? lane / LPW : 0, sl = lane % LPW;
   const uint32_t w = (uint32_t)(wg * FIX_WPW + wl);
   const TFix* wtab = tab + (size_t)w * M * nc;
   TAcc xacc = TAcc::identity();
@@ -569,11 +577,11 @@ template <int CB, int FIX_WPW> __device__ __forceinline__ void msm_fix_body(cons
       fix_digits<CB, FIX_WPW>(k.v, wg * FIX_WPW, digits + t, FIX_CHUNK);
     }
     __syncthreads();
-    const int16_t* row = digits + wl * FIX_CHUNK;
+    const DT* row = digits + wl * FIX_CHUNK;
     // every lane walks its slice i = sl, sl+LPW, ...: same trip count for all lanes; the gather of the next point is in
     // flight while the current one is added (products inlined)
     auto fetch = [&](int i, int& d) {
-      d = i < m ? row[i] : 0;
+      d = (i < m && working) ? row[i] : 0;
       const uint32_t g = base + i;
       return d ? wtab[(size_t)((d < 0 ? -d : d) - 1) * nc + task.off + (task.idx ? task.idx[g] : g)].a : TAff::identity();
     };
@@ -606,20 +614,30 @@ __global__ __launch_bounds__(64, 2) void k_msm_fix_tblw(const FixTask* __restric
 
 // Table of multiples from the shifted copies: thread per (window, base) walks m = 1..M with mixed additions and
 // normalises `chunk` entries at a time (own Montgomery trick + one inversion per work-group).
-template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* __restrict__ shift, int nc, TFix* __restrict__ tab, TblTmp* __restrict__ tmp, int chunk) {
-  constexpr int W = 256 / CB;
+// (segs > 1: the M multiples of a (window, base) are split over that many threads, each starting from seg * (M / segs) * S.)
+template <int CB> __global__ __launch_bounds__(64) void k_fix_build(const TAff* __restrict__ shift, int nc, TFix* __restrict__ tab, TblTmp* __restrict__ tmp, int chunk,
+                                                                    int segs) {
+  constexpr int W = (256 + CB - 1) / CB;
   constexpr uint32_t M = 1u << (CB - 1);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = g < W * nc;
-  const int w = live ? g / nc : 0, i = live ? g % nc : 0;
+  const bool live = g < W * nc * segs;
+  const int seg = live ? g / (W * nc) : 0, wi = live ? g % (W * nc) : 0;
+  const int w = wi / nc, i = wi % nc;
   const TAff S = live ? shift[(size_t)w * nc + i] : TAff::identity();
   const bool inf = S.is_identity();
   TblTmp* my = tmp + (size_t)g * chunk;
+  const uint32_t per = M / (uint32_t)segs, first = (uint32_t)seg * per;
   TFix* out = tab + (size_t)w * M * nc + i;
   TJac acc = TJac::identity();
-  for (uint32_t m0 = 0; m0 < M; m0 += chunk) {
+  if (live && !inf && first) {   // first * S by double-and-add
+    for (int b = 31; b >= 0; b--) {
+      acc = t_dbl(acc);
+      if ((first >> b) & 1u) acc = t_add_mixed(acc, S);
+    }
+  }
+  for (uint32_t m0 = first; m0 < first + per; m0 += chunk) {
     TF prod = t_one();
     if (live) {
       for (int j = 0; j < chunk; j++) {
@@ -765,7 +783,7 @@ __device__ __forceinline__ void tmp_load(const uint32_t* tmp, size_t nthreads, s
 // of 256 - sb doublings storing every sb-th value; the C-1 Jacobian copies are normalised with the thread's own
 // Montgomery trick plus one inversion per work-group.
 __global__ __launch_bounds__(64) void k_table_build(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
-                                                     int npts, int copy_stride, int copies, int endo, TblTmp* __restrict__ tmp_) {
+                                                     int npts, int copy_stride, int copies, int endo, TblTmp* __restrict__ tmp_, int step_bits) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);
   uint32_t* tmp = reinterpret_cast<uint32_t*>(tmp_);
@@ -774,7 +792,7 @@ __global__ __launch_bounds__(64) void k_table_build(const Aff* __restrict__ src,
   const bool live = g < total;
   // endo: the row holds copies / 2 shifted copies 2^(8c) P followed by their images -phi(.) = (beta x, -y) (glv.hpp)
   const int real = endo ? copies / 2 : copies;
-  const int sb = (endo ? 128 : 256) / real;
+  const int sb = step_bits > 0 ? step_bits : (endo ? 128 : 256) / real;
   const TF beta = t_beta();
   TAff* col = nullptr;
   TF prod = t_one();
@@ -820,7 +838,7 @@ __global__ __launch_bounds__(64) void k_table_build(const Aff* __restrict__ src,
 // wait in LDS instead of the scratch buffer.
 constexpr int TBQ_CHUNK = 4;   // copies per lane: real - 1 <= 16
 __global__ __launch_bounds__(64) void k_table_build_quad(const Aff* __restrict__ src, size_t src_row_stride, TAff* __restrict__ table, int rows, size_t row_stride,
-                                                          int npts, int copy_stride, int copies, int endo) {
+                                                          int npts, int copy_stride, int copies, int endo, int step_bits) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   TF* buf = reinterpret_cast<TF*>(smem);                         // [2 * 64] batch inversion
   TF* pre_s = buf + 2 * 64;                                      // [TBQ_CHUNK][64]
@@ -830,7 +848,7 @@ __global__ __launch_bounds__(64) void k_table_build_quad(const Aff* __restrict__
   const long total = (long)rows * npts;
   const bool live = g < total;
   const int real = endo ? copies / 2 : copies;
-  const int sb = (endo ? 128 : 256) / real;
+  const int sb = step_bits > 0 ? step_bits : (endo ? 128 : 256) / real;
   const TF beta = t_beta();
   TAff* col = nullptr;
   TAff P = TAff::identity();
@@ -1397,7 +1415,7 @@ const OptField kOptFields[] = {
     {"tbw_slices", &Options::tbw_slices, 0, 4},                  {"reduce_wave_max", &Options::reduce_wave_max, -1, 1L << 30},
     {"fix_min_waves", &Options::fix_min_waves, 0, 1L << 30},     {"fix_lat_waves", &Options::fix_lat_waves, 0, 1L << 30},
     {"finalize_wave_max", &Options::finalize_wave_max, 0, 1L << 30}, {"table_quad_max", &Options::table_quad_max, 0, 1L << 30},
-    {"decompress_quad_max", &Options::decompress_quad_max, 0, 1L << 30}, {"fix_bits", &Options::fix_bits, 8, 16},
+    {"decompress_quad_max", &Options::decompress_quad_max, 0, 1L << 30}, {"fix_bits", &Options::fix_bits, 8, 19},
     {"device_min_batch", &Options::device_min_batch, 1, 1L << 30}, {"spin_team", &Options::spin_team, 0, 1},
     {"spin_team_threads", &Options::spin_team_threads, 1, 256},  {"inline_below", &Options::inline_below, 0, 1L << 30},
     {"cu_mask", &Options::cu_mask, 0, 1},                        {"trace", &Options::trace, 0, 1},
@@ -1409,7 +1427,7 @@ bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;
   if (!strcmp(f.key, "tbw_wpw")) return v == 0 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32;
   if (!strcmp(f.key, "tbw_slices")) return v == 0 || v == 1 || v == 2 || v == 4;
-  if (!strcmp(f.key, "fix_bits")) return v == 8 || v == 16;
+  if (!strcmp(f.key, "fix_bits")) return v == 8 || v == 16 || v == 19;
   if (!strcmp(f.key, "late_rounds")) return v == 0 || v == 4;
   if (!strcmp(f.key, "late_slices")) return v == 1 || v == 2 || v == 4 || v == 8;
   return true;
@@ -1569,6 +1587,7 @@ void launch_reduce_sets(const Options& o, const uint32_t* d_raw, const uint32_t*
   }
 }
 int msm_fix_windows_per_wave(const Options& o, int ntasks, int cbits) {
+  if (cbits == 19) return 7;   // 14 windows: two waves per task, 7 windows x 9 point slices each
   const int w = 256 / cbits;
   const long min_waves = o.fix_min_waves;   // default: two waves per SIMD
   if ((long)ntasks * (w / 16) >= min_waves) return 16;
@@ -1581,9 +1600,10 @@ int msm_fix_windows_per_wave(const Options& o, int ntasks, int cbits) {
 }
 void launch_msm_fix(const FixTask* d_tasks, int ntasks, const TFix* d_fix_tab, int cbits, int wpw, int nc, uint32_t* d_raw, uint32_t* d_raw_slot, hipStream_t s) {
   if (ntasks <= 0) return;
-  const size_t lds = 16 * FIX_CHUNK * 2;   // digit rows
-  const dim3 grid(ntasks * (256 / cbits / wpw)), block(64);
-  if (cbits == 16 && wpw == 16) CPX_LAUNCH((k_msm_fix<16, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+  const size_t lds = 16 * FIX_CHUNK * 2;   // digit rows (7 rows of 32-bit digits at 19 bits)
+  const dim3 grid(ntasks * msm_fix_parts(cbits, wpw)), block(64);
+  if (cbits == 19) CPX_LAUNCH((k_msm_fix<19, 7>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
+  else if (cbits == 16 && wpw == 16) CPX_LAUNCH((k_msm_fix<16, 16>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
   else if (cbits == 16 && wpw == 4) CPX_LAUNCH((k_msm_fix<16, 4>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
   else if (cbits == 16 && wpw == 2) CPX_LAUNCH((k_msm_fix<16, 2>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
   else if (cbits == 16) CPX_LAUNCH((k_msm_fix<16, 8>), grid, block, lds, s, d_tasks, d_fix_tab, nc, d_raw, d_raw_slot);
@@ -1597,11 +1617,14 @@ void launch_msm_fix_tblw(const FixTask* d_ftasks, int nftasks, const TFix* d_fix
   CPX_LAUNCH(k_msm_fix_tblw, dim3(nfix_blocks + ntbl_blocks), dim3(64), lds, s, d_ftasks, d_fix_tab, nc, d_fraw, d_fraw_slot, nfix_blocks, d_ttasks, d_traw,
              d_traw_slot, slices);
 }
-void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s) {
-  const int W = 256 / cbits, total = W * nc;
+int msm_fix_windows(int cbits) { return (256 + cbits - 1) / cbits; }
+int msm_fix_parts(int cbits, int wpw) { return msm_fix_windows(cbits) / wpw; }
+void launch_fix_build(const TAff* d_shift, int nc, int cbits, TFix* d_fix_tab, TblTmp* d_tmp, int chunk, hipStream_t s, int segs) {
+  const int W = msm_fix_windows(cbits), total = W * nc * segs;
   const size_t lds = 2 * 64 * sizeof(TF);
-  if (cbits == 16) CPX_LAUNCH(k_fix_build<16>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
-  else CPX_LAUNCH(k_fix_build<8>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk);
+  if (cbits == 19) CPX_LAUNCH(k_fix_build<19>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk, segs);
+  else if (cbits == 16) CPX_LAUNCH(k_fix_build<16>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk, segs);
+  else CPX_LAUNCH(k_fix_build<8>, dim3((total + 63) / 64), dim3(64), lds, s, d_shift, nc, d_fix_tab, d_tmp, chunk, segs);
 }
 void launch_finalize_ranges(const Options& o, const TJac* d_part, const uint32_t* d_first, const uint32_t* d_count, int n, Aff* d_aff, const uint32_t* d_dst_index,
                             uint8_t* d_comp, hipStream_t s, const uint32_t* d_addends, const uint32_t* d_comp_index) {
@@ -1614,7 +1637,7 @@ void launch_finalize_ranges(const Options& o, const TJac* d_part, const uint32_t
   CPX_LAUNCH(k_finalize_ranges, dim3((n + 63) / 64), dim3(64), 2 * 64 * sizeof(TF), s, d_part, d_first, d_count, n, d_aff, d_dst_index, d_comp, d_addends, d_comp_index);
 }
 void launch_table_build(const Options& o, const Aff* d_src, size_t src_row_stride, TAff* d_table, int rows, size_t row_stride, int npts, int copy_stride, int copies, bool endo,
-                        TblTmp* d_tmp, hipStream_t s) {
+                        TblTmp* d_tmp, hipStream_t s, int step_bits) {
   const long total = (long)rows * npts;
   if (total <= 0) return;
   // single-wave work-groups: a 256-thread group of this 241-VGPR kernel only ever got one group per CU (38 ms against 19 ms per
@@ -1625,11 +1648,11 @@ void launch_table_build(const Options& o, const Aff* d_src, size_t src_row_strid
   if (total <= quad_max && real - 1 <= 4 * TBQ_CHUNK) {   // a few rows: quad per base point
     const size_t lds = (2 * 64 + TBQ_CHUNK * 64) * sizeof(TF) + TBQ_CHUNK * 64 * sizeof(TJac);
     CPX_LAUNCH(k_table_build_quad, dim3((unsigned)((total + 15) / 16)), dim3(blk), lds, s, d_src, src_row_stride, d_table, rows, row_stride, npts, copy_stride, copies,
-               endo ? 1 : 0);
+               endo ? 1 : 0, step_bits);
     return;
   }
   CPX_LAUNCH(k_table_build, dim3((unsigned)((total + blk - 1) / blk)), dim3(blk), 2 * blk * sizeof(TF), s, d_src, src_row_stride, d_table, rows, row_stride, npts,
-                     copy_stride, copies, endo ? 1 : 0, d_tmp);
+                     copy_stride, copies, endo ? 1 : 0, d_tmp, step_bits);
 }
 void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_index, uint8_t* d_comp, hipStream_t s, const uint32_t* d_addend_index) {
   if (n <= 0) return;

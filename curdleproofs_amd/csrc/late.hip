@@ -36,7 +36,7 @@ namespace {
 // exactly as k_msm_fix recodes them: carry into the next window when a chunk reaches 2^(CB-1)).  The scalar sits in a shift
 // register, so the loop stays rolled with static register indices: ONE copy of the addition per call site.
 template <int CB, bool INL> __device__ __forceinline__ TAcc late_fix_accumulate(TAcc acc, const Fr& mont, const TFix* __restrict__ tab, int nc, uint32_t col) {
-  constexpr int W = 256 / CB;
+  constexpr int W = (256 + CB - 1) / CB;
   constexpr uint32_t M = 1u << (CB - 1), HALF = 1u << (CB - 1), FULL = 1u << CB;
   Fr k = fe_from_mont(mont);
   uint32_t carry = 0;
@@ -316,7 +316,8 @@ void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, i
                      int nproofs, hipStream_t s) {
   const int total = nproofs * m;
   if (total <= 0) return;
-  if (cbits == 16) LATE_LAUNCH(k_late_fix<16>, dim3((total + 63) / 64), dim3(64), 0, s, d_scal, sstride, d_cols, n, m, d_fix_tab, nc, d_out, ostride, total);
+  if (cbits == 19) LATE_LAUNCH(k_late_fix<19>, dim3((total + 63) / 64), dim3(64), 0, s, d_scal, sstride, d_cols, n, m, d_fix_tab, nc, d_out, ostride, total);
+  else if (cbits == 16) LATE_LAUNCH(k_late_fix<16>, dim3((total + 63) / 64), dim3(64), 0, s, d_scal, sstride, d_cols, n, m, d_fix_tab, nc, d_out, ostride, total);
   else LATE_LAUNCH(k_late_fix<8>, dim3((total + 63) / 64), dim3(64), 0, s, d_scal, sstride, d_cols, n, m, d_fix_tab, nc, d_out, ostride, total);
 }
 void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, size_t ptab_proof_stride, int NP, const TAff* d_ctab, int nc, const uint32_t* d_gb_cols, int n,

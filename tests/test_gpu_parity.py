@@ -526,6 +526,8 @@ def test_fused_batch_verifier_many_points(ctx, orc, ell, nproofs):
 THROUGHPUT = {"fix_min_waves": 1, "tbw_wpw": 32, "reduce_wave_max": 0, "finalize_wave_max": 0, "tail_wave_max": 0, "table_quad_max": 0, "decompress_quad_max": 0}
 VARIANTS = {
     "fix8": {"fix_bits": 8},
+    "fix19": {"fix_bits": 19},                                  # 14 windows of 19 bits, 122 GB table at ell = 252 (falls back to 16 when HBM is short)
+    "fix19_late_rounds_throughput_kernels": {"fix_bits": 19, "late_min_batch": 1, "device_min_batch": 1, "fix_min_waves": 1, "reduce_wave_max": 0},
     "device_resident": {"device_min_batch": 1},
     "host_driven": {"device_min_batch": 1000000},
     "throughput_kernels": THROUGHPUT,

@@ -581,7 +581,7 @@ def main():
                                                "(the per-GPU share on 8 GPUs) and 1024 proofs on one GPU" % ell, **shapes)
             if ell == 252:   # BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
                 try:
-                    e3, b3 = 1020, 1024   # enough proofs to fill the GPU (256 proofs per pass under-reported the path: 1.6 k against 2.5+ k proofs/s)
+                    e3, b3 = 1020, 2048   # enough proofs to fill the GPU (256 proofs per pass: 1.6 k, 1024: 2.8 k, 2048: 3.5 k proofs/s)
                     d3 = synth_batch(c0, e3, b3, seed=4321)
                     c0.load_batch(d3["vec_R"], d3["vec_S"], d3["vec_T"], d3["vec_U"], d3["M"])
                     a3 = [c0.marshal(d3[k_]) for k_ in ("perms", "k", "mbl", "prand", "vrand")]

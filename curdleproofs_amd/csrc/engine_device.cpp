@@ -306,8 +306,9 @@ void Engine::prepare_device_prover() {
   // the last four rounds of a large batch work on 16 materialised folded bases per family instead (late.hip)
   DevProver::Late& lt = dp.late;
   lt.m = 16;
-  // (late_min_batch is stated for n = 256: the grids the decision is about grow with the proof size)
-  lt.on = opt_.late_rounds == 4 && L >= 5 && B * n >= (size_t)opt_.late_min_batch * 256 && late_supported((int)n, lt.m) && 4 * lt.m <= 64;
+  // (late_min_batch is stated for n <= 256; larger proofs have larger grids per proof: the threshold shrinks with 256 / n)
+  const size_t late_min = n <= 256 ? (size_t)opt_.late_min_batch : std::max<size_t>(1, (size_t)opt_.late_min_batch * 256 / n);
+  lt.on = opt_.late_rounds == 4 && L >= 5 && B >= late_min && late_supported((int)n, lt.m) && 4 * lt.m <= 64;
   lt.j0 = lt.on ? L - 4 : L;
   for (size_t j = 0; j < L; j++) {
     if (j >= lt.j0) {   // placeholders: exec_late_round takes these rounds

@@ -33,7 +33,7 @@ struct Options {
   long cu_mask = 1;                // 0: plain instead of CU-masked streams for the lone-proof prover
   long trace = 0;                  // 1: print the challenges of proof 0 to stderr (debugging aid)
   long late_rounds = 4;            // 4: the last four log rounds of a large batch run on materialised folded bases (late.hip); 0: all-MSM everywhere
-  long late_min_batch = 2048;      // ... for batches of at least this many proofs at n = 256 (scaled by 256 / n: 512 at ell = 1020); the lane-per-output kernels need a full GPU to pay
+  long late_min_batch = 2048;      // ... for batches of at least this many proofs (n <= 256; scaled by 256 / n above: 512 at ell = 1020); the lane-per-output kernels need a full GPU to pay
   long late_slices = 8;            // lanes per cross term of a late round (1, 2, 4, 8): 15.3 k proofs/s at 8, 14.9 k at 4 and 2, 14.3 k at 1
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
 };

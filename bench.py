@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16384, help="instances per GPU per step (16 x the BASELINE configs[3] batch, split over the engine contexts: 8192 per context; 8192 per step measured 3 % lower: the latency-bound kernels of a pass amortise over fewer proofs)")
+    ap.add_argument("--batch", type=int, default=16384, help="instances per GPU per step (16 x the BASELINE configs[3] batch, split over the engine contexts: 8192 per context; 8192 per step measured 3 %% lower: the latency-bound kernels of a pass amortise over fewer proofs)")
     ap.add_argument("--ell", type=int, default=252)
     ap.add_argument("--fused-verify", action="store_true", help="measure BASELINE config 5 instead: the batched verifier (one accumulated MSM over "
                     "all proofs of all GPUs, one all-gather of 144-byte partial sums); not the headline metric")

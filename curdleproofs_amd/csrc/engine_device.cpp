@@ -368,7 +368,7 @@ void Engine::prepare_device_prover() {
     lt.h_col = iH;
     lt.part.ensure(6 * B * (size_t)opt_.late_slices);
     lt.extra.ensure(4 * B);
-    CPX_HIP(hipMemset(lt.extra.p, 0, 4 * B * sizeof(TJac)));   // all-zero = the identity: the outputs without a CRS term keep it
+    CPX_HIP(hipMemsetAsync(lt.extra.p, 0, 4 * B * sizeof(TJac), stream_));   // all-zero = the identity: the outputs without a CRS term keep it (ordered before the prove's launches on this stream)
     lt.ipa.clear();
     lt.smsm.clear();
     lt.ipa_comp.clear();

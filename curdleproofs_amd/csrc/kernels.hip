@@ -526,27 +526,13 @@ template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void
 // ------------------------------------------------------------------ fixed-base MSM over multiples tables
 constexpr int FIX_CHUNK = 256;
 
-// signed radix-2^c digits (c = 8 or 16) of a canonical scalar; writes the NW digits of windows [w0, w0+NW)
-// (CB = 19: 14 windows cover 266 bits, chunks straddle words; digits need 32 bits)
+// signed radix-2^c digits of a canonical scalar (recode.hpp); writes the NW digits of windows [w0, w0+NW).  Digits in
+// [-2^(c-1), 2^(c-1) - 1]: |d| indexes the table, -2^15 still fits int16_t; 19-bit digits need 32 bits
 template <int CB> struct FixDigit { typedef int16_t type; };
 template <> struct FixDigit<19> { typedef int32_t type; };
 template <int CB, int NW> __device__ __forceinline__ void fix_digits(const uint32_t* k, int w0, typename FixDigit<CB>::type* out, int stride) {
-  constexpr int W = (256 + CB - 1) / CB;
-  constexpr uint32_t HALF = 1u << (CB - 1), FULL = 1u << CB;
-  uint32_t carry = 0;
-  for (int w = 0; w < W; w++) {
-    const int bit = w * CB, wd = bit >> 5;
-    const uint64_t two = (uint64_t)k[wd] | ((uint64_t)(wd + 1 < 8 ? k[wd + 1] : 0u) << 32);
-    const uint32_t chunk = (uint32_t)(two >> (bit & 31)) & (FULL - 1);
-    const uint32_t v = chunk + carry;
-    // digits in [-2^(c-1), 2^(c-1) - 1]: |d| <= 2^(c-1) indexes the table, and -2^15 still fits int16_t.
-    // No carry leaves the top window: scalars are < r < 2^255, so the top chunk is < 2^(c-1) - 1.
-    const int d = (v >= HALF) ? (int)v - (int)FULL : (int)v;
-    carry = (v >= HALF) ? 1u : 0u;
-    if (w >= w0 && w < w0 + NW) out[(w - w0) * stride] = (typename FixDigit<CB>::type)d;
-  }
+  fix_window_digits<CB, NW>(k, w0, out, stride);   // recode.hpp (host + device: checked on the CPU by tests/test_host_emul.py)
 }
-
 // One wave = FIX_WPW windows x (64 / FIX_WPW) point slices of one task.  16 windows per wave (a whole radix-2^16
 // task) keeps the fixed 6-step tree reduction small against the per-lane additions (n/4 per lane); 8 windows
 // per wave double the number of waves when the launch would not fill the GPU otherwise.

@@ -26,6 +26,7 @@
 #include "g1.hpp"
 #include "g1_28.hpp"
 #include "glv.hpp"
+#include "recode.hpp"
 #include "kernels.h"
 #include "block_inverse.hpp"
 
@@ -36,17 +37,11 @@ namespace {
 // exactly as k_msm_fix recodes them: carry into the next window when a chunk reaches 2^(CB-1)).  The scalar sits in a shift
 // register, so the loop stays rolled with static register indices: ONE copy of the addition per call site.
 template <int CB, bool INL> __device__ __forceinline__ TAcc late_fix_accumulate(TAcc acc, const Fr& mont, const TFix* __restrict__ tab, int nc, uint32_t col) {
-  constexpr int W = (256 + CB - 1) / CB;
-  constexpr uint32_t M = 1u << (CB - 1), HALF = 1u << (CB - 1), FULL = 1u << CB;
-  Fr k = fe_from_mont(mont);
-  uint32_t carry = 0;
-  auto next_digit = [&]() {
-    const uint32_t v = (k.v[0] & (FULL - 1)) + carry;
-    CPX_UNROLL for (int j = 0; j < 7; j++) k.v[j] = (k.v[j] >> CB) | (k.v[j + 1] << (32 - CB));
-    k.v[7] >>= CB;
-    carry = (v >= HALF) ? 1u : 0u;
-    return (v >= HALF) ? (int)v - (int)FULL : (int)v;
-  };
+  constexpr int W = FixWin<CB>::W;
+  constexpr uint32_t M = 1u << (CB - 1);
+  const Fr kc = fe_from_mont(mont);
+  FixDigitStream<CB> ds(kc.v);   // recode.hpp
+  auto next_digit = [&]() { return ds.next(); };
   auto fetch = [&](int w, int d) { return d ? tab[((size_t)w * M + (size_t)((d < 0 ? -d : d) - 1)) * nc + col].a : TAff::identity(); };
   int dn = next_digit();
   TAff pn = fetch(0, dn);
@@ -247,17 +242,8 @@ __global__ __launch_bounds__(64, 2) void k_late_msm(const LateRound r) {
     glv_split(k.v, h[0], h[1], nk, ntg);
     signs |= ((nk ^ ntg) << (2 * s)) | (nk << (2 * s + 1));
     CPX_UNROLL for (int hf = 0; hf < 2; hf++) {
-      // signed radix-16 digits in [-7, 8] of a value < 2^127, stored biased by 7, eight per word; no carry leaves nibble 31
-      uint32_t carry = 0, packed[4];
-      CPX_UNROLL for (int wd = 0; wd < 4; wd++) {
-        packed[wd] = 0;
-        CPX_UNROLL for (int q = 0; q < 8; q++) {
-          const uint32_t v = ((h[hf][wd] >> (4 * q)) & 15u) + carry;   // 0 .. 16
-          const int d = v > 8 ? (int)v - 16 : (int)v;
-          carry = v > 8 ? 1u : 0u;
-          packed[wd] |= (uint32_t)(d + 7) << (4 * q);
-        }
-      }
+      uint32_t packed[4];
+      recode_signed_nibbles_biased(h[hf], packed);   // recode.hpp: signed radix-16 digits in [-7, 8], biased by 7, eight per word
       // keep the words that hold this slice's windows
       for (int x = 0; x < wph; x++) {
         uint32_t word = 0;

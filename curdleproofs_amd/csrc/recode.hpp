@@ -45,4 +45,54 @@ CPX_HD void recode_naf(const uint32_t* k, uint32_t* nz /*9*/, uint32_t* ng /*9*/
   }
 }
 
+// ---- fixed-base windows (k_msm_fix, k_late_fix): signed radix-2^CB digits of a canonical scalar k < 2^255 ----
+// k = sum_w d_w 2^(CB w),  d_w in [-2^(CB-1), 2^(CB-1) - 1],  W = ceil(256 / CB) windows (CB = 8: 32, 16: 16, 19: 14 covering 266 bits);
+// |d| indexes the table of multiples (entry |d| - 1).  No carry leaves the top window: k < r < 2^255.
+template <int CB> struct FixWin {
+  static constexpr int W = (256 + CB - 1) / CB;
+  static constexpr uint32_t HALF = 1u << (CB - 1), FULL = 1u << CB;
+};
+// digit stream from a shift register: next() returns d_0, d_1, ... (rolled loops with static register indices on the device)
+template <int CB> struct FixDigitStream {
+  uint32_t v[8];
+  uint32_t carry;
+  CPX_HD explicit FixDigitStream(const uint32_t* k) : carry(0) {
+    CPX_UNROLL for (int j = 0; j < 8; j++) v[j] = k[j];
+  }
+  CPX_HD int next() {
+    const uint32_t x = (v[0] & (FixWin<CB>::FULL - 1)) + carry;
+    CPX_UNROLL for (int j = 0; j < 7; j++) v[j] = (v[j] >> CB) | (v[j + 1] << (32 - CB));
+    v[7] >>= CB;
+    carry = (x >= FixWin<CB>::HALF) ? 1u : 0u;
+    return (x >= FixWin<CB>::HALF) ? (int)x - (int)FixWin<CB>::FULL : (int)x;
+  }
+};
+// the NW digits of windows [w0, w0 + NW) written to out[(w - w0) * stride] (DT: int16_t up to CB = 16, int32_t above)
+template <int CB, int NW, class DT> CPX_HD void fix_window_digits(const uint32_t* k, int w0, DT* out, int stride) {
+  uint32_t carry = 0;
+  for (int w = 0; w < FixWin<CB>::W; w++) {
+    const int bit = w * CB, wd = bit >> 5;
+    const uint64_t two = (uint64_t)k[wd] | ((uint64_t)(wd + 1 < 8 ? k[wd + 1] : 0u) << 32);   // a chunk may straddle two words
+    const uint32_t x = ((uint32_t)(two >> (bit & 31)) & (FixWin<CB>::FULL - 1)) + carry;
+    const int d = (x >= FixWin<CB>::HALF) ? (int)x - (int)FixWin<CB>::FULL : (int)x;
+    carry = (x >= FixWin<CB>::HALF) ? 1u : 0u;
+    if (w >= w0 && w < w0 + NW) out[(w - w0) * stride] = (DT)d;
+  }
+}
+
+// ---- late rounds (k_late_msm): signed radix-16 digits in [-7, 8] of a value v < 2^127 (an endomorphism half), biased by 7 and
+// packed eight per word: v = sum_j (nibble_j - 7) 16^j, j < 32; no carry leaves nibble 31 ----
+CPX_HD void recode_signed_nibbles_biased(const uint32_t* v /*4*/, uint32_t* packed /*4*/) {
+  uint32_t carry = 0;
+  CPX_UNROLL for (int wd = 0; wd < 4; wd++) {
+    packed[wd] = 0;
+    CPX_UNROLL for (int q = 0; q < 8; q++) {
+      const uint32_t x = ((v[wd] >> (4 * q)) & 15u) + carry;   // 0 .. 16
+      const int d = x > 8 ? (int)x - 16 : (int)x;
+      carry = x > 8 ? 1u : 0u;
+      packed[wd] |= (uint32_t)(d + 7) << (4 * q);
+    }
+  }
+}
+
 }  // namespace cpx

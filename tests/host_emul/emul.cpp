@@ -479,6 +479,156 @@ void emul_msm_endo(const uint8_t* bases, const uint8_t* scalars, size_t n, int p
   memcpy(out, &r, sizeof r);
 }
 
+// ---- late rounds (late.hip), in the kernels' own arithmetic and with the product's recodings (recode.hpp) ----
+// Fixed-base digit recodings: for every scalar the W = ceil(256 / cb) digits of FixDigitStream<cb> (k_late_fix) and of
+// fix_window_digits<cb> (k_msm_fix) as int32, stream first: out[i][2][32]
+}  // extern "C" (templates below)
+template <int CB> static void fix_digits_both(const uint32_t* k, int32_t* o) {
+  FixDigitStream<CB> ds(k);
+  for (int w = 0; w < FixWin<CB>::W; w++) o[w] = ds.next();
+  if (CB <= 16) {
+    int16_t d[32];
+    fix_window_digits<CB, FixWin<CB>::W>(k, 0, d, 1);
+    for (int w = 0; w < FixWin<CB>::W; w++) o[32 + w] = d[w];
+  } else {
+    fix_window_digits<CB, FixWin<CB>::W>(k, 0, o + 32, 1);
+  }
+}
+extern "C" {
+int emul_fix_digits(int cb, const uint8_t* k, size_t n, int32_t* out) {
+  for (size_t i = 0; i < n; i++) {
+    uint32_t w[8];
+    memcpy(w, k + 32 * i, 32);
+    int32_t* o = out + 64 * i;
+    memset(o, 0, 64 * sizeof(int32_t));
+    if (cb == 8) fix_digits_both<8>(w, o);
+    else if (cb == 16) fix_digits_both<16>(w, o);
+    else if (cb == 19) fix_digits_both<19>(w, o);
+    else return -1;
+  }
+  return cb == 8 ? FixWin<8>::W : cb == 16 ? FixWin<16>::W : FixWin<19>::W;
+}
+// signed radix-16 digits of values < 2^127 (16 bytes each): out[i][32] = digit in [-7, 8]
+void emul_signed_nibbles(const uint8_t* v, size_t n, int8_t* out) {
+  for (size_t i = 0; i < n; i++) {
+    uint32_t w[4], packed[4];
+    memcpy(w, v + 16 * i, 16);
+    recode_signed_nibbles_biased(w, packed);
+    for (int j = 0; j < 32; j++) out[32 * i + j] = (int8_t)((int)((packed[j >> 3] >> (4 * (j & 7))) & 15u) - 7);
+  }
+}
+namespace {
+// table row of a point as k_table_build (endo) leaves it: 16 shifted copies 2^(8c) P and their images (beta x, -y)
+void emul_shifted_row(const Aff& P, TAff* row /*32*/) {
+  const TF beta = t_beta();
+  const TAff p0 = t_from_std(P);
+  const bool inf = p0.is_identity();
+  TJac acc = TJac::from_affine(p0);
+  for (int c = 0; c < 16; c++) {
+    TAff a = p0;
+    if (c && !inf) {
+      for (int d = 0; d < 8; d++) acc = t_dbl(acc);
+      a = t_to_affine(acc, t_inv(acc.z));
+    }
+    row[c] = a;
+    row[16 + c] = inf ? a : TAff{t_mul(a.x, beta), t_neg(a.y)};
+  }
+}
+}  // namespace
+// k_late_uniform for ONE output: sum_t S_t * P_t with the shared digit sequence — entries (t, copy) counting-sorted by |digit|
+// (descending), `split` lanes taking every split-th entry of a level, each with its own running sum and total, totals added.
+void emul_late_uniform(const uint8_t* bases, const uint8_t* scalars, size_t nt, int split, uint8_t* out) {
+  const Aff* P = reinterpret_cast<const Aff*>(bases);
+  std::vector<TAff> rows(32 * nt);
+  for (size_t t = 0; t < nt; t++) emul_shifted_row(P[t], &rows[32 * t]);
+  std::vector<std::vector<uint32_t>> level(129);   // entries per magnitude: (t << 6) | (copy << 1) | neg
+  for (size_t t = 0; t < nt; t++) {
+    Fr k;
+    memcpy(k.v, scalars + 32 * t, 32);
+    k = fe_from_mont(k);
+    uint32_t tt[4], qq[4], bytes[8], nk, ntg;
+    glv_split(k.v, tt, qq, nk, ntg);
+    glv_biased_bytes(tt, bytes);
+    glv_biased_bytes(qq, bytes + 4);
+    for (int c = 0; c < 32; c++) {
+      const int d = (int)((bytes[c >> 2] >> (8 * (c & 3))) & 255u) - 128;
+      if (!d) continue;
+      const uint32_t neg = (d < 0 ? 1u : 0u) ^ (c < 16 ? (nk ^ ntg) : nk);
+      level[d < 0 ? -d : d].push_back(((uint32_t)t << 6) | ((uint32_t)c << 1) | neg);
+    }
+  }
+  std::vector<TAcc> acc(split, TAcc::identity()), total(split, TAcc::identity());
+  size_t pos = 0;
+  for (int b = 128; b >= 1; b--) {
+    const size_t c = level[b].size();
+    for (int sub = 0; sub < split; sub++) {
+      for (size_t e = (size_t)sub; e < c; e += (size_t)split) {
+        const uint32_t en = level[b][e];
+        acc[sub] = t_acc_add_mixed(acc[sub], t_cneg(rows[32 * (en >> 6) + ((en >> 1) & 31u)], (en & 1u) != 0));
+      }
+      if (pos + c) total[sub] = t_acc_add(total[sub], acc[sub]);
+    }
+    pos += c;
+  }
+  TAcc sum = total[0];
+  for (int sub = 1; sub < split; sub++) sum = t_acc_add(sum, total[sub]);
+  const Jac r = t_jac_to_std(t_acc_to_jac(sum));
+  memcpy(out, &r, sizeof r);
+}
+// k_late_tables + k_late_msm + k_msm_tail for ONE output: multiples 1..8 of every point and their images, Straus over the
+// endomorphism-split scalars with signed 4-bit digits, the 32 windows in `slices` groups joined by a Horner chain.
+void emul_late_msm(const uint8_t* bases, const uint8_t* scalars, size_t n, int slices, uint8_t* out) {
+  const Aff* P = reinterpret_cast<const Aff*>(bases);
+  const TF beta = t_beta();
+  std::vector<TAff> tab(16 * n);
+  for (size_t i = 0; i < n; i++) {
+    const TJac P0 = TJac::from_affine(t_from_std(P[i]));
+    TJac m[8];
+    for (int j = 0; j < 8; j++) m[j] = j == 0 ? P0 : (j & 1) ? t_dbl(m[j / 2]) : t_add(m[j - 1], P0);
+    for (int j = 0; j < 8; j++) {
+      const TAff a = m[j].is_identity() ? TAff::identity() : t_to_affine(m[j], t_inv(m[j].z));
+      tab[16 * i + j] = a;
+      tab[16 * i + 8 + j] = a.is_identity() ? a : TAff{t_mul(a.x, beta), t_neg(a.y)};
+    }
+  }
+  std::vector<uint32_t> dig(8 * n);
+  std::vector<uint32_t> sign(2 * n);
+  for (size_t i = 0; i < n; i++) {
+    Fr k;
+    memcpy(k.v, scalars + 32 * i, 32);
+    k = fe_from_mont(k);
+    uint32_t h[2][4], nk, ntg;
+    glv_split(k.v, h[0], h[1], nk, ntg);
+    sign[2 * i] = nk ^ ntg;
+    sign[2 * i + 1] = nk;
+    recode_signed_nibbles_biased(h[0], &dig[8 * i]);
+    recode_signed_nibbles_biased(h[1], &dig[8 * i + 4]);
+  }
+  const int ws = 32 / slices;
+  std::vector<TJac> part(slices);
+  for (int sl = 0; sl < slices; sl++) {
+    TAcc acc = TAcc::identity();
+    for (int win = sl * ws + ws - 1; win >= sl * ws; win--) {
+      if (win != sl * ws + ws - 1)
+        for (int q = 0; q < 4; q++) acc = t_acc_dbl(acc);
+      for (size_t sh = 0; sh < 2 * n; sh++) {
+        const int d = (int)((dig[4 * sh + (win >> 3)] >> (4 * (win & 7))) & 15u) - 7;
+        if (!d) continue;
+        const bool neg = (d < 0) != (sign[sh] != 0);
+        acc = t_acc_add_mixed(acc, t_cneg(tab[16 * (sh >> 1) + 8 * (sh & 1) + (d < 0 ? -d : d) - 1], neg));
+      }
+    }
+    part[sl] = t_acc_to_jac(acc);
+  }
+  TJac res = part[slices - 1];   // k_msm_tail: group = slices, shift = 128 / slices
+  for (int j = slices - 2; j >= 0; j--) {
+    for (int d = 0; d < 128 / slices; d++) res = t_dbl(res);
+    res = t_add(res, part[j]);
+  }
+  const Jac r = t_jac_to_std(res);
+  memcpy(out, &r, sizeof r);
+}
+
 // The reduction programs of k_reduce_sets_wave (quad_program.hpp: the tables the GPU runs) interpreted over integers: a point is
 // a number, an addition a sum, a doubling a product by two.  kind 0 = plain, 1 = bucket set (lower half), 2 = upper half.
 // out[0] = the result, out[1] = rounds, out[2] = addition rounds, out[3] = hazards (a job reading an entry another job of the

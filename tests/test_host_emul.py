@@ -46,6 +46,13 @@ def emul():
     L.emul_quad_program.restype = None
     L.emul_thread_helpers.argtypes = [ctypes.c_int, sz, sz, sz, ctypes.c_long]
     L.emul_thread_helpers.restype = ctypes.c_int
+    L.emul_fix_digits.argtypes = [ctypes.c_int, vp, sz, vp]
+    L.emul_signed_nibbles.argtypes = [vp, sz, vp]
+    L.emul_signed_nibbles.restype = None
+    L.emul_late_uniform.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+    L.emul_late_uniform.restype = None
+    L.emul_late_msm.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+    L.emul_late_msm.restype = None
     return L
 
 
@@ -425,3 +432,70 @@ def test_thread_helpers_visit_every_item_once(emul, kind):
     for threads, n, jobs in ((4, 7, 300), (8, 3, 300), (3, 1, 50), (2, 64, 100), (8, 31, 200)):
         assert emul.emul_thread_helpers(kind, threads, n, jobs, -1) == 0, (threads, n, jobs)
     assert emul.emul_thread_helpers(kind, 4, 9, 40, 17) == 0
+
+
+@pytest.mark.parametrize("cb", [8, 16, 19])
+def test_fixed_base_digit_recodings(emul, cb):
+    """recode.hpp: the signed radix-2^cb digits k_msm_fix (fix_window_digits) and k_late_fix (FixDigitStream) index the table of
+    multiples with — both forms agree, reconstruct the scalar, stay in [-2^(cb-1), 2^(cb-1) - 1], and the top window carries nothing
+    out (cb = 19: 14 windows over 266 bits, chunks straddling words)."""
+    import random
+    rnd = random.Random(19 * cb)
+    vals = [0, 1, R - 1, (R - 1) // 2, (1 << (cb - 1)) - 1, 1 << (cb - 1), (1 << cb) - 1, 1 << cb, (1 << 254) + 12345] + [rnd.randrange(R) for _ in range(200)]
+    vals += [sum(((1 << (cb - 1)) - (j & 1)) << (cb * j) for j in range(255 // cb)) % R]      # every chunk at / just below the carry threshold
+    blob = b"".join(v.to_bytes(32, "little") for v in vals)
+    out = (ctypes.c_int32 * (64 * len(vals)))()
+    W = emul.emul_fix_digits(cb, _b(blob), len(vals), out)
+    assert W == -(-256 // cb)
+    for i, k in enumerate(vals):
+        stream, windows = list(out[64 * i:64 * i + W]), list(out[64 * i + 32:64 * i + 32 + W])
+        assert stream == windows, hex(k)
+        assert all(-(1 << (cb - 1)) <= d < (1 << (cb - 1)) for d in stream)
+        assert sum(d << (cb * w) for w, d in enumerate(stream)) == k, hex(k)
+
+
+def test_signed_nibble_recoding(emul):
+    """recode.hpp recode_signed_nibbles_biased (k_late_msm): 32 digits in [-7, 8] reconstructing any value below 2^127"""
+    import random
+    rnd = random.Random(4)
+    vals = [0, 1, 8, 9, 15, 16, (1 << 127) - 1, int("8" * 31, 16), int("9" * 31, 16), int("7" + "f" * 31, 16)] + [rnd.randrange(1 << 127) for _ in range(300)]
+    out = (ctypes.c_int8 * (32 * len(vals)))()
+    emul.emul_signed_nibbles(_b(b"".join(v.to_bytes(16, "little") for v in vals)), len(vals), out)
+    for i, v in enumerate(vals):
+        d = list(out[32 * i:32 * i + 32])
+        assert all(-7 <= x <= 8 for x in d) and sum(x << (4 * j) for j, x in enumerate(d)) == v, hex(v)
+
+
+@pytest.mark.parametrize("nt,split", [(2, 1), (16, 1), (16, 2), (5, 2)])
+def test_late_uniform_schedule_matches_oracle_msm(emul, orc, nt, split):
+    """k_late_uniform's algorithm for one output (late.hip): the shared digit sequence of the fold coefficients sorted by magnitude,
+    running sums folded into totals once per magnitude, `split` lanes per output — equals the MSM  sum_t S_t P_t  of the oracle, incl.
+    an identity point, equal points, zero / unit / r - 1 coefficients."""
+    rng = orc.rng(1000 + nt + split)
+    bases = bytearray(rng.g1_affine(nt))
+    scalars = bytearray(rng.fr(nt))
+    one, zero = orc.fr_from_u64(1), bytes(32)
+    scalars[:32] = one
+    scalars[32:64] = orc.fr_from_canonical_bytes((R - 1).to_bytes(32, "little"))
+    if nt > 4:
+        scalars[64:96] = zero
+        bases[3 * AFF:4 * AFF] = bytes(AFF)                   # the point at infinity
+        bases[4 * AFF:5 * AFF] = bases[0:AFF]                 # a repeated point
+    out = _o(JAC)
+    emul.emul_late_uniform(_b(bytes(bases)), _b(bytes(scalars)), nt, split, out)
+    assert orc.g1_compress_jac(bytes(out)) == orc.g1_compress_jac(orc.g1_msm(bytes(bases), bytes(scalars)))
+
+
+@pytest.mark.parametrize("n,slices", [(8, 1), (8, 8), (8, 4), (1, 2), (3, 8)])
+def test_late_msm_straus_matches_oracle_msm(emul, orc, n, slices):
+    """k_late_tables + k_late_msm + k_msm_tail for one output: multiples 1..8 and their endomorphism images, signed 4-bit digits of both
+    scalar halves, the windows in `slices` groups joined by the Horner chain — equals the oracle's MSM."""
+    rng = orc.rng(2000 + n + slices)
+    bases, scalars = bytearray(rng.g1_affine(n)), bytearray(rng.fr(n))
+    scalars[:32] = orc.fr_from_canonical_bytes((R - 1).to_bytes(32, "little"))
+    if n > 2:
+        scalars[32:64] = bytes(32)
+        bases[2 * AFF:3 * AFF] = bases[0:AFF]
+    out = _o(JAC)
+    emul.emul_late_msm(_b(bytes(bases)), _b(bytes(scalars)), n, slices, out)
+    assert orc.g1_compress_jac(bytes(out)) == orc.g1_compress_jac(orc.g1_msm(bytes(bases), bytes(scalars)))

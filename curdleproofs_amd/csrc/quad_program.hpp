@@ -10,7 +10,11 @@ namespace cpx {
 struct QuadJob {
   uint8_t a, b, dst, on;
 };
-constexpr int QP_ROW = 64, QP_COL = 96, QP_T = 128, QP_P = 140, QP_IDENT = 144, QP_ENTRIES = 145, QP_MAX_ROUNDS = 20;
+// Entry map (97 entries = 21.7 KB of LDS per wave: 7 waves per CU; the first layout kept every stage in fresh entries, 145 = 32.5 KB:
+// 4 waves per CU): inputs 0..63; the column tree overwrites its own first operand (entries 0..31: the row tree, which runs in the
+// rounds before, has read them by then), the row tree lives in 64..95, the bit sums T and the plain sums P in the inputs that are
+// dead after the first level (32..47), one entry that always holds the identity.
+constexpr int QP_ROW = 64, QP_COL = 0, QP_T = 32, QP_P = 44, QP_IDENT = 96, QP_ENTRIES = 97, QP_MAX_ROUNDS = 20;
 struct QuadProgram {
   int nrounds;
   int result;

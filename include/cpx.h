@@ -62,7 +62,7 @@ void cpx_host_free(void* p);
 
 /* crs.rs:37-58 `CurdleproofsCrs::from_points(ell, points)`: ell + 7 affine points in the order
  * vec_G[ell] | vec_H[4] | H | G_t | G_u.  Uploads them, computes G_sum / H_sum on the device and builds the fixed-base
- * tables (radix 2^16: 15 GB at ell = 252; falls back to radix 2^8 when free HBM is short).  `n_points` is the number of
+ * tables (option "fix_bits": radix 2^16 by default, 17.5 GB at ell = 252; 2^19 = 122 GB; falls back 19 -> 16 -> 8 when free HBM is short).  `n_points` is the number of
  * points behind `points`: fewer than ell + 7 is the reference's "not enough points" error (crs.rs:40-42) ->
  * CPX_ERR_ARG; surplus points are ignored, as the reference's slicing does.  On failure the context holds no CRS. */
 int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points, size_t n_points);

@@ -51,29 +51,44 @@ def build_variant(name, defines, verbose=False):
 
 
 def build(force=False, verbose=False):
+    """Builds libcpx.so if any source is newer.  Concurrent callers (a test session and a manual build, several ranks starting at
+    once) are serialised by a lock file, objects go to a directory of their own per build and the finished library is moved into
+    place atomically: a reader never sees a half-written or mixed-generation libcpx.so."""
+    import fcntl
     if not force and not _stale():
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)
-    hipcc = _hipcc()
-    objs = []
-    procs = []
-    for src in SOURCES:
-        obj = os.path.join(OUT_DIR, src + ".o")
-        cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            sys.stderr.write(out.decode())
-            raise RuntimeError("hipcc failed on " + src)
-        if verbose and out:
-            print(out.decode())
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-lpthread"]
-    subprocess.check_call(cmd)
-    build_selfcheck()
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():      # somebody else built it while we waited
+            return LIB
+        hipcc = _hipcc()
+        work = os.path.join(OUT_DIR, "build.tmp")   # (fixed name: builds are serialised by the lock, and the output stays reproducible)
+        shutil.rmtree(work, ignore_errors=True)
+        os.makedirs(work)
+        try:
+            objs = []
+            procs = []
+            for src in SOURCES:
+                obj = os.path.join(work, src + ".o")
+                cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+                objs.append(obj)
+            for src, p in procs:
+                out, _ = p.communicate()
+                if p.returncode != 0:
+                    sys.stderr.write(out.decode())
+                    raise RuntimeError("hipcc failed on " + src)
+                if verbose and out:
+                    print(out.decode())
+            tmp_lib = os.path.join(work, "libcpx.so")
+            subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp_lib] + objs + ["-lpthread"])
+            os.replace(tmp_lib, LIB)
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+        build_selfcheck()
     return LIB
 
 

@@ -490,7 +490,9 @@ void Engine::enqueue_prove_device() {
   CPX_HIP(hipEventRecord(dp.ev_b, side_.stream));
   {
     const int nt = 2 * Bi;
-    launch_msm_endo(side_.tasks.p, nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
+    // (R and S of a proof share the scalars vec_a: one wave per (proof, window) serves both, kernels.h launch_msm_endo_pairs)
+    if (opt_.rs_pairs) launch_msm_endo_pairs(side_.tasks.p, Bi, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
+    else launch_msm_endo(side_.tasks.p, nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
     launch_reduce_sets(opt_, side_.raw.p, side_.rawslot.p, 0, nt * 32, side_.mid.p, side_.part.p, side_.stream, Bi);
     launch_msm_tail(opt_, side_.part.p, nullptr, side_.res.p, nt, 16, 8, side_.stream, nullptr, 0, 2);
     launch_finalize(side_.res.p, nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);

@@ -35,6 +35,7 @@ struct Options {
   long late_rounds = 4;            // 4: the last four log rounds of a large batch run on materialised folded bases (late.hip); 0: all-MSM everywhere
   long late_min_batch = 2048;      // ... for batches of at least this many proofs (n <= 256; scaled by 256 / n above: 512 at ell = 1020); the lane-per-output kernels need a full GPU to pay
   long late_slices = 8;            // lanes per cross term of a late round (1, 2, 4, 8): 15.3 k proofs/s at 8, 14.9 k at 4 and 2, 14.3 k at 1
+  long rs_pairs = 1;               // 1: the prover's R and S MSMs of a proof share their waves (same scalars: one digit sort for both); 0: two separate tasks
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
 };
 const Options& default_options();                               // built-in defaults overridden by CPX_<NAME> environment variables
@@ -112,6 +113,11 @@ size_t reduce_mid_per_set();   // TJac entries of launch_reduce_sets' d_mid scra
 // part[(task*16 + w) * 2 * slices + d] carry the weight 2^(8w) (tail: dup = 2 * slices).
 void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
                      hipStream_t s, int slices = 1);
+// The same for PAIRS of tasks with identical scalar vectors (d_tasks[2 p] and d_tasks[2 p + 1]: same n, same scalars pointer
+// contents — the prover's R = <a, vec_R>, S = <a, vec_S>): one wave per (pair, window) sorts the digits once and walks the bucket
+// lists once per task.  Raw sets and partial-sum slots as for 2 * npairs tasks of launch_msm_endo (slices = 1).
+void launch_msm_endo_pairs(const MsmTask* d_tasks, int npairs, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
+                           hipStream_t s);
 // The first nplain sets are plain sums, the following nweighted ones bucket sets (lower / upper half alternating).
 // nproofs: how many proofs the batch in flight holds (0: unknown) — picks between the wave-per-set and the work-efficient kernels
 void launch_reduce_sets(const Options& o, const uint32_t* d_raw, const uint32_t* d_raw_slot, int nplain, int nweighted, TJac* d_mid, TJac* d_part, hipStream_t s,

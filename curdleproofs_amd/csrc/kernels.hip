@@ -387,9 +387,15 @@ __device__ __forceinline__ uint32_t tbw_bucket(uint32_t word, int j, uint32_t& n
 // PERWIN (k_msm_tblw<2, true>): the same wave over bases WITHOUT shifted copies (the verifier's per-proof points, used once):
 // the "table" has two copies, P and -phi(P) (k_to_table_endo), wave w of a task takes digit w of |t| and of q, and the
 // 16 window results carry the weights 2^(8w) (Horner tail, k_msm_tail).
-template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
-                                                                            uint32_t* __restrict__ raw_slot, int slices, const uint32_t bid) {
+// PAIR (with PERWIN; the prover's R = <a, vec_R>, S = <a, vec_S>): tasks 2 t and 2 t + 1 have the SAME scalars, hence the same digits
+// and the same sorted bucket lists — one wave serves both, walking its lists once per task: the fixed cost of a wave (digit load,
+// histogram, ranking, scatter: as much as a dozen additions) is paid once for 16 instead of 8 additions per lane.  Four raw sets
+// per wave: [task 2 t lower | upper | task 2 t + 1 lower | upper].
+template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ void msm_tblw_body(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
+                                                                                               uint32_t* __restrict__ raw_slot, int slices, const uint32_t bid) {
   static_assert(!PERWIN || WPW == 2, "one window of each half per wave");
+  static_assert(!PAIR || PERWIN, "pairs only for the one-off MSMs");
+  constexpr int NSETS = PAIR ? 4 : 2;
   constexpr int WV = PERWIN ? 16 : TBW_WINDOWS / WPW;   // waves per task
   constexpr int NW = (WPW + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -405,13 +411,19 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
   uint32_t* dcache = reinterpret_cast<uint32_t*>(smem + TBW_LDS);      // [TBW_ROUND_PTS], CACHE only
   // a few tasks in flight (latency matters): `slices` waves share a task's points (each its own 64-aligned range and raw sets), so
   // that a lane's chain of additions is a quarter as long; slices = 1 otherwise
-  const TblTask task = tasks[bid / (WV * slices)];
+  const uint32_t tidx = (PAIR ? 2u : 1u) * (bid / (WV * slices));
+  const TblTask task = tasks[tidx];
+  TblTask task2 = task;   // the second task of a pair: other bases, other partial-sum slots
+  if (PAIR) {
+    task2.seg[0].base = tasks[tidx + 1].seg[0].base;
+    task2.pad = tasks[tidx + 1].pad;
+  }
   const int wv = (bid / slices) % WV, w0 = PERWIN ? wv : wv * WPW, slice = bid % slices;
   const int lane = threadIdx.x;
   const uint32_t nall = task.seg[0].n + task.seg[1].n, per = ((nall + slices - 1) / slices + 63) & ~63u;
   const uint32_t first = min(nall, (uint32_t)slice * per), ntot = min(nall, first + per);
-  uint32_t* raw0 = raw + (size_t)bid * 2 * RAW_SET_WORDS;
-  if (lane < 2) raw_slot[bid * 2 + lane] = task.pad + 2 * (wv * slices + slice) + lane;   // task.pad = first partial slot of the task
+  uint32_t* raw0 = raw + (size_t)bid * NSETS * RAW_SET_WORDS;
+  if (lane < NSETS) raw_slot[bid * NSETS + lane] = (lane < 2 ? task.pad : task2.pad) + 2 * (wv * slices + slice) + (lane & 1);   // pad = first partial slot of the task
 
   uint32_t next = first;
   bool later = false;   // a later round: the accumulators are parked in raw0 / raw1
@@ -474,8 +486,6 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
     __syncthreads();
     const uint32_t b0 = order[lane], b1 = order[127 - lane];
     const uint32_t c0 = cnt[b0], c1 = cnt[b1], s0_ = start[b0], s1_ = start[b1];
-    uint32_t* const rb0 = raw0 + (b0 >> 6) * RAW_SET_WORDS;   // bucket b lives in set b / 64 at position b % 64
-    uint32_t* const rb1 = raw0 + (b1 >> 6) * RAW_SET_WORDS;
     for (uint32_t s0 = next; s0 < end; s0 += 64) {
       const uint32_t i = s0 + lane;
       if (i < end) {
@@ -497,22 +507,28 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
       }
     }
     __syncthreads();
-    TAcc xacc = later ? raw_load(rb0, b0 & 63) : TAcc::identity();
-    const uint32_t cboth = c0 + c1;
-    for (uint32_t k = 0; k < cboth; k++) {
-      if (k == c0) {   // first bucket done: park it, go on with the second
+#pragma unroll 1
+    for (int pass = 0; pass < (PAIR ? 2 : 1); pass++) {   // (a pair walks the same lists once per task)
+      const TblTask& tk = pass ? task2 : task;
+      uint32_t* const rb0 = raw0 + (2 * pass + (b0 >> 6)) * RAW_SET_WORDS;   // bucket b lives in set b / 64 at position b % 64
+      uint32_t* const rb1 = raw0 + (2 * pass + (b1 >> 6)) * RAW_SET_WORDS;
+      TAcc xacc = later ? raw_load(rb0, b0 & 63) : TAcc::identity();
+      const uint32_t cboth = c0 + c1;
+      for (uint32_t k = 0; k < cboth; k++) {
+        if (k == c0) {   // first bucket done: park it, go on with the second
+          raw_store(rb0, b0 & 63, xacc);
+          xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
+        }
+        const uint32_t e = list[k < c0 ? s0_ + k : s1_ + (k - c0)];
+        const TAff q = *tbl_point(tk, next + (e >> 6), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & 31u));
+        xacc = t_acc_add_mixed_inl(xacc, t_cneg_lazy(q, (e & 1u) != 0));   // products inlined: no argument moves, 231 VGPRs, no scratch
+      }
+      if (c1 == 0) {
         raw_store(rb0, b0 & 63, xacc);
         xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
       }
-      const uint32_t e = list[k < c0 ? s0_ + k : s1_ + (k - c0)];
-      const TAff q = *tbl_point(task, next + (e >> 6), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & 31u));
-      xacc = t_acc_add_mixed_inl(xacc, t_cneg_lazy(q, (e & 1u) != 0));   // products inlined: no argument moves, 231 VGPRs, no scratch
+      raw_store(rb1, b1 & 63, xacc);
     }
-    if (c1 == 0) {
-      raw_store(rb0, b0 & 63, xacc);
-      xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
-    }
-    raw_store(rb1, b1 & 63, xacc);
     __syncthreads();
     next = end;
     later = true;
@@ -521,6 +537,10 @@ template <int WPW, bool PERWIN> __device__ __forceinline__ void msm_tblw_body(co
 template <int WPW, bool PERWIN = false> __global__ __launch_bounds__(64, 2) void k_msm_tblw(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw,
                                                                                             uint32_t* __restrict__ raw_slot, int slices) {
   msm_tblw_body<WPW, PERWIN>(tasks, raw, raw_slot, slices, blockIdx.x);
+}
+
+__global__ __launch_bounds__(64, 2) void k_msm_tblw_pair(const TblTask* __restrict__ tasks, uint32_t* __restrict__ raw, uint32_t* __restrict__ raw_slot) {
+  msm_tblw_body<2, true, true>(tasks, raw, raw_slot, 1, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ fixed-base MSM over multiples tables
@@ -1407,7 +1427,7 @@ const OptField kOptFields[] = {
     {"cu_mask", &Options::cu_mask, 0, 1},                        {"trace", &Options::trace, 0, 1},
     {"bench_field", &Options::bench_field, 12, 28},
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
-    {"late_slices", &Options::late_slices, 1, 8},
+    {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;
@@ -1505,6 +1525,18 @@ void launch_msm_endo(const MsmTask* d_tasks, int ntasks, int max_n, TAff* d_conv
     tl_ev_stop = eb;
   }
   CPX_LAUNCH((k_msm_tblw<2, true>), dim3(ntasks * 16 * slices), dim3(64), TBW_LDS, s, d_ttasks, d_raw, d_raw_slot, slices);
+}
+void launch_msm_endo_pairs(const MsmTask* d_tasks, int npairs, int max_n, TAff* d_conv, uint32_t* d_digits, TblTask* d_ttasks, uint32_t* d_raw, uint32_t* d_raw_slot,
+                           hipStream_t s) {
+  if (npairs <= 0) return;
+  {
+    hipEvent_t ea = tl_ev_start, eb = tl_ev_stop;   // the profiling events belong to the accumulation kernel
+    tl_ev_start = tl_ev_stop = nullptr;
+    CPX_LAUNCH(k_to_table_endo, dim3((std::max(max_n, 1) + 63) / 64, 2 * npairs), dim3(64), 0, s, d_tasks, d_conv, d_digits, d_ttasks, 1);
+    tl_ev_start = ea;
+    tl_ev_stop = eb;
+  }
+  CPX_LAUNCH(k_msm_tblw_pair, dim3(npairs * 16), dim3(64), TBW_LDS, s, d_ttasks, d_raw, d_raw_slot);
 }
 int msm_tblw_windows_per_wave(const Options& o, int ntasks) {
   // the largest group of windows per wave that still yields one wave per wave slot of the GPU (256 CUs x 4 SIMDs x 2);

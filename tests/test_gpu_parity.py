@@ -542,6 +542,7 @@ VARIANTS = {
     "late_rounds_one_lane_per_output": {"late_min_batch": 1, "device_min_batch": 1, "late_slices": 1},
     "late_rounds_eight_lanes_per_output": {"late_min_batch": 1, "device_min_batch": 1, "late_slices": 8, "tail_wave_max": 0},
     "late_rounds_off": {"late_rounds": 0, "device_min_batch": 1},
+    "rs_as_two_tasks": {"rs_pairs": 0, "device_min_batch": 1},     # R = <a, vec_R>, S = <a, vec_S> as separate tasks (default: one wave serves both)
 }
 
 

@@ -2,12 +2,13 @@
 //
 // Half a wave (32 lanes) per transcript: 25 of the lanes hold one 64-bit word of the Keccak state each — word x + 5 y sits in lane
 // 5 y + x (+ 1 for y >= 3): lane 15 stays empty so that no plane (the five words of one y) straddles the two 16-lane DPP rows of
-// the group.  A round is then two stages of ds_bpermute (theta's column parities: 4 shuffles; rho + pi: 1) and two stages of DPP row
-// shifts (theta's neighbour columns — a column parity is the same in every plane, so lane l - 1 / l + 1 has it — and chi's x + 1,
-// x + 2 inside the plane), instead of ~150 dependent 64-bit operations on one lane (a single GPU lane needs ~17 us per
-// permutation; this form 5.6 us alone on a SIMD and 7.1 us with 4096 groups in flight, with all four stages as ds_bpermute 6.0 and
-// 9.6 us: scripts/micro/keccak_micro.hip, which also checks it against the host permutation; +0.5 % on the bench, 12.80 k against
-// 12.74 k proofs/s on the same box).  Message bytes are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.hpp (the host's code, merlin 3.0.0 as used by transcript.rs:28-60 of
+// the group.  A round is then ONE ds_bpermute stage (rho + pi, a gather over the 25 lanes) and DPP / permlane stages: theta's
+// column parities (four row shifts by 5 / 10 lanes inside a 16-lane row + one v_permlane16_swap between the two rows), theta's
+// neighbour columns (a column parity is the same in every plane, so lane l - 1 / l + 1 has it) and chi's x + 1, x + 2 inside the
+// plane — instead of ~150 dependent 64-bit operations on one lane (a single GPU lane needs ~17 us per permutation; this form
+// 4.8 us alone on a SIMD and 4.9 us with 4096 groups in flight; with the parities as four ds_bpermute shuffles — rounds 1-2 — 5.4
+// and 7.1 us: scripts/micro/keccak_micro.hip, which also checks it against the host permutation; profiles/r03_keccak_micro.txt).
+// Message bytes are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.hpp (the host's code, merlin 3.0.0 as used by transcript.rs:28-60 of
 // the reference), pinned by the bit-exact proof tests.  When a whole 64-lane wave drives ONE transcript, both halves run
 // the same operations on the same inputs and hold identical copies of the state.
 #pragma once
@@ -42,6 +43,14 @@ struct WaveStrobe {
     return ((uint64_t)hi << 32) | lo;
   }
 
+  // v ^ (the same lane of the other 16-lane row of the 32-lane group), in every lane: v_permlane16_swap_b32 swaps the odd rows of
+  // its first operand with the even rows of the second; with both operands = v the two results hold (row 0, row 0, row 2, row 2) and
+  // (row 1, row 1, row 3, row 3)
+  static __device__ __forceinline__ uint64_t rows_xor(uint64_t v) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)v, (uint32_t)v, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(v >> 32), (uint32_t)(v >> 32), false, false);
+    return ((uint64_t)(hi[0] ^ hi[1]) << 32) | (uint64_t)(lo[0] ^ lo[1]);
+  }
   __device__ __forceinline__ uint64_t shfl(uint64_t v, int src) const {
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 32), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 32);
     return ((uint64_t)hi << 32) | lo;
@@ -58,16 +67,19 @@ struct WaveStrobe {
     constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110;   // DPP row shifts: row_shl:n reads lane i + n, row_shr:n lane i - n (within 16 lanes)
     const int wc = w >= 0 ? w : 0;   // empty lanes run along on word 0's indices (nobody reads them, they are cleared at the end)
     const int x = wc % 5, y = wc / 5;
-    int col[4];
-    CPX_UNROLL for (int k = 1; k < 5; k++) col[k - 1] = lane_of_word(x + 5 * ((y + k) % 5));
     // rho + pi as a gather: destination (X, Y) = (y, (2x + 3y) % 5)  <=>  source x = (X + 3Y) % 5, y = X
     const int sx = (x + 3 * y) % 5, sy = x, src = lane_of_word(sx + 5 * sy), rot = RHO[sx + 5 * sy];
     // a column parity is the same in all planes: lane l - 1 holds column x - 1 and lane l + 1 column x + 1, except next to the
     // row ends and the empty lanes, where the lane four further holds the same column
     const bool m1_alt = l == 0 || l == 16, p1_alt = l == 14 || l == 25;
     for (int r = 0; r < 24; r++) {
-      uint64_t c = a;
-      CPX_UNROLL for (int k = 0; k < 4; k++) c ^= shfl(a, col[k]);
+      // theta's column parities without LDS traffic: the planes of a row sit 5 lanes apart, so four DPP row shifts (out-of-row and
+      // empty lanes read as zero) add up a column inside each 16-lane row, and ONE v_permlane16_swap (gfx950) exchanges the two
+      // rows of the group: r[0] ^ r[1] = row 0's sums ^ row 1's sums in every lane.  (Until round 3 of this build: four
+      // ds_bpermute shuffles — a round had two dependent LDS round trips, now one: the rho + pi gather below.)
+      const uint64_t am = w >= 0 ? a : 0;   // (the empty lanes run along with garbage: keep it out of the sums)
+      uint64_t c = am ^ dpp64<ROW_SHL + 5>(am) ^ dpp64<ROW_SHL + 10>(am) ^ dpp64<ROW_SHR + 5>(am) ^ dpp64<ROW_SHR + 10>(am);
+      c = rows_xor(c);
       // (both candidates are fetched by every lane, then one is picked: a DPP read inside a divergent branch would see disabled lanes)
       const uint64_t cm_a = dpp64<ROW_SHL + 4>(c), cm_b = dpp64<ROW_SHR + 1>(c), cp_a = dpp64<ROW_SHR + 4>(c), cp_b = dpp64<ROW_SHL + 1>(c);
       const uint64_t cm1 = m1_alt ? cm_a : cm_b, cp1 = p1_alt ? cp_a : cp_b;

@@ -283,9 +283,12 @@ class Oracle:
 
     # ---- protocol ----
     def generate_crs_points(self, ell):
-        o = _buf(AFF * (ell + 7))
-        self.lib.orc_generate_crs_points(ell, o)
-        return bytes(o)
+        cache = self.__dict__.setdefault("_crs_cache", {})
+        if ell not in cache:
+            o = _buf(AFF * (ell + 7))
+            self.lib.orc_generate_crs_points(ell, o)
+            cache[ell] = bytes(o)
+        return cache[ell]
 
     def hash_to_curve_points(self, num_points, seed):
         """/root/reference/tests/crs.rs:13-52 generate_random_points: (points as 96-byte affine records, increments consumed)"""
@@ -306,6 +309,18 @@ class Oracle:
         return bytes(g), bytes(h)
 
     def make_instance(self, ell, seed, crs_points):
+        """README.md:76-118 recipe for StdRng(seed): instance, witness, the prover's draws, the oracle's proof and verdict.  Results are
+        memoised (the engine-variant tests ask for the same few instances a dozen times; an ell = 252 instance costs 0.7 s)."""
+        key = (ell, seed, hash(crs_points))
+        cache = self.__dict__.setdefault("_inst_cache", {})
+        if key in cache:
+            return dict(cache[key])
+        inst = self._make_instance(ell, seed, crs_points)
+        if len(cache) < 256:
+            cache[key] = dict(inst)
+        return inst
+
+    def _make_instance(self, ell, seed, crs_points):
         n = ell + N_BLINDERS
         R, S, T, U = (_buf(AFF * ell) for _ in range(4))
         M, k, mb = _buf(JAC), _buf(FR), _buf(FR * 4)

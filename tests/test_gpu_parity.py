@@ -588,6 +588,41 @@ def test_late_rounds_on_materialised_bases_other_sizes(orc, oracle_vectors, ell,
         c.close()
 
 
+def test_late_rounds_at_default_options_every_proof_matches_oracle(orc):
+    """The late rounds of late.hip as a large batch takes them by DEFAULT (>= 2048 proofs per context; the variant tests force them onto
+    small batches): 2048 independent ell = 28 instances on one context with default options — k_late_* must have run (kernel
+    statistics), every proof equals the oracle's bytes, every verdict the oracle's incl. two wrong proofs, and the same batch with
+    late_rounds = 0 gives the same bytes."""
+    from concurrent.futures import ThreadPoolExecutor
+    import curdleproofs_amd as cpx
+    ell, N = 28, 2048
+    crs = orc.generate_crs_points(ell)
+    with ThreadPoolExecutor(min(len(os.sched_getaffinity(0)), 64)) as ex:
+        insts = list(ex.map(lambda s: orc.make_instance(ell, 70000 + s, crs), range(N)))
+    cat = lambda key: b"".join(i[key] for i in insts)
+    perms = [x for i in insts for x in i["permutation"]]
+    out = {}
+    for late in (4, 0):
+        c = cpx.Context(0, options={"late_rounds": late})
+        try:
+            c.set_crs(ell, crs)
+            c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+            c.set_profiling(True)
+            proofs = c.prove_batch(perms, cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+            assert (c.stat("k_late_msm")["launches"] > 0) == (late == 4) and (c.stat("k_late_uniform")["launches"] > 0) == (late == 4)
+            out[late] = proofs
+            if late == 4:
+                wrong = [j for j, (i, p) in enumerate(zip(insts, proofs)) if p != i["proof"]]
+                assert not wrong, "%d proofs differ from the oracle's, first at %d" % (len(wrong), wrong[0])
+                bad = list(proofs)
+                bad[7], bad[N - 1] = proofs[8], proofs[N - 1][:48 * 3] + proofs[N - 1][48 * 4:48 * 5] + proofs[N - 1][48 * 3:48 * 4] + proofs[N - 1][48 * 5:]
+                got = c.verify_batch(bad, cat("verifier_rand"))
+                assert [j for j in range(N) if got[j] != cpx.CPX_OK] == [7, N - 1] and got[7] == got[N - 1] == cpx.CPX_ERR_VERIFY
+        finally:
+            c.close()
+    assert out[4] == out[0]
+
+
 def test_options_are_per_context_and_validated(ctx):
     """cpx_ctx_set_option: unknown keys and out-of-range values are argument errors; an option set on one context does not leak
     into another one (the environment only seeds the defaults)."""

@@ -233,6 +233,97 @@ def run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, r
         sys.exit(3)
 
 
+def load_first(c0, data, ell, nb):
+    """context c0 <- the first nb instances of the synthetic batch"""
+    import curdleproofs_amd as cpx
+    AFF, JAC = cpx.AFF, cpx.JAC
+    c0.load_batch(data["vec_R"][:nb * ell * AFF], data["vec_S"][:nb * ell * AFF], data["vec_T"][:nb * ell * AFF], data["vec_U"][:nb * ell * AFF], data["M"][:nb * JAC])
+
+
+def shape_passes(c0, data, ell, nb, min_s=1.0):
+    """steady-state prove + verify passes over the first nb instances on one engine context"""
+    import curdleproofs_amd as cpx
+    FR, n_ = cpx.FR, ell + 4
+    load_first(c0, data, ell, nb)
+    a_ = [c0.marshal(x) for x in (data["perms"][:nb * ell], data["k"][:nb * FR], data["mbl"][:nb * 4 * FR], data["prand"][:nb * (3 * n_ + 9) * FR],
+                                  data["vrand"][:nb * 8 * FR])]
+    reps, okall = 0, True
+    t0 = time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < min_s and reps < 50):
+        pr_ = c0.prove_batch(a_[0], a_[1], a_[2], a_[3], raw=True)
+        okall &= all(v == cpx.CPX_OK for v in c0.verify_batch(pr_, a_[4]))
+        reps += 1
+    dt_ = time.perf_counter() - t0
+    return dict(value=nb * reps / dt_, unit="proofs/s", ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall))
+
+
+def fused_check(c0, proofs_raw, nb, ell, peak_mm, prod_per_add, brief=False):
+    """BASELINE configs[4] on ONE engine context: the nb proofs loaded into c0 (bytes in proofs_raw) go through ONE accumulated check
+    (cpx_batch_verify_fused + cpx_g1_sum_jac), verdict included; a batch with one wrong proof must be refused."""
+    from curdleproofs_amd import params as pr_
+    L = (ell + 4).bit_length() - 1
+    frand = c0.marshal(pr_.random_fr_wire(random.Random(55), 12 * nb))
+
+    def fused_once(blob):
+        part, bad = c0.verify_batch_fused_partial(blob, frand)
+        return bad == 0 and c0.sum_jac(part)[1]
+    ok5 = fused_once(proofs_raw)   # warm-up (plans, buffers)
+    c0.set_profiling(True)
+    c0.reset_stats()
+    reps5 = 0
+    t0 = time.perf_counter()
+    while reps5 < 3 or (time.perf_counter() - t0 < 1.0 and reps5 < 20):
+        ok5 = fused_once(proofs_raw) and ok5
+        reps5 += 1
+    dt5 = time.perf_counter() - t0
+    st5 = c0.stat("k_msm_tblw<2, true>")
+    c0.set_profiling(False)
+    bad_proofs = bytearray(bytes(proofs_raw))
+    bad_proofs[48:96], bad_proofs[0:48] = bad_proofs[0:48], bad_proofs[48:96]      # proof 0 with two points swapped: the batch must be refused
+    rejects = not fused_once(bytes(bad_proofs))
+    npts5 = nb * (4 * ell + 6 + 18 + 10 * L)
+    mm5 = st5["units"] * 32 * 255.0 / 256 * prod_per_add / (st5["ms"] * 1e-3) if st5["ms"] else 0.0
+    d = dict(value=nb * reps5 / dt5, unit="proofs/s", proofs_per_check=nb, ms_per_check=1e3 * dt5 / reps5, checks=reps5, all_verified=bool(ok5),
+             rejects_a_batch_with_one_wrong_proof=bool(rejects), points_in_the_accumulated_msm=npts5 + ell + 4,
+             algorithmic_bytes_per_check=128.0 * (npts5 + ell + 4), kernel_ms_per_check=st5["ms"] / max(reps5, 1),
+             valu=dict(achieved=mm5, peak=peak_mm, frac=mm5 / peak_mm if peak_mm else None, unit="381-bit modular products/s"))
+    if not brief:
+        d = dict(dict(metric="shuffle proofs/sec checked by the batched verifier (BASELINE configs[4]) at ell=%d" % ell, kernel="k_msm_tblw<2, true>"), **d)
+        d["hbm"] = dict(achieved=128.0 * st5["units"] / (st5["ms"] * 1e-3) / 1e9 if st5["ms"] else None, peak=HBM_PEAK_GBS, unit="GB/s")
+        d["note"] = ("one engine context alone on the GPU, proofs and instances resident in HBM, 12 random factors per proof uploaded per check; "
+                     "the oracle has no batched verifier: cpu_verify_per_proof is its per-proof verifier")
+    return d
+
+
+def other_ell(c0, e3, b3, seed, what):
+    """another proof size as throughput on one engine context (its own CRS, fixed-base table and synthetic batch): prove + verify passes,
+    and the prover's and the verifier's rates apart."""
+    import curdleproofs_amd as cpx
+    try:
+        d3 = synth_batch(c0, e3, b3, seed=seed)
+        c0.load_batch(d3["vec_R"], d3["vec_S"], d3["vec_T"], d3["vec_U"], d3["M"])
+        a3 = [c0.marshal(d3[k_]) for k_ in ("perms", "k", "mbl", "prand", "vrand")]
+        pr_ = c0.prove_batch(a3[0], a3[1], a3[2], a3[3], raw=True)   # warm-up (buffers, plans)
+        okall = all(v == cpx.CPX_OK for v in c0.verify_batch(pr_, a3[4]))
+        reps, tp, tv = 0, 0.0, 0.0
+        t0 = time.perf_counter()
+        while reps < 2 or (time.perf_counter() - t0 < 2.0 and reps < 20):
+            t1 = time.perf_counter()
+            pr_ = c0.prove_batch(a3[0], a3[1], a3[2], a3[3], raw=True)
+            t2 = time.perf_counter()
+            okall &= all(v == cpx.CPX_OK for v in c0.verify_batch(pr_, a3[4]))
+            tv += time.perf_counter() - t2
+            tp += t2 - t1
+            reps += 1
+        dt_ = time.perf_counter() - t0
+        return dict(value=b3 * reps / dt_, unit="proofs/s", batch=b3, ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall),
+                    prove_per_s=b3 * reps / tp, verify_per_s=b3 * reps / tv, prove_ms_per_pass=1e3 * tp / reps, verify_ms_per_pass=1e3 * tv / reps,
+                    note="%s: ell=%d, %d proofs per pass, one engine context; value = prove + verify, prove_per_s / verify_per_s = CurdleproofsProof::new / "
+                         "::verify alone (as criterion reports them)" % (what, e3, b3))
+    except Exception as e:   # e.g. not enough free HBM for this ell's fixed-base table beside the bench's buffers
+        return dict(value=None, error=repr(e))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -482,14 +573,15 @@ def main():
                                      "'isolated' repeats the measurement with one context running alone after the timed region")
         if iso:   # every MSM kernel, one context alone: point-scalar pairs, additions x their product equivalents against the measured peak
             per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11,
-                        "k_msm_fix": (14 if any(k.startswith("k_msm_fix<19") for k in iso) else 16) * PROD_PER_ADD}
+                        "k_msm_fix": 16 * PROD_PER_ADD}
+            pair_cost = lambda k: (14 * PROD_PER_ADD if k.startswith("k_msm_fix<19") else per_pair[k.split("<")[0]])
             roofline["valu"]["isolated_by_kernel"] = {
                 k: dict(pairs_per_proof=v["units"] / (B // K), ms_per_proof_batch=v["ms"],
-                        frac=(v["units"] * per_pair[k.split("<")[0]] / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None,
+                        frac=(v["units"] * pair_cost(k) / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None,
                         # the same measurement in the accounting of rounds 1-2a (11 products per addition), for comparison with their numbers
-                        frac_at_11_products_per_addition=(v["units"] * per_pair[k.split("<")[0]] * (11.0 / PROD_PER_ADD if k.split("<")[0] != "k_msm_accw" else 1.0)
+                        frac_at_11_products_per_addition=(v["units"] * pair_cost(k) * (11.0 / PROD_PER_ADD if k.split("<")[0] != "k_msm_accw" else 1.0)
                                                           / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None)
-                for k, v in iso.items() if k.split("<")[0] in per_pair and v["ms"]}
+                for k, v in iso.items() if k.split("<")[0] in per_pair and v["ms"] and v["launches"] > 0}
         if iso and dom in iso and iso[dom]["ms"]:
             ist = iso[dom]
             iso_mm = ist["units"] * mulmods_per_point / (ist["ms"] * 1e-3)
@@ -506,45 +598,18 @@ def main():
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
                    vs_readme_i7_8550u=value / README_I7_PROOFS_PER_S, roofline=roofline)
-        # BASELINE configs[4] (the batched verifier) on this GPU, driver-visible: context 0 still holds its share of the timed batch
-        # (4096 proofs at the default shape) and the proofs of the last pass; ONE accumulated check over all of them, verdict included
-        # (cpx_batch_verify_fused + cpx_g1_sum_jac; with N GPUs the 144-byte partial sums are all-gathered first: --fused-verify)
-        if world == 1 and not args.no_extra_shapes:
-            from curdleproofs_amd import params as pr_
-            c0 = ctxs[0]
-            nb5 = B // K
-            frand = c0.marshal(pr_.random_fr_wire(random.Random(55), 12 * nb5))
-            def fused_once():
-                part, bad = c0.verify_batch_fused_partial(proofs[0], frand)
-                return bad == 0 and c0.sum_jac(part)[1]
-            ok5 = fused_once()   # warm-up (plans, buffers)
-            c0.set_profiling(True)
-            c0.reset_stats()
-            reps5 = 0
-            t0 = time.perf_counter()
-            while reps5 < 3 or (time.perf_counter() - t0 < 1.0 and reps5 < 20):
-                ok5 = fused_once() and ok5
-                reps5 += 1
-            dt5 = time.perf_counter() - t0
-            st5 = c0.stat("k_msm_tblw<2, true>")
-            c0.set_profiling(False)
-            bad_proofs = bytearray(bytes(proofs[0]))
-            bad_proofs[48:96], bad_proofs[0:48] = bad_proofs[0:48], bad_proofs[48:96]      # proof 0 with two points swapped: the batch must be refused
-            part_bad, nbad_bad = c0.verify_batch_fused_partial(bytes(bad_proofs), frand)
-            rejects = not (nbad_bad == 0 and c0.sum_jac(part_bad)[1])
-            npts5 = nb5 * (4 * ell + 6 + 18 + 10 * L)
-            mm5 = st5["units"] * 32 * 255.0 / 256 * PROD_PER_ADD / (st5["ms"] * 1e-3) if st5["ms"] else 0.0
-            out["config5"] = dict(metric="shuffle proofs/sec checked by the batched verifier (BASELINE configs[4]) at ell=%d" % ell, value=nb5 * reps5 / dt5, unit="proofs/s",
-                                  proofs_per_check=nb5, ms_per_check=1e3 * dt5 / reps5, checks=reps5, all_verified=bool(ok5), rejects_a_batch_with_one_wrong_proof=bool(rejects),
-                                  points_in_the_accumulated_msm=npts5 + ell + 4, algorithmic_bytes_per_check=128.0 * (npts5 + ell + 4),
-                                  kernel="k_msm_tblw<2, true>", kernel_ms_per_check=st5["ms"] / max(reps5, 1),
-                                  valu=dict(achieved=mm5, peak=peak_mm, frac=mm5 / peak_mm if peak_mm else None, unit="381-bit modular products/s"),
-                                  hbm=dict(achieved=128.0 * st5["units"] / (st5["ms"] * 1e-3) / 1e9 if st5["ms"] else None, peak=HBM_PEAK_GBS, unit="GB/s"),
-                                  note="one engine context alone on the GPU, proofs and instances resident in HBM, 12 random factors per proof uploaded per check; "
-                                       "the oracle has no batched verifier: cpu_verify_per_proof is its per-proof verifier")
-        # BASELINE configs[1]: the same instance shape as ONE proof (latency, not throughput): instance 0 alone on context 0
+        # Everything below runs on rank 0 only, outside the timed region, at ANY N (the other ranks wait at the final barrier): the
+        # literal BASELINE shapes, the batched verifier, the other proof sizes and the CPU baseline belong to every line.
         AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
         c0, n_ = ctxs[0], ell + 4
+        psz_bench = c0.proof_size
+        proof0 = bytes(proofs[0])[:psz_bench]
+        if not args.no_extra_shapes:
+            # BASELINE configs[4] (the batched verifier), driver-visible: context 0 still holds its share of the timed batch and the proofs
+            # of the last pass; ONE accumulated check over all of them, verdict included (cpx_batch_verify_fused + cpx_g1_sum_jac; with
+            # N GPUs the 144-byte partial sums are all-gathered first: --fused-verify)
+            out["config5"] = fused_check(c0, proofs[0], B // K, ell, peak_mm, PROD_PER_ADD)
+        # BASELINE configs[1]: the same instance shape as ONE proof (latency, not throughput): instance 0 alone on context 0
         c0.load_batch(data["vec_R"][:ell * AFF], data["vec_S"][:ell * AFF], data["vec_T"][:ell * AFF], data["vec_U"][:ell * AFF], data["M"][:JAC])
         tp, tv = [], []
         for _ in range(4):
@@ -557,48 +622,32 @@ def main():
             tv.append(t2 - t1)
         out["single_proof"] = dict(prove_ms=1e3 * min(tp), verify_ms=1e3 * min(tv), accepted=v1 == [cpx.CPX_OK],
                                    note="BASELINE configs[1] as a latency figure: one ell=%d proof alone on the GPU (best of 4)" % ell)
-        psz_bench = c0.proof_size   # (context 0 takes another CRS below)
-        if not args.no_extra_shapes and world == 1:   # (N > 1: the other ranks would idle at the final barrier meanwhile)
+        if not args.no_extra_shapes:
             # BASELINE configs[3] at its literal shapes: 1024 proofs total = 128 per GPU on 8 GPUs; and 1024 on one GPU.  One context, proofs of the
             # bench batch; steady-state prove + verify passes (not the headline: smaller batches fill the GPU less)
             shapes = {}
             for nb in (128, 1024):
-                if nb > B:
-                    continue
-                c0.load_batch(data["vec_R"][:nb * ell * AFF], data["vec_S"][:nb * ell * AFF], data["vec_T"][:nb * ell * AFF], data["vec_U"][:nb * ell * AFF],
-                              data["M"][:nb * JAC])
-                a_ = [c0.marshal(x) for x in (data["perms"][:nb * ell], data["k"][:nb * FR], data["mbl"][:nb * 4 * FR], data["prand"][:nb * (3 * n_ + 9) * FR],
-                                              data["vrand"][:nb * 8 * FR])]
-                reps, okall = 0, True
-                t0 = time.perf_counter()
-                while reps < 3 or (time.perf_counter() - t0 < 1.0 and reps < 50):
-                    pr_ = c0.prove_batch(a_[0], a_[1], a_[2], a_[3], raw=True)
-                    okall &= all(v == cpx.CPX_OK for v in c0.verify_batch(pr_, a_[4]))
-                    reps += 1
-                dt_ = time.perf_counter() - t0
-                shapes["batch_%d_per_gpu" % nb] = dict(value=nb * reps / dt_, unit="proofs/s", ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall))
+                if nb <= B:
+                    shapes["batch_%d_per_gpu" % nb] = shape_passes(c0, data, ell, nb)
             out["baseline_shapes"] = dict(note="BASELINE configs[3] (1024 independent ell=%d proofs) at its literal shapes, one engine context: 128 proofs per GPU "
                                                "(the per-GPU share on 8 GPUs) and 1024 proofs on one GPU" % ell, **shapes)
-            if ell == 252:   # BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
-                try:
-                    e3, b3 = 1020, 2048   # enough proofs to fill the GPU (256 proofs per pass: 1.6 k, 1024: 2.8 k, 2048: 3.5 k proofs/s)
-                    d3 = synth_batch(c0, e3, b3, seed=4321)
-                    c0.load_batch(d3["vec_R"], d3["vec_S"], d3["vec_T"], d3["vec_U"], d3["M"])
-                    a3 = [c0.marshal(d3[k_]) for k_ in ("perms", "k", "mbl", "prand", "vrand")]
-                    reps, okall = 0, True
-                    pr_ = c0.prove_batch(a3[0], a3[1], a3[2], a3[3], raw=True)   # warm-up (buffers, plans)
-                    t0 = time.perf_counter()
-                    while reps < 2 or (time.perf_counter() - t0 < 2.0 and reps < 20):
-                        pr_ = c0.prove_batch(a3[0], a3[1], a3[2], a3[3], raw=True)
-                        okall &= all(v == cpx.CPX_OK for v in c0.verify_batch(pr_, a3[4]))
-                        reps += 1
-                    dt_ = time.perf_counter() - t0
-                    out["ell_1020"] = dict(value=b3 * reps / dt_, unit="proofs/s", batch=b3, ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall),
-                                           note="BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput: %d proofs per pass, one engine context" % b3)
-                except Exception as e:   # e.g. not enough free HBM for the ell = 1020 fixed-base table beside the bench's buffers
-                    out["ell_1020"] = dict(value=None, error=repr(e))
-        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(ell, data, bytes(proofs[0])[:psz_bench])
+            # BASELINE configs[4] at its literal shapes: 4096 proofs in one accumulated check = 512 per GPU on 8 GPUs; and all 4096 on one GPU
+            lit = {}
+            for nb in (512, 4096):
+                if nb <= B:
+                    load_first(c0, data, ell, nb)
+                    a_ = [c0.marshal(x) for x in (data["perms"][:nb * ell], data["k"][:nb * FR], data["mbl"][:nb * 4 * FR], data["prand"][:nb * (3 * n_ + 9) * FR])]
+                    lit["proofs_%d_per_check" % nb] = fused_check(c0, c0.prove_batch(a_[0], a_[1], a_[2], a_[3], raw=True), nb, ell, peak_mm, PROD_PER_ADD, brief=True)
+            if "config5" in out:
+                out["config5"]["literal_shapes"] = dict(note="BASELINE configs[4] is 4096 proofs in ONE accumulated check: 512 per GPU on 8 GPUs (then one all-gather of "
+                                                             "148 bytes per rank), or all 4096 on one GPU; one engine context each", **lit)
+            if ell == 252:
+                # the reference's own bench shape (benches/perf.rs:29: N = 512, ell = 508), prover and verifier rates apart as criterion prints
+                # them; and BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
+                out["ell_508"] = other_ell(c0, 508, 4096, 5081, "the reference's in-tree criterion bench shape (benches/perf.rs:29, N = 512)")
+                out["ell_1020"] = other_ell(c0, 1020, 2048, 4321, "BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput")
+        if not args.no_cpu_baseline:   # the CPU oracle beside the GPU number in the same run, on rank 0 at every N
+            out["cpu_baseline"] = cpu_baseline(ell, data, proof0)
             if "config5" in out:
                 vs = out["cpu_baseline"]["verify_s"]
                 out["config5"]["cpu_verify_per_proof"] = dict(value=1.0 / vs, unit="proofs/s", cores=1, kind="port",

@@ -1014,7 +1014,7 @@ def test_bench_two_ranks_on_one_gpu(fused):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ell", "28", "--batch", "128", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-extra-shapes"] + (["--fused-verify"] if fused else []), env=env, cwd=root, capture_output=True, text=True,
+                        "--no-extra-shapes"] + (["--fused-verify"] if fused else []), env=env, cwd=root, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1024,6 +1024,15 @@ def test_bench_two_ranks_on_one_gpu(fused):
     assert d["config"]["global_batch"] == 256 and d["config"]["batch_per_gpu"] == 128
     assert abs(d["value"] - 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     assert ("batched verifier" in d["metric"]) == fused
+    # the N > 1 line is a complete line: the CPU baseline (rank 0 times the oracle while the other ranks wait at the final barrier) and
+    # the roofline object sit beside the GPU number in the same run
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert d["roofline"] is not None and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and d["roofline"]["achieved"] > 0
+    if not fused:
+        assert d["cpu_baseline"]["gpu_proof_bit_exact"] is True
+        by_kernel = d["roofline"]["valu"]["isolated_by_kernel"]
+        if d["roofline"]["kernel"] in by_kernel:   # one measurement, one number (round 3 printed two)
+            assert by_kernel[d["roofline"]["kernel"]]["frac"] == pytest.approx(d["roofline"]["valu"]["isolated"]["frac"], rel=1e-9)
 
 
 @pytest.mark.parametrize("copies", [1, 97], ids=["host_driven", "device_resident"])

@@ -171,8 +171,12 @@ class Context:
             raise CpxError(rc, "cpx_ctx_create(device=%d): no usable MI355X/HIP device" % device)
         self._h = h
         self.ell = None
-        for key, value in (options or {}).items():
-            self.set_option(key, value)
+        try:
+            for key, value in (options or {}).items():
+                self.set_option(key, value)
+        except Exception:   # an unknown key / a value out of range: do not leak the native context (streams, engine) of the half-built object
+            self.close()
+            raise
 
     @property
     def batch(self):

@@ -12,7 +12,7 @@ from . import AFF, N_BLINDERS, CPX_ERR_DESERIALIZE, CpxError
 from . import whisk
 
 
-_HEX_POINT = re.compile(r"^0x[0-9a-fA-F]{96}$")
+_HEX_POINT = re.compile(r"0x[0-9a-fA-F]{96}")   # used with fullmatch: `$` alone would let a trailing newline through
 
 
 def crs_to_hex(ctx):
@@ -33,7 +33,7 @@ def crs_from_hex(ctx, obj):
     def unhex(s):
         if not isinstance(s, str) or not s.startswith("0x"):
             raise whisk.SerializationError("missing 0x prefix")
-        if not _HEX_POINT.match(s):   # hex::decode rejects whitespace and odd lengths; bytes.fromhex alone would skip blanks
+        if not _HEX_POINT.fullmatch(s):   # hex::decode rejects whitespace and odd lengths; bytes.fromhex alone would skip blanks
             raise whisk.SerializationError("a compressed G1 point is 0x + 96 hex digits")
         return bytes.fromhex(s[2:])
     vec_G, vec_H = [unhex(s) for s in obj["vec_G"]], [unhex(s) for s in obj["vec_H"]]

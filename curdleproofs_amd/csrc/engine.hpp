@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstring>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -148,7 +149,15 @@ class Engine {
   // per-context tunables (kernels.h `Options`; cpx_ctx_set_option).  fix_bits takes effect at the next set_crs; a change invalidates
   // the cached device plans (their task layouts depend on the kernel selection).
   bool set_option(const char* key, long value);
-  bool get_option(const char* key, long* value) const { return cpx::get_option(opt_, key, value); }
+  // read-only beside the tunables: "fix_bits_effective" = the radix of the fixed-base table in use (set_crs falls back 19 -> 16 -> 8 when
+  // free HBM is short; 0 before the first set_crs)
+  bool get_option(const char* key, long* value) const {
+    if (key && !strcmp(key, "fix_bits_effective")) {
+      if (value) *value = crs_tab_ ? fix_bits_ : 0;
+      return true;
+    }
+    return cpx::get_option(opt_, key, value);
+  }
   hipStream_t stream() const { return stream_; }
   void sync() { CPX_HIP(hipStreamSynchronize(stream_)); }
 

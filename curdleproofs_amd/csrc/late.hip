@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <stdexcept>
 #include "g1.hpp"
 #include "g1_28.hpp"
 #include "glv.hpp"
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(64) void k_late_restart(Fr* __restrict__ vec, int n
 
 size_t late_tab_entries() { return 2 * LATE_MULT; }
 size_t late_tmp_per_lane() { return LATE_MULT; }
-bool late_supported(int n, int m) { return m >= 2 && n % m == 0 && n / m <= LU_MAX_T && n > m; }
+// (2 families x m outputs x 2 lanes per output must fit the 64 lanes of k_late_uniform's wave: m <= 16)
+bool late_supported(int n, int m) { return m >= 2 && m <= 16 && n % m == 0 && n / m <= LU_MAX_T && n > m; }
 
 void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, int n, int m, const TFix* d_fix_tab, int cbits, int nc, TJac* d_out, size_t ostride,
                      int nproofs, hipStream_t s) {
@@ -308,7 +310,11 @@ void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, i
 }
 void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, size_t ptab_proof_stride, int NP, const TAff* d_ctab, int nc, const uint32_t* d_gb_cols, int n,
                          int m, int nfam, int split, TJac* d_out, size_t fstride, int nproofs, hipStream_t s) {
-  if (nproofs <= 0 || nfam * m * split > 64) return;
+  if (nproofs <= 0) return;
+  // (late_supported() keeps the engine away from shapes this kernel cannot take; a caller that gets here anyway must not go on with
+  // uninitialised folded bases)
+  if (nfam * m * split > 64 || m <= 0 || n % m || n / m > LU_MAX_T || (n / m) > (1 << 10))
+    throw std::invalid_argument("launch_late_uniform: nfam * m * split lanes must fit one wave and n / m the 16-bit list entries");
   const int nent = 32 * (n / m);
   const size_t lds = 64 * sizeof(TAcc) + (size_t)((nent + 1) & ~1) * 2 + 2 * 132 * 4;
   LATE_LAUNCH(k_late_uniform, dim3(nproofs), dim3(64), lds, s, d_sm, sstride, d_ptab, ptab_proof_stride, NP, d_ctab, nc, d_gb_cols, n, m, nfam, split, d_out, fstride);

@@ -51,7 +51,8 @@ int cpx_device_count(void);
  * "tbw_wpw", "reduce_wave_max", ...).  A new context starts from the built-in defaults, overridden by CPX_<KEY> environment
  * variables read once per process; everything after that goes through these calls and concerns this context only.  Results never
  * depend on an option (tests/test_gpu_parity.py::test_engine_variants_stay_bit_exact), only speed does.  "fix_bits" takes effect at
- * the next cpx_ctx_set_crs.  Unknown key / value out of range -> CPX_ERR_ARG. */
+ * the next cpx_ctx_set_crs.  Unknown key / value out of range -> CPX_ERR_ARG.  cpx_ctx_get_option also answers the read-only key
+ * "fix_bits_effective": the radix of the fixed-base table this context actually uses (the fallback of cpx_ctx_set_crs; 0 = no CRS). */
 int cpx_ctx_set_option(cpx_ctx* ctx, const char* key, long long value);
 int cpx_ctx_get_option(const cpx_ctx* ctx, const char* key, long long* value);
 

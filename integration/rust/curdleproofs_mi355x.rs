@@ -74,7 +74,7 @@ impl CurdleproofsProof {
             rand.extend(prover_draws(n, rng)); // instance by instance, each in the reference's order
         }
         let psz = unsafe {
-            let rc = cpx_batch_load(h, b, r.as_ptr(), s.as_ptr(), t.as_ptr(), u.as_ptr(), projective_ptr(&m));
+            let rc = cpx_batch_load(h, b, r.as_ptr(), s.as_ptr(), t.as_ptr(), u.as_ptr(), projective_to_wire(&m).as_ptr());
             assert_eq!(rc, CPX_OK, "cpx_batch_load");
             cpx_proof_size(h)
         };
@@ -103,7 +103,7 @@ impl CurdleproofsProof {
         let mut verdict: std::os::raw::c_int = CPX_ERR_INTERNAL;
         unsafe {
             let rc = cpx_batch_load(h, 1, affine_to_wire(vec_R).as_ptr(), affine_to_wire(vec_S).as_ptr(), affine_to_wire(vec_T).as_ptr(),
-                                    affine_to_wire(vec_U).as_ptr(), M as *const G1Projective as *const u8);
+                                    affine_to_wire(vec_U).as_ptr(), projective_to_wire(std::slice::from_ref(M)).as_ptr());
             assert_eq!(rc, CPX_OK, "cpx_batch_load");
             let rc = cpx_batch_verify(h, bytes.as_ptr(), scalars_ptr(&factors), &mut verdict);
             assert_eq!(rc, CPX_OK, "cpx_batch_verify");

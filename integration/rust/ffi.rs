@@ -1,9 +1,11 @@
 //! `src/ffi.rs` — bindings to the MI355X core (`include/cpx.h`, `libcpx.so`).  NOT COMPILED in the build image (no rustc there).
 //!
 //! arkworks 0.4 keeps `Fr` / `Fq` as `BigInt<N>([u64; N])` in Montgomery form and `G1Projective` as `{x, y, z}` of `Fq`:
-//! exactly the wire layout of the C-ABI (Fr 32 B, Fp 48 B, Jacobian 144 B), so scalars and projective points are passed
-//! as the memory they already occupy.  `G1Affine {x, y, infinity}` is `repr(Rust)`: affine points are marshalled to
-//! 96 bytes `x || y`, the point at infinity as 96 zero bytes.
+//! the limb layout of the C-ABI (Fr 32 B, Fp 48 B).  `Fr` is `repr(transparent)`-like over `[u64; 4]` (a newtype chain of single
+//! fields), so scalar slices are passed as the memory they occupy (checked once at start-up by `layout_self_check`).  Points are
+//! NOT: `G1Affine {x, y, infinity}` and `G1Projective {x, y, z}` are `repr(Rust)` structs whose field order and padding the
+//! compiler may choose, so both are marshalled field by field — affine points to 96 bytes `x || y` (the point at infinity as 96 zero
+//! bytes), projective points to 144 bytes `X || Y || Z`.
 #![allow(non_snake_case, non_camel_case_types, dead_code)]
 
 use ark_bls12_381::{Fq, Fr, G1Affine, G1Projective};
@@ -50,6 +52,8 @@ extern "C" {
     pub fn cpx_g1_scale(ctx: *mut cpx_ctx, p: *const u8, scalars: *const u8, scalar_stride: usize, n: usize, out: *mut u8) -> c_int;
     pub fn cpx_g1_normalize(ctx: *mut cpx_ctx, jac: *const u8, n: usize, out_affine: *mut u8, out_compressed: *mut u8) -> c_int;
     pub fn cpx_g1_decompress(ctx: *mut cpx_ctx, compressed: *const u8, n: usize, out_affine: *mut u8, check_subgroup: c_int) -> c_int;
+    // one verdict per point (0 ok, 1 malformed / not on the curve, 2 outside the subgroup): the square root behind tests/crs.rs:13-52
+    pub fn cpx_g1_decompress_status(ctx: *mut cpx_ctx, compressed: *const u8, n: usize, out_affine: *mut u8, check_subgroup: c_int, status: *mut u8) -> c_int;
     // tier 1: msm_accumulator.rs:22-68
     pub fn cpx_accum_new(ctx: *mut cpx_ctx, out: *mut *mut cpx_accum) -> c_int;
     pub fn cpx_accum_free(acc: *mut cpx_accum);
@@ -111,12 +115,31 @@ pub fn affine_from_wire(b: &[u8]) -> Vec<G1Affine> {
         })
         .collect()
 }
-/// `&[Fr]` and `&[G1Projective]` already are wire memory
+/// `&[Fr]` already is wire memory (4 x u64 little-endian Montgomery limbs per element); `layout_self_check` asserts it
 pub fn scalars_ptr(s: &[Fr]) -> *const u8 {
     s.as_ptr() as *const u8
 }
-pub fn projective_ptr(p: &[G1Projective]) -> *const u8 {
-    p.as_ptr() as *const u8
+/// 144 bytes per point, `X || Y || Z`, written field by field (`Projective<P>` is `repr(Rust)`: no cast of the struct's memory)
+pub fn projective_to_wire(points: &[G1Projective]) -> Vec<u8> {
+    let mut v = vec![0u8; JAC * points.len()];
+    for (i, q) in points.iter().enumerate() {
+        v[JAC * i..JAC * i + 48].copy_from_slice(&fq_bytes(&q.x));
+        v[JAC * i + 48..JAC * i + 96].copy_from_slice(&fq_bytes(&q.y));
+        v[JAC * i + 96..JAC * i + 144].copy_from_slice(&fq_bytes(&q.z));
+    }
+    v
+}
+/// Run once before the first FFI call (`ctx()` does): what the scalar pointer casts rest on — an `Fr` occupies exactly its four
+/// Montgomery limbs, in order, little-endian.
+pub fn layout_self_check() {
+    use ark_ff::One;
+    assert_eq!(std::mem::size_of::<Fr>(), FR, "Fr is not 4 x u64");
+    assert_eq!(std::mem::align_of::<Fr>(), 8);
+    let x = Fr::one() + Fr::one() + Fr::one();
+    let bytes: [u8; FR] = unsafe { std::mem::transmute_copy(&x) };
+    for i in 0..4 {
+        assert_eq!(u64::from_le_bytes(bytes[8 * i..8 * i + 8].try_into().unwrap()), x.0 .0[i], "Fr memory is not its Montgomery limbs in order");
+    }
 }
 pub fn projective_from_wire(b: &[u8; JAC]) -> G1Projective {
     let z = fq_from_bytes(&b[96..]);
@@ -144,6 +167,7 @@ pub fn ctx() -> *mut cpx_ctx {
             let mut h: *mut cpx_ctx = std::ptr::null_mut();
             let rc = unsafe { cpx_ctx_create(dev, &mut h) };
             assert_eq!(rc, CPX_OK, "cpx_ctx_create: no usable MI355X (there is no CPU fallback)");
+            layout_self_check();
             *c = Some(Ctx(h));
         }
         c.as_ref().unwrap().0

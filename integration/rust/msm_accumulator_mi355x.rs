@@ -29,8 +29,9 @@ impl MsmAccumulator {
         }
         let n = vec_x.len().min(vec_V.len()); // `zip`
         let v = affine_to_wire(&vec_V[..n]);
+        let c_wire = projective_to_wire(std::slice::from_ref(C)); // field by field: Projective is repr(Rust)
         let rc = unsafe {
-            cpx_accum_check(self.h, C as *const G1Projective as *const u8, scalars_ptr(vec_x), v.as_ptr(), n, &random_factor as *const Fr as *const u8)
+            cpx_accum_check(self.h, c_wire.as_ptr(), scalars_ptr(vec_x), v.as_ptr(), n, scalars_ptr(std::slice::from_ref(&random_factor)))
         };
         assert_eq!(rc, CPX_OK, "cpx_accum_check");
     }

@@ -24,7 +24,7 @@ pub fn msm(points: &[G1Affine], scalars: &[Fr]) -> G1Projective {
 pub fn msm_from_projective(points: &[G1Projective], scalars: &[Fr]) -> G1Projective {
     assert_eq!(points.len(), scalars.len());
     let mut out = [0u8; JAC];
-    let rc = unsafe { cpx_g1_msm_jac(ctx(), projective_ptr(points), scalars_ptr(scalars), points.len(), out.as_mut_ptr()) };
+    let rc = unsafe { cpx_g1_msm_jac(ctx(), projective_to_wire(points).as_ptr(), scalars_ptr(scalars), points.len(), out.as_mut_ptr()) };
     assert_eq!(rc, CPX_OK, "cpx_g1_msm_jac");
     projective_from_wire(&out)
 }
@@ -35,7 +35,7 @@ pub fn fold_bases(vec_L: &mut [G1Affine], vec_R: &[G1Affine], gamma: &Fr) {
     assert_eq!(vec_L.len(), vec_R.len());
     let mut l = affine_to_wire(vec_L);
     let r = affine_to_wire(vec_R);
-    let rc = unsafe { cpx_g1_fold(ctx(), l.as_mut_ptr(), r.as_ptr(), gamma as *const Fr as *const u8, vec_L.len()) };
+    let rc = unsafe { cpx_g1_fold(ctx(), l.as_mut_ptr(), r.as_ptr(), scalars_ptr(std::slice::from_ref(gamma)), vec_L.len()) };
     assert_eq!(rc, CPX_OK, "cpx_g1_fold");
     vec_L.copy_from_slice(&affine_from_wire(&l));
 }

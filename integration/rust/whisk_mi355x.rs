@@ -66,7 +66,7 @@ pub fn generate_whisk_shuffle_proof<T: RngCore>(
     let mut post = vec![0u8; 96 * ELL];
     let mut proof = [0u8; WHISK_SHUFFLE_PROOF_SIZE];
     map_rc(unsafe {
-        cpx_whisk_generate_shuffle_proof(ctx_with_crs(crs), trackers_to_wire(pre_trackers).as_ptr(), permutation.as_ptr(), &k as *const Fr as *const u8,
+        cpx_whisk_generate_shuffle_proof(ctx_with_crs(crs), trackers_to_wire(pre_trackers).as_ptr(), permutation.as_ptr(), scalars_ptr(std::slice::from_ref(&k)),
                                          scalars_ptr(&vec_m_blinders), scalars_ptr(&rand), post.as_mut_ptr(), proof.as_mut_ptr())
     })?;
     let post_trackers = post.chunks(96).map(|c| WhiskTracker { r_G: c[..48].try_into().unwrap(), k_r_G: c[48..].try_into().unwrap() }).collect();
@@ -86,6 +86,6 @@ pub fn generate_whisk_tracker_proof<T: RngCore>(rng: &mut T, tracker: &WhiskTrac
     let blinder = Fr::rand(rng); // :238
     let mut out = [0u8; TRACKER_PROOF_SIZE];
     let t = trackers_to_wire(std::slice::from_ref(tracker));
-    map_rc(unsafe { cpx_whisk_generate_tracker_proof(ctx(), t.as_ptr(), k as *const Fr as *const u8, &blinder as *const Fr as *const u8, out.as_mut_ptr()) })?;
+    map_rc(unsafe { cpx_whisk_generate_tracker_proof(ctx(), t.as_ptr(), scalars_ptr(std::slice::from_ref(k)), scalars_ptr(std::slice::from_ref(&blinder)), out.as_mut_ptr()) })?;
     Ok(out)
 }

@@ -569,7 +569,21 @@ def test_engine_variants_stay_bit_exact(name, orc, whisk_kat, oracle_vectors):
     try:
         for k, v in VARIANTS[name].items():
             assert c.get_option(k) == v
+        seen = []   # the radix of the fixed-base table actually in use after every set_crs of the checks
+        plain_set_crs = c.set_crs
+        c.set_crs = lambda ell, pts: (plain_set_crs(ell, pts), seen.append((ell, c.get_option("fix_bits_effective"))))[0]
         _variant_checks(c, orc, whisk_kat, oracle_vectors)
+        if "fix_bits" in VARIANTS[name]:
+            # the CONFIGURED radix is not the one in use when set_crs fell back (19 -> 16 -> 8 when free HBM is short, e.g. beside other
+            # contexts' tables in this process): a variant that silently ran another table pins nothing
+            fell_back = sorted({(e, b) for e, b in seen if b != VARIANTS[name]["fix_bits"]})
+            if fell_back:
+                pytest.skip("fixed-base table fell back (free HBM) at (ell, bits) = %s: the %d-bit kernels did not run there" % (fell_back, VARIANTS[name]["fix_bits"]))
+            if VARIANTS[name]["fix_bits"] == 19 and "late_min_batch" in VARIANTS[name]:
+                c.set_profiling(True)
+                c.reset_stats()
+                test_prove_verify_batch40_ell28(c, orc)
+                assert c.stat("k_msm_fix<19, 7>")["launches"] > 0 and c.stat("k_late_fix")["launches"] > 0
     finally:
         c.close()
 
@@ -636,6 +650,8 @@ def test_options_are_per_context_and_validated(ctx):
             with pytest.raises(cpx.CpxError) as e:
                 other.set_option(key, value)
             assert e.value.code == cpx.CPX_ERR_ARG
+        with pytest.raises(cpx.CpxError):   # a bad option at construction: the error surfaces and the native context is released again
+            cpx.Context(0, options={"no_such_option": 1})
     finally:
         other.close()
 
@@ -800,10 +816,8 @@ def test_headline_shape_1024_proofs_ell252_every_proof_matches_oracle(orc):
     from concurrent.futures import ThreadPoolExecutor
     import curdleproofs_amd as cpx
     ell, K, N = 252, 2, 1024
-    ncpu = min(len(os.sched_getaffinity(0)), os.cpu_count() or 8, 64)
     crs = orc.generate_crs_points(ell)
-    with ThreadPoolExecutor(ncpu) as ex:   # the oracle is a C library behind ctypes (the GIL is released): ~0.7 s per instance and core
-        insts = list(ex.map(lambda s: orc.make_instance(ell, s, crs), range(N)))
+    insts = _instance_list(orc, ell, N, crs)   # ~0.7 s per instance and core, shared with the one-context test of the bench shape
     assert all(i["verdict"] == 1 for i in insts)
     per = N // K
     errors = []
@@ -855,6 +869,79 @@ def test_headline_shape_1024_proofs_ell252_every_proof_matches_oracle(orc):
     assert c.sum_jac(b"".join(p for p, _ in partials))[1], "partial sums of 1024 valid ell=252 proofs must add up to the identity"
     assert not c.sum_jac(b"".join(p for p, _ in partials_bad))[1]
     c.close()
+
+
+_INSTANCE_LISTS = {}
+
+
+def _instance_list(orc, ell, count, crs):
+    """instances 0 .. count-1 of BASELINE configs[3]'s recipe (instance i from StdRng(i)), computed once per session on all host cores (the
+    oracle is a C library behind ctypes: the GIL is released) and shared by the tests of the large shapes"""
+    from concurrent.futures import ThreadPoolExecutor
+    have = _INSTANCE_LISTS.setdefault(ell, [])
+    if len(have) < count:
+        ncpu = min(len(os.sched_getaffinity(0)), os.cpu_count() or 8, 64)
+        with ThreadPoolExecutor(ncpu) as ex:
+            have.extend(ex.map(lambda s: orc._make_instance(ell, s, crs), range(len(have), count)))
+    return have[:count]
+
+
+def _three_wrong(good):
+    """a neighbour's proof, two points swapped, the last scalar changed"""
+    per = len(good)
+    bad = list(good)
+    bad[5] = good[6]
+    bad[per // 2] = good[per // 2][48:96] + good[per // 2][:48] + good[per // 2][96:]
+    last = bytearray(good[per - 1])
+    last[-1] ^= 0x01
+    bad[per - 1] = bytes(last)
+    return bad, (5, per // 2, per - 1)
+
+
+@pytest.mark.parametrize("ell,N", [(252, 2048), (1020, 512)], ids=["bench_shape_2048_x_ell252", "bench_shape_512_x_ell1020"])
+def test_bench_code_path_one_context_default_options_every_proof_matches_oracle(orc, ell, N):
+    """The configuration that produces the bench numbers, pinned on EVERY proof: one engine context with DEFAULT options holding a batch
+    large enough for the late rounds on materialised folded bases (late.hip: >= 2048 proofs at ell = 252 — the bench runs 8192 per
+    context —, >= 512 at ell = 1020 — the `ell_1020` key runs 2048), i.e. k_msm_fix<16, 16>, k_msm_tblw<32, false>, the thread-per-group
+    reductions, k_late_fix / k_late_uniform / k_late_tables / k_late_msm and the device-resident protocol all at once.  Every proof's
+    bytes and every verdict (three deliberately wrong proofs) must equal the oracle's, then BASELINE configs[4]'s fused verifier over
+    the same batch (curdleproofs.rs:385-471, inner_product_argument.rs:150-186, same_multiscalar_argument.rs:99-136)."""
+    import curdleproofs_amd as cpx
+    crs = orc.generate_crs_points(ell)
+    insts = _instance_list(orc, ell, N, crs)
+    assert all(i["verdict"] == 1 for i in insts)
+    cat = lambda key: b"".join(i[key] for i in insts)
+    c = cpx.Context(0)
+    try:
+        assert c.get_option("late_rounds") == 4 and c.get_option("fix_bits") == 16
+        c.set_crs(ell, crs)
+        if c.get_option("fix_bits_effective") != 16:
+            pytest.skip("not enough free HBM for the 16-bit fixed-base table at ell = %d (other contexts' tables resident): the bench shape cannot run here" % ell)
+        c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+        c.set_profiling(True)
+        c.reset_stats()
+        proofs = c.prove_batch([x for i in insts for x in i["permutation"]], cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+        for name in ("k_late_fix", "k_late_uniform", "k_late_tables", "k_late_msm", "k_msm_fix<16, 16>", "k_msm_tblw<32, false>"):
+            assert c.stat(name)["launches"] > 0, "%s did not run: this is not the bench's code path" % name
+        c.set_profiling(False)
+        wrong = [j for j, (i, p) in enumerate(zip(insts, proofs)) if p != i["proof"]]
+        assert not wrong, "%d of %d proofs differ from the oracle's, first at index %d" % (len(wrong), N, wrong[0])
+        good = [i["proof"] for i in insts]
+        bad, where = _three_wrong(good)
+        got = c.verify_batch(bad, cat("verifier_rand"))
+        want = [cpx.CPX_OK] * N
+        for j in where:
+            x = insts[j]
+            o = orc.verify(ell, crs, x["vec_R"], x["vec_S"], x["vec_T"], x["vec_U"], x["M"], bad[j], x["verifier_rand"])
+            want[j] = {1: cpx.CPX_OK, 0: cpx.CPX_ERR_VERIFY, -1: cpx.CPX_ERR_DESERIALIZE}[o]
+        assert all(want[j] != cpx.CPX_OK for j in where)
+        assert got == want, "verdicts differ at %s" % [j for j in range(N) if got[j] != want[j]][:8]
+        assert c.verify_batch(good, cat("verifier_rand")) == [cpx.CPX_OK] * N
+        frand = orc.rng(9300 + ell).fr(12 * N)
+        assert c.verify_batch_fused(good, frand)
+        assert not c.verify_batch_fused(bad, frand)
+    finally:
+        c.close()
 
 
 def test_verifier_rejects_degenerate_random_factors(ctx, orc):

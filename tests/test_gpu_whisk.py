@@ -145,16 +145,23 @@ def test_crs_hex_json_roundtrip(ctx, orc):
     bad = dict(obj, H="0x " + obj["H"][4:] + " ")          # blanks inside the hex: hex::decode refuses them (bytes.fromhex would not)
     with pytest.raises(whisk.SerializationError):
         crsmod.crs_from_hex(c2, bad)
+    bad = dict(obj, H=obj["H"] + "\n")                    # a trailing newline: hex::decode refuses it (`$` + bytes.fromhex would not)
+    with pytest.raises(whisk.SerializationError):
+        crsmod.crs_from_hex(c2, bad)
     # sums that do not belong to the vectors: refused BEFORE anything is loaded — a fresh context stays without a CRS,
     # a context that held one keeps it
     other = orc.rng(8).g1_affine(ell + 7)
-    c3 = cpx.Context(0)
-    c3.set_crs(ell, other)
-    bad = dict(obj, G_sum=obj["H_sum"])
-    for c in (cpx.Context(0), c3):
-        with pytest.raises(ValueError):
-            crsmod.crs_from_hex(c, bad)
-    assert c3.crs_sums() == orc.crs_sums(ell, other) and c3.crs_points == other
+    c3, c4 = cpx.Context(0), cpx.Context(0)
+    try:
+        c3.set_crs(ell, other)
+        bad = dict(obj, G_sum=obj["H_sum"])
+        for c in (c4, c3):
+            with pytest.raises(ValueError):
+                crsmod.crs_from_hex(c, bad)
+        assert c3.crs_sums() == orc.crs_sums(ell, other) and c3.crs_points == other
+    finally:
+        for c in (c2, c3, c4):
+            c.close()
 
 
 @pytest.mark.parametrize("n", [128, 8])

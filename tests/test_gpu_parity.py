@@ -1040,50 +1040,170 @@ import os, sys, json
 sys.path.insert(0, %r)
 import torch, torch.distributed as dist
 import curdleproofs_amd as cpx
-from curdleproofs_amd.dist import max_over_ranks, all_gather_partials, fused_verify_all_ranks
+from curdleproofs_amd.dist import max_over_ranks, all_gather_partials, fused_verify_all_ranks, partition
 from tests.oracle_lib import Oracle
-torch.cuda.set_device(0)
-dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # nccl == RCCL on ROCm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))   # nccl == RCCL on ROCm
 orc = Oracle()
 ell = 28
 crs = orc.generate_crs_points(ell)
-insts = [orc.make_instance(ell, 40 + s, crs) for s in range(3)]
+every = [orc.make_instance(ell, 40 + s, crs) for s in range(3 * world)]
+insts = [every[i] for i in partition(len(every), world, rank)]       # this rank's share of ONE accumulated check over all proofs
 cat = lambda key: b"".join(i[key] for i in insts)
-c = cpx.Context(0)
+c = cpx.Context(rank)                                                 # one context per GPU: rank r drives device r
 c.set_crs(ell, crs)
 c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
 proofs = [i["proof"] for i in insts]
-rand = orc.rng(3).fr(12 * 3)
+rand = orc.rng(3 + rank).fr(12 * len(insts))
 dist.barrier()
-tmax = max_over_ranks(1.25, dist, "cuda")                      # ncclAllReduce(MAX) on a device tensor: the bench's timing step
+tmax = max_over_ranks(1.25 + rank, dist, "cuda")               # ncclAllReduce(MAX) on a device tensor: the bench's timing step
 part, bad = c.verify_batch_fused_partial(proofs, rand)
 parts, bad_total = all_gather_partials(part, bad, dist, "cuda")   # ncclAllGather of the 148-byte payload on device tensors
 ok = fused_verify_all_ranks(c, proofs, rand, dist, "cuda")
-wrong = fused_verify_all_ranks(c, [proofs[1], proofs[0], proofs[2]], rand, dist, "cuda")
-print(json.dumps(dict(backend=dist.get_backend(), tmax=tmax, same=parts == part, bad=bad_total, ok=bool(ok), wrong=bool(wrong))))
+swapped = [proofs[1], proofs[0], proofs[2]] if rank == world - 1 else proofs   # ONE rank holds wrong proofs: every rank must refuse
+wrong = fused_verify_all_ranks(c, swapped, rand, dist, "cuda")
+if rank == 0:
+    print(json.dumps(dict(backend=dist.get_backend(), world=world, tmax=tmax, nparts=len(parts) // 144, mine_first=parts[:144] == part, bad=bad_total, ok=bool(ok),
+                          wrong=bool(wrong), all_identity=c.sum_jac(parts)[1])))
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
 def test_rccl_collectives_of_the_fused_verifier_run_on_the_gpu(tmp_path):
-    """The exchange step of BASELINE configs[4] and the bench's timing reduction through backend "nccl" (= RCCL) on device tensors.
-    A 1-GPU box cannot host two RCCL ranks (RCCL refuses two ranks on one device), so the communicator has ONE rank: the same
-    ncclAllGather / ncclAllReduce calls on the same tensors as at N > 1, executed on the MI355X (the N = 2 data flow itself is
-    covered over gloo: tests/test_distributed_cpu.py and test_bench_two_ranks_on_one_gpu)."""
+    """The exchange step of BASELINE configs[4] and the bench's timing reduction through backend "nccl" (= RCCL) on device tensors, with
+    world = min(2, visible GPUs) ranks, rank r on device r.  On a 1-GPU box the communicator has ONE rank (RCCL refuses two ranks on
+    one device): the same ncclAllGather / ncclAllReduce calls on the same tensors; with a second GPU present the partial sums really
+    cross xGMI, one rank holds the wrong proofs and every rank must refuse the batch.  (The N = 2 data flow is also covered over gloo:
+    tests/test_distributed_cpu.py and test_bench_two_ranks_on_one_gpu.)"""
     import json
     import subprocess
     import sys
+    import curdleproofs_amd as cpx
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    world = min(2, cpx.device_count())
     script = tmp_path / "rccl_worker.py"
     script.write_text(RCCL_WORKER % root)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d == dict(backend="nccl", tmax=1.25, same=True, bad=0, ok=True, wrong=False)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK=str(rank), WORLD_SIZE=str(world),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.pop("LOCAL_RANK", None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o[-1500:] + e[-3000:]
+    d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert d == dict(backend="nccl", world=world, tmax=1.25 + world - 1, nparts=world, mine_first=True, bad=0, ok=True, wrong=False, all_identity=True)
+
+
+def _multi_device_shares(orc, ell, per_dev, ndev):
+    crs = orc.generate_crs_points(ell)
+    insts = [orc.make_instance(ell, 8000 + s, crs) for s in range(per_dev * ndev)]
+    return crs, [insts[d * per_dev:(d + 1) * per_dev] for d in range(ndev)]
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 8], ids=["one_gpu", "two_gpus", "eight_gpus"])
+def test_configs_4_and_5_in_process_over_the_visible_devices(orc, ndev):
+    """BASELINE configs[3] / configs[4] the way a Rust caller of the C-ABI would run them on a multi-GPU node, WITHOUT torch or RCCL: one
+    engine context and one host thread per device (cpx_ctx_create(d)), independent proofs sharded over the devices (no collective:
+    msm_accumulator.rs:55-68 needs none for per-proof verification), and for the batched verifier every device's 144-byte partial sum
+    (cpx_batch_verify_fused) brought to ONE context and added with cpx_g1_sum_jac — the in-process equivalent of the all-gather.
+    Runs on min(ndev, visible) ... skipped when the box has fewer than ndev GPUs (1-GPU boxes run the first case only)."""
+    import threading
+    import curdleproofs_amd as cpx
+    if cpx.device_count() < ndev:
+        pytest.skip("needs %d GPUs, %d visible" % (ndev, cpx.device_count()))
+    ell, per_dev = 28, 100   # >= 96 proofs per device: the device-resident protocol
+    crs, shares = _multi_device_shares(orc, ell, 4, ndev)
+    shares = [[sh[i % len(sh)] for i in range(per_dev)] for sh in shares]
+    partials, partials_bad, errors = [None] * ndev, [None] * ndev, []
+
+    def run(d):
+        try:
+            c = cpx.Context(d)
+            mine = shares[d]
+            cat = lambda key: b"".join(i[key] for i in mine)
+            c.set_crs(ell, crs)
+            c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+            proofs = c.prove_batch([x for i in mine for x in i["permutation"]], cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+            if [p == i["proof"] for p, i in zip(proofs, mine)] != [True] * per_dev:
+                errors.append("device %d: proof bytes differ from the oracle's" % d)
+            if c.verify_batch(proofs, cat("verifier_rand")) != [cpx.CPX_OK] * per_dev:
+                errors.append("device %d: a valid proof was rejected" % d)
+            frand = orc.rng(700 + d).fr(12 * per_dev)
+            partials[d] = c.verify_batch_fused_partial(proofs, frand)
+            bad = list(proofs)
+            bad[3] = proofs[2] if proofs[2] != proofs[3] else proofs[1]
+            partials_bad[d] = c.verify_batch_fused_partial(bad, frand) if d == ndev - 1 else partials[d]
+            c.close()
+        except Exception as e:
+            errors.append("device %d: %r" % (d, e))
+
+    th = [threading.Thread(target=run, args=(d,)) for d in range(ndev)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    c0 = cpx.Context(0)
+    try:
+        assert all(b == 0 for _, b in partials)
+        assert c0.sum_jac(b"".join(p for p, _ in partials))[1], "the partial sums of all devices must add up to the identity"
+        assert not c0.sum_jac(b"".join(p for p, _ in partials_bad))[1], "one device holds a wrong proof: the batch must be refused"
+    finally:
+        c0.close()
+
+
+def test_four_contexts_switching_crs_concurrently_stay_bit_exact(orc):
+    """Engine robustness (the sanitizer runs cover the host headers, not engine.cpp): FOUR contexts on four host threads, each walking its
+    own sequence over four CRS — two different CRS at ell = 28 and two at ell = 60 — with batches of 96 (device-resident protocol, cached
+    plans) in between: the process-wide registry of shared CRS tables (engine.cpp set_crs_impl: weak pointers, tables built once per
+    (device, CRS), released with their last context) and every context's plan caches are exercised CONCURRENTLY — contexts asking for
+    the same table at the same time, a table released by one context while another still proves with it, a context coming back to a
+    CRS whose table has meanwhile been rebuilt at another address.  Every proof's bytes and every verdict equal the oracle's."""
+    import threading
+    import curdleproofs_amd as cpx
+    nb = 96
+    crs_sets = {}
+    for ell in (28, 60):
+        for tag, pts in (("a", orc.generate_crs_points(ell)), ("b", orc.rng(4000 + ell).g1_affine(ell + 7))):
+            insts = [orc.make_instance(ell, 600 + s, pts) for s in range(3)]
+            crs_sets[(ell, tag)] = (pts, [insts[i % 3] for i in range(nb)])
+    keys = sorted(crs_sets)
+    errors = []
+
+    def run(t):
+        try:
+            c = cpx.Context(0)
+            order = [keys[(t + j * (1 + t % 3)) % 4] for j in range(6)]   # every thread its own walk; neighbours collide on the same CRS
+            for key in order:
+                ell = key[0]
+                pts, insts = crs_sets[key]
+                cat = lambda k_: b"".join(i[k_] for i in insts)
+                c.set_crs(ell, pts)
+                c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+                proofs = c.prove_batch([x for i in insts for x in i["permutation"]], cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+                if [p == i["proof"] for p, i in zip(proofs, insts)] != [True] * nb:
+                    errors.append("thread %d, CRS %s: proof bytes differ from the oracle's" % (t, key))
+                bad = list(proofs)
+                bad[7] = proofs[8]   # instance 8 != instance 7 (three instances repeating)
+                got = c.verify_batch(bad, cat("verifier_rand"))
+                if got != [cpx.CPX_OK] * 7 + [cpx.CPX_ERR_VERIFY] + [cpx.CPX_OK] * (nb - 8):
+                    errors.append("thread %d, CRS %s: verdicts %s" % (t, key, [j for j, v in enumerate(got) if v != cpx.CPX_OK]))
+                if not c.verify_batch_fused(proofs, orc.rng(t).fr(12 * nb)):
+                    errors.append("thread %d, CRS %s: fused verifier refused a valid batch" % (t, key))
+            c.close()
+        except Exception as e:
+            errors.append("thread %d: %r" % (t, e))
+
+    th = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["prove_verify", "config5_fused_verify"])

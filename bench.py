@@ -510,14 +510,23 @@ def main():
                 acc[f] += st[f]
         c.set_profiling(False)
     iso = None
-    if rank == 0 and K > 1:   # one more pass of context 0 ALONE (outside the timed region): uncontended kernel durations
-        c = ctxs[0]
+    if rank == 0:   # one more pass of context 0 ALONE, outside the timed region, with its side stream's kernels in line on the main stream
+        c = ctxs[0]  # (option serial_streams): every kernel then has the GPU to itself and its duration is its own — in the timed region a
+        c.set_option("serial_streams", 1)   # kernel shares the GPU with the other context AND with its own context's side stream
         c.set_profiling(True)
+        c.reset_stats()
+        step_one(0, [None] * K)             # (plans are rebuilt after an option change: this pass only counts for the all-launches average)
+        torch.cuda.synchronize()
+        for name, st in c.stats().items():
+            acc = warm.setdefault(name, dict(launches=0, ms=0.0))
+            acc["launches"] += st["launches"]
+            acc["ms"] += st["ms"]
         c.reset_stats()
         step_one(0, [None] * K)
         torch.cuda.synchronize()
         iso = c.stats()
         c.set_profiling(False)
+        c.set_option("serial_streams", 0)
 
     if rank == 0:
         n = ell + 4
@@ -570,9 +579,10 @@ def main():
         roofline["valu"] = dict(achieved=ach_mm, peak=peak_mm, unit="381-bit modular products/s", frac=ach_mm / peak_mm if peak_mm else None,
                                 mulmods_per_point=mulmods_per_point,
                                 note="kernel time is measured with all engine contexts sharing the GPU, so it includes the other contexts' kernels; "
-                                     "'isolated' repeats the measurement with one context running alone after the timed region")
+                                     "'isolated' repeats the measurement after the timed region with one context alone and its side stream's kernels in line "
+                                     "(option serial_streams): the kernel has the GPU to itself")
         if iso:   # every MSM kernel, one context alone: point-scalar pairs, additions x their product equivalents against the measured peak
-            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11,
+            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_tblw_pair": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11,
                         "k_msm_fix": 16 * PROD_PER_ADD}
             pair_cost = lambda k: (14 * PROD_PER_ADD if k.startswith("k_msm_fix<19") else per_pair[k.split("<")[0]])
             roofline["valu"]["isolated_by_kernel"] = {
@@ -587,6 +597,9 @@ def main():
             iso_mm = ist["units"] * mulmods_per_point / (ist["ms"] * 1e-3)
             roofline["valu"]["isolated"] = dict(achieved=iso_mm, frac=iso_mm / peak_mm if peak_mm else None, launches=ist["launches"],
                                                 avg_launch_ms=ist["ms"] / max(ist["launches"], 1))
+            # the isolated pass as a whole: one context, one stream — the pass is the plain sum of its kernels
+            roofline["valu"]["isolated_pass"] = dict(proofs=B // K, kernel_ms={k: v["ms"] for k, v in iso.items() if v["launches"] and not k.startswith("host_")},
+                                                     wall_ms=iso.get("host_prove_wall", {}).get("ms", 0.0) + iso.get("host_verify_wall", {}).get("ms", 0.0))
         out = dict(metric="shuffle proofs/sec (prove+verify) at ell=%d, BLS12-381" % ell, value=value, unit="proofs/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="int64", data="synthetic",

@@ -387,7 +387,7 @@ class Context:
         return dict(launches=n.value, ms=ms.value, alg_bytes=by.value, units=un.value)
 
     KERNELS = ("k_msm_tblw<32, false>", "k_reduce_sets", "k_msm_tblw<16, false>", "k_msm_tblw<8, false>", "k_msm_tblw<4, false>", "k_msm_tblw<2, false>", "k_msm_fix<19, 7>", "k_msm_fix<16, 4>", "k_msm_fix<16, 2>", "k_msm_fix<16, 16>", "k_msm_fix<16, 8>", "k_msm_fix<8, 16>", "k_msm_fix<8, 8>",
-               "k_late_fix", "k_late_uniform", "k_late_tables", "k_late_msm", "k_finalize_ranges", "k_table_build", "k_msm_accw", "k_msm_tblw<2, true>", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_prove_wall", "host_verify_wall")
+               "k_transcript_step1", "k_msm_tblw_pair", "k_late_fix", "k_late_uniform", "k_late_tables", "k_late_msm", "k_finalize_ranges", "k_table_build", "k_msm_accw", "k_msm_tblw<2, true>", "k_msm_tail", "k_smul", "k_finalize", "k_compress", "k_decompress", "host_parallel_for", "host_wait_device", "host_prove_wall", "host_verify_wall")
 
     def stats(self):
         return {k: self.stat(k) for k in self.KERNELS}

@@ -242,7 +242,7 @@ class Engine {
     DevBuf<uint32_t> perm, mdst;
     DevBuf<Fr> k, mbl, rnd, vec, sc, rvec2;
     DevBuf<uint8_t> slotcomp, proofs;
-    TblPlan p1, p2, p3;
+    TblPlan p1, p1b, p2, p3;
     std::vector<std::unique_ptr<TblPlan>> ipa, smsm;
     // the last log rounds on materialised folded bases (late.hip; options late_rounds, late_min_batch)
     struct Late {

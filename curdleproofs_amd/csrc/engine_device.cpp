@@ -240,11 +240,13 @@ void Engine::prepare_device_prover() {
     CPX_HIP(hipMemcpy(dp.mdst.p, md.data(), B * 4, hipMemcpyHostToDevice));
   }
   // -- phase 1: everything that depends only on vec_a and the prover's randomness (curdleproofs.rs:93,110-116,
-  //    same_multiscalar_argument.rs:80-82, inner_product_argument.rs:126, same_scalar_argument.rs:60-61)
+  //    same_multiscalar_argument.rs:80-82, inner_product_argument.rs:126, same_scalar_argument.rs:60-61).
   for (size_t p = 0; p < B; p++) {
     const int TMPX = sm.TMP(6);   // compressed bytes nobody reads
-    reqs.push_back(req(cseg(0, (uint32_t)n), none, vec(p, V_APERM), slot_index(p, SL_A)));            // A
-    ci.push_back(cidx(p, SL_A));
+    if (!opt_.p1_split) {
+      reqs.push_back(req(cseg(0, (uint32_t)n), none, vec(p, V_APERM), slot_index(p, SL_A)));          // A
+      ci.push_back(cidx(p, SL_A));
+    }
     reqs.push_back(req(cseg(0, (uint32_t)n, iGb), none, rnd(p, ri.VR())));                            // B_a
     ci.push_back(cidx(p, sm.BA()));
     reqs.push_back(req(pseg(p, O_T, (uint32_t)n), none, rnd(p, ri.VR())));                            // B_t
@@ -268,6 +270,16 @@ void Engine::prepare_device_prover() {
     }
   }
   build_plan(dp.p1, reqs, ci);
+  // -- phase 1b (option p1_split): A = msm(G | Hvec, a_sigma | blinders) (curdleproofs.rs:93) alone — the one commitment of phase 1
+  //    that needs vec_a; the rest of the phase then runs before the main stream waits for the transcript prefix
+  reqs.clear();
+  ci.clear();
+  if (opt_.p1_split)
+    for (size_t p = 0; p < B; p++) {
+      reqs.push_back(req(cseg(0, (uint32_t)n), none, vec(p, V_APERM), slot_index(p, SL_A)));
+      ci.push_back(cidx(p, SL_A));
+    }
+  build_plan(dp.p1b, reqs, ci);
   // -- phase 2: B = A + alpha M + beta sum(G) (same_permutation_argument.rs:75-76), A' = A + cm_T.T_1 + cm_U.T_1
   //    (curdleproofs.rs:134), C = msm(G | Hvec, c) (grand_product_argument.rs:76)
   reqs.clear();
@@ -455,6 +467,7 @@ void Engine::prepare_device_prover() {
       max_sets = std::max(max_sets, pl.fix_sets + pl.tbl_sets);
     };
     upd(dp.p1);
+    upd(dp.p1b);
     upd(dp.p2);
     upd(dp.p3);
     for (auto& pl : dp.ipa)
@@ -478,6 +491,9 @@ void Engine::enqueue_prove_device() {
   DevProver& dp = dprove_;
   const ProveDev& d = dp.dev;
   const int Bi = (int)B;
+  // (measurement aid, option serial_streams: the side stream's work in line on the main stream, so that every kernel's duration is its
+  // own and a pass is the plain sum of its kernels)
+  hipStream_t const side = opt_.serial_streams ? stream_ : side_.stream;
   // -- P0: compressed instance vectors, M -> affine (table source slot 0); side stream: transcript prefix (instance + M
   //    absorbed, vec_a drawn), then R and S; main stream: the per-proof tables
   tick("k_compress", 0, (double)(4 * ell * B));
@@ -485,31 +501,48 @@ void Engine::enqueue_prove_device() {
   tock();
   launch_finalize(d_Mjac_.p, Bi, d_psrc_.p, dp.mdst.p, d_mcomp_.p, stream_);
   CPX_HIP(hipEventRecord(dp.ev_a, stream_));
-  CPX_HIP(hipStreamWaitEvent(side_.stream, dp.ev_a, 0));
-  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side_.stream);
-  CPX_HIP(hipEventRecord(dp.ev_b, side_.stream));
+  CPX_HIP(hipStreamWaitEvent(side, dp.ev_a, 0));
+  tick("k_transcript_step1", 0, (double)B);
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B >= opt_.transcript_lane_min_batch);
+  tock();
+  CPX_HIP(hipEventRecord(dp.ev_b, side));
   {
     const int nt = 2 * Bi;
     // (R and S of a proof share the scalars vec_a: one wave per (proof, window) serves both, kernels.h launch_msm_endo_pairs)
-    if (opt_.rs_pairs) launch_msm_endo_pairs(side_.tasks.p, Bi, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
-    else launch_msm_endo(side_.tasks.p, nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side_.stream);
-    launch_reduce_sets(opt_, side_.raw.p, side_.rawslot.p, 0, nt * 32, side_.mid.p, side_.part.p, side_.stream, Bi);
-    launch_msm_tail(opt_, side_.part.p, nullptr, side_.res.p, nt, 16, 8, side_.stream, nullptr, 0, 2);
-    launch_finalize(side_.res.p, nt, d_pp_.p, side_.dst.p, nullptr, side_.stream);
+    tick(opt_.rs_pairs ? "k_msm_tblw_pair" : "k_msm_tblw<2, true>", 128.0 * 2 * ell * B, (double)(2 * ell * B));
+    if (opt_.rs_pairs) launch_msm_endo_pairs(side_.tasks.p, Bi, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side);
+    else launch_msm_endo(side_.tasks.p, nt, (int)ell, side_.conv.p, side_.digits.p, side_.ttasks.p, side_.raw.p, side_.rawslot.p, side);
+    tock();
+    if (opt_.serial_streams) tick("k_reduce_sets", 0, (double)(nt * 32), true);   // (a span is bracketed on the main stream)
+    launch_reduce_sets(opt_, side_.raw.p, side_.rawslot.p, 0, nt * 32, side_.mid.p, side_.part.p, side, Bi);
+    if (opt_.serial_streams) tock();
+    tick("k_msm_tail", 0, (double)nt);
+    launch_msm_tail(opt_, side_.part.p, nullptr, side_.res.p, nt, 16, 8, side, nullptr, 0, 2);
+    tock();
+    launch_finalize(side_.res.p, nt, d_pp_.p, side_.dst.p, nullptr, side);
   }
   tick("k_table_build", 0, (double)(B * NP));
   launch_table_build(opt_, d_psrc_.p, NP, d_ptab_.p, Bi, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
   tock();
-  CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_b, 0));   // vec_a and the transcript states
-
-  // -- P1
-  launch_ps_aperm(d, Bi, stream_);
-  exec_plan(dp.p1, dp.slotcomp.p);
-  CPX_HIP(hipEventRecord(dp.ev_c, stream_));           // the r * H points of the T_2 commitments are in TMP0..3
-  CPX_HIP(hipStreamWaitEvent(side_.stream, dp.ev_c, 0));
-  launch_smul(side_.stasks.p, 4 * Bi, 1, side_.stream);
-  launch_compress_cols(d_pp_.p + 4 * ell, dp.side_cols, 6, (int)pp_stride_, Bi, dp.slotcomp.p, (int)NS, side_.stream);
-  CPX_HIP(hipEventRecord(dp.ev_d, side_.stream));
+  if (opt_.p1_split) {   // the randomness-only commitments beside the prefix, A behind it
+    exec_plan(dp.p1, dp.slotcomp.p);
+    CPX_HIP(hipEventRecord(dp.ev_c, stream_));
+    CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_b, 0));
+    launch_ps_aperm(d, Bi, stream_);
+    exec_plan(dp.p1b, dp.slotcomp.p);
+  } else {
+    CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_b, 0));   // vec_a and the transcript states
+    // -- P1
+    launch_ps_aperm(d, Bi, stream_);
+    exec_plan(dp.p1, dp.slotcomp.p);
+    CPX_HIP(hipEventRecord(dp.ev_c, stream_));           // the r * H points of the T_2 commitments are in TMP0..3
+  }
+  CPX_HIP(hipStreamWaitEvent(side, dp.ev_c, 0));
+  tick("k_smul", 0, (double)(4 * B));
+  launch_smul(side_.stasks.p, 4 * Bi, 1, side);
+  tock();
+  launch_compress_cols(d_pp_.p + 4 * ell, dp.side_cols, 6, (int)pp_stride_, Bi, dp.slotcomp.p, (int)NS, side);
+  CPX_HIP(hipEventRecord(dp.ev_d, side));
   launch_ps_sameperm(d, Bi, stream_);
   // -- P2, P3
   exec_plan(dp.p2, dp.slotcomp.p);
@@ -751,9 +784,12 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
   tock();
   launch_finalize(d_Mjac_.p, Bi, d_pp_.p, dv.mdst.p, d_mcomp_.p, stream_);
   CPX_HIP(hipEventRecord(dv.ev_a, stream_));
-  CPX_HIP(hipStreamWaitEvent(side_.stream, dv.ev_a, 0));
-  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side_.stream);
-  CPX_HIP(hipEventRecord(dv.ev_b, side_.stream));
+  hipStream_t const side = opt_.serial_streams ? stream_ : side_.stream;
+  CPX_HIP(hipStreamWaitEvent(side, dv.ev_a, 0));
+  tick("k_transcript_step1", 0, (double)B);
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B >= opt_.transcript_lane_min_batch);
+  tock();
+  CPX_HIP(hipEventRecord(dv.ev_b, side));
   tick("k_decompress", 0, (double)(B * NPP));
   launch_decompress(opt_, dv.proofs.p, (int)(B * NPP), d_pp_.p, dv.dst.p, dv.status.p, 1, stream_, dv.src_off.p);
   tock();

@@ -1379,6 +1379,135 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
   t.store(out_state + (size_t)p * 27);
 }
 
+// The same prefix with ONE LANE per transcript (large batches: option transcript_lane_min_batch).  The lane-parallel form above is built
+// for latency — 32 lanes and ~1.07 M wave instructions per pair of proofs, 3.5 % of a pass's VALU time at 8192 proofs — but a large
+// batch hides the prefix behind the table build (prover) and the decompression (verifier) anyway; one lane per transcript runs the
+// plain 64-bit Keccak of strobe.hpp (~1/5 of the wave instructions per proof) on 1/32 of the waves.  The sponge state lives in LDS,
+// word-interleaved by lane (word i of lane l at [i * 64 + l]: dynamic word indices without scratch memory, no bank conflicts).
+struct LaneStrobe {
+  uint64_t* st;   // &lds[lane]; word i at st[64 * i]
+  uint32_t pos, pos_begin;
+  __device__ __forceinline__ uint64_t& w(uint32_t i) { return st[64 * i]; }
+  __device__ __forceinline__ void xor_byte(uint32_t i, uint8_t b) { w(i >> 3) ^= (uint64_t)b << (8 * (i & 7)); }
+  __device__ void run_f() {
+    xor_byte(pos, (uint8_t)pos_begin);
+    xor_byte(pos + 1, 0x04);
+    xor_byte(Strobe::RATE + 1, 0x80);
+    uint64_t a[25];
+    CPX_UNROLL for (int i = 0; i < 25; i++) a[i] = st[64 * i];
+    keccak_f1600(a);
+    CPX_UNROLL for (int i = 0; i < 25; i++) st[64 * i] = a[i];
+    pos = pos_begin = 0;
+  }
+  __device__ void absorb(const uint8_t* d, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+      if ((pos & 7) == 0 && n - i >= 8 && pos + 8 <= Strobe::RATE) {
+        uint64_t v;
+        if ((reinterpret_cast<uintptr_t>(d + i) & 7) == 0) v = *reinterpret_cast<const uint64_t*>(d + i);
+        else {
+          v = 0;
+          for (int j = 0; j < 8; j++) v |= (uint64_t)d[i + j] << (8 * j);
+        }
+        w(pos >> 3) ^= v;
+        pos += 8;
+        i += 8;
+        continue;
+      }
+      xor_byte(pos, d[i++]);
+      if (++pos == Strobe::RATE) run_f();
+    }
+  }
+  __device__ void begin_op(uint32_t flags, bool more) {
+    if (more) return;
+    const uint8_t hdr[2] = {(uint8_t)pos_begin, (uint8_t)flags};
+    pos_begin = pos + 1;
+    absorb(hdr, 2);
+    if ((flags & (Strobe::FLAG_C | Strobe::FLAG_K)) && pos != 0) run_f();
+  }
+  __device__ void meta_ad(const void* d, size_t n, bool more) {
+    begin_op(Strobe::FLAG_M | Strobe::FLAG_A, more);
+    absorb(static_cast<const uint8_t*>(d), n);
+  }
+  __device__ void append_begin(const char* label, size_t label_len, size_t len) {
+    const uint8_t l4[4] = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
+    meta_ad(label, label_len, false);
+    meta_ad(l4, 4, true);
+    begin_op(Strobe::FLAG_A, false);
+  }
+  __device__ void init(const char* label, size_t label_len) {
+    for (int i = 0; i < 25; i++) st[64 * i] = 0;
+    const uint8_t ini[18] = {1, 168, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
+    for (int i = 0; i < 18; i++) xor_byte(i, ini[i]);
+    pos = pos_begin = 0;
+    {
+      uint64_t a[25];
+      CPX_UNROLL for (int i = 0; i < 25; i++) a[i] = st[64 * i];
+      keccak_f1600(a);
+      CPX_UNROLL for (int i = 0; i < 25; i++) st[64 * i] = a[i];
+    }
+    meta_ad("Merlin v1.0", 11, false);
+    append_begin("dom-sep", 7, label_len);
+    absorb(reinterpret_cast<const uint8_t*>(label), label_len);
+  }
+};
+__global__ __launch_bounds__(64) void k_transcript_step1_lane(const uint8_t* __restrict__ inst_comp, const uint8_t* __restrict__ m_comp, int nproofs, int ell,
+                                                              uint64_t* __restrict__ out_state, Fr* __restrict__ out_vec_a) {
+  __shared__ uint64_t lds[25 * 64];
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= nproofs) return;   // (no barrier below: a lane only touches its own words)
+  LaneStrobe t;
+  t.st = lds + threadIdx.x;
+  t.init("curdleproofs", 12);
+  for (int v = 0; v < 4; v++) {   // Vec<G1Affine>: u64-LE length prefix, then the compressed points, as one message
+    t.append_begin("curdleproofs_step1", 18, 8 + 48 * (size_t)ell);
+    uint8_t len8[8];
+    for (int j = 0; j < 8; j++) len8[j] = (uint8_t)((uint64_t)ell >> (8 * j));
+    t.absorb(len8, 8);
+    t.absorb(inst_comp + ((size_t)p * 4 + v) * ell * 48, 48 * (size_t)ell);
+  }
+  t.append_begin("curdleproofs_step1", 18, 48);
+  t.absorb(m_comp + (size_t)p * 48, 48);
+  for (int i = 0; i < ell; i++) {
+    for (;;) {   // get_and_append_challenge (transcript.rs:40-60), as in k_transcript_step1
+      const uint8_t l4[4] = {64, 0, 0, 0};
+      t.meta_ad("curdleproofs_vec_a", 18, false);
+      t.meta_ad(l4, 4, true);
+      t.begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
+      uint64_t sq[4];
+      CPX_UNROLL for (int j = 0; j < 4; j++) sq[j] = t.w(j);
+      CPX_UNROLL for (int j = 0; j < 8; j++) t.w(j) = 0;   // the PRF operation overwrites the 64 squeezed bytes with zero
+      t.pos = 64;
+      sq[3] &= 0x7fffffffffffffffULL;
+      Fr c;
+      CPX_UNROLL for (int j = 0; j < 4; j++) {
+        c.v[2 * j] = (uint32_t)sq[j];
+        c.v[2 * j + 1] = (uint32_t)(sq[j] >> 32);
+      }
+      bool nz = false, lt = false;
+      for (int j = 0; j < 8; j++) nz |= c.v[j] != 0;
+      for (int j = 7; j >= 0; j--) {
+        if (c.v[j] != FrCfg::P[j]) {
+          lt = c.v[j] < FrCfg::P[j];
+          break;
+        }
+      }
+      if (lt && nz) {
+        t.append_begin("curdleproofs_vec_a", 18, 32);
+        uint8_t b32[32];
+        CPX_UNROLL for (int j = 0; j < 32; j++) b32[j] = (uint8_t)(sq[j >> 3] >> (8 * (j & 7)));
+        t.absorb(b32, 32);
+        out_vec_a[(size_t)p * ell + i] = fe_to_mont(c);
+        break;
+      }
+    }
+  }
+  uint64_t* o = out_state + (size_t)p * 27;
+  for (int i = 0; i < 25; i++) o[i] = t.w(i);
+  o[25] = t.pos;
+  o[26] = t.pos_begin;
+}
+
 // ------------------------------------------------------------------ micro-benchmarks (bench.py --micro)
 // Dependent Fp multiply chains: measures the achieved modular-multiply rate of this build.
 __global__ __launch_bounds__(256) void k_bench_fpmul(Fp* data, int iters) {
@@ -1425,7 +1554,8 @@ const OptField kOptFields[] = {
     {"device_min_batch", &Options::device_min_batch, 1, 1L << 30}, {"spin_team", &Options::spin_team, 0, 1},
     {"spin_team_threads", &Options::spin_team_threads, 1, 256},  {"inline_below", &Options::inline_below, 0, 1L << 30},
     {"cu_mask", &Options::cu_mask, 0, 1},                        {"trace", &Options::trace, 0, 1},
-    {"bench_field", &Options::bench_field, 12, 28},
+    {"bench_field", &Options::bench_field, 12, 28},              {"serial_streams", &Options::serial_streams, 0, 1},
+    {"p1_split", &Options::p1_split, 0, 1},                      {"transcript_lane_min_batch", &Options::transcript_lane_min_batch, 1, 1L << 30},
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
 };
@@ -1712,8 +1842,12 @@ void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr
 void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s, int active) {
   if (nproofs > 0) CPX_LAUNCH(k_smsm_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, active > 0 ? active : n, half, d_gam);
 }
-void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s) {
+void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s, bool lane_per_proof) {
   if (nproofs <= 0) return;
+  if (lane_per_proof) {
+    CPX_LAUNCH(k_transcript_step1_lane, dim3((nproofs + 63) / 64), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
+    return;
+  }
   CPX_LAUNCH(k_transcript_step1, dim3((nproofs + 1) / 2), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
 }
 void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s) { CPX_LAUNCH(k_sum_jac, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_flag); }

@@ -542,6 +542,8 @@ VARIANTS = {
     "late_rounds_one_lane_per_output": {"late_min_batch": 1, "device_min_batch": 1, "late_slices": 1},
     "late_rounds_eight_lanes_per_output": {"late_min_batch": 1, "device_min_batch": 1, "late_slices": 8, "tail_wave_max": 0},
     "late_rounds_off": {"late_rounds": 0, "device_min_batch": 1},
+    "lane_per_transcript_prefix": {"transcript_lane_min_batch": 1, "device_min_batch": 1},   # k_transcript_step1_lane: one lane per proof hashes the instance
+    "phase1_in_one_piece": {"p1_split": 0, "device_min_batch": 1},   # A inside phase 1 (default: phase 1 without A before the transcript prefix is awaited, A behind it)
     "rs_as_two_tasks": {"rs_pairs": 0, "device_min_batch": 1},     # R = <a, vec_R>, S = <a, vec_S> as separate tasks (default: one wave serves both)
 }
 
@@ -921,7 +923,8 @@ def test_bench_code_path_one_context_default_options_every_proof_matches_oracle(
         c.set_profiling(True)
         c.reset_stats()
         proofs = c.prove_batch([x for i in insts for x in i["permutation"]], cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
-        for name in ("k_late_fix", "k_late_uniform", "k_late_tables", "k_late_msm", "k_msm_fix<16, 16>", "k_msm_tblw<32, false>"):
+        assert (N >= c.get_option("transcript_lane_min_batch")) == (ell == 252)   # the one-lane-per-proof prefix kernel runs at 2048 proofs, the 32-lane one at 512
+        for name in ("k_late_fix", "k_late_uniform", "k_late_tables", "k_late_msm", "k_msm_fix<16, 16>", "k_msm_tblw<32, false>", "k_transcript_step1"):
             assert c.stat(name)["launches"] > 0, "%s did not run: this is not the bench's code path" % name
         c.set_profiling(False)
         wrong = [j for j, (i, p) in enumerate(zip(insts, proofs)) if p != i["proof"]]

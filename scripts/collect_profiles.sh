@@ -4,7 +4,7 @@
 # PMC passes are separate runs (no traces together with --pmc).  The HBM counter pass runs first because bench.py reads
 # profiles/${RND}_hbm_counters.json for roofline.traffic.
 set -x
-RND=${RND:-r03}
+RND=${RND:-r04}
 R=$PWD
 O=$R/gpurun_out/prof
 mkdir -p $O
@@ -28,6 +28,11 @@ python bench.py --fused-verify --synth-cache /tmp/synth.pkl 2>/dev/null | tail -
 # one engine context alone (4096 and 8192 proofs per pass): uncontended kernel durations, what a pass consists of
 python bench.py --synth-cache /tmp/synth.pkl --no-cpu-baseline --no-extra-shapes --ctxs 1 --batch 8192 --steps 4 2>/dev/null | tail -1 > $O/${RND}_bench_one_context.json
 python bench.py --synth-cache /tmp/synth.pkl --no-cpu-baseline --no-extra-shapes --opt late_rounds=0 --steps 6 2>/dev/null | tail -1 > $O/${RND}_bench_late_rounds_off.json
+# one context with its side stream's kernels in line on the main stream: every kernel alone on the GPU, a pass = the sum of its kernels
+python bench.py --synth-cache /tmp/synth.pkl --no-cpu-baseline --no-extra-shapes --ctxs 1 --batch 8192 --steps 4 --opt serial_streams=1 2>/dev/null | tail -1 > $O/${RND}_bench_serial_streams.json
+# A/B of this round's defaults on the same box: the 32-lane transcript prefix kernel at every batch size, phase 1 in one piece
+python bench.py --synth-cache /tmp/synth.pkl --no-cpu-baseline --no-extra-shapes --opt transcript_lane_min_batch=1000000000 --steps 6 2>/dev/null | tail -1 > $O/${RND}_bench_wave_transcript.json
+python bench.py --synth-cache /tmp/synth.pkl --no-cpu-baseline --no-extra-shapes --steps 6 2>/dev/null | tail -1 > $O/${RND}_bench_defaults_again.json
 python scripts/single_proof_latency.py > $O/${RND}_single_proof_latency.txt 2>&1
 # the lone-proof timeline (which kernel a lone proof waits for, launch by launch) and the micro-benchmarks behind the latency kernels
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/scripts/single_proof_timeline.py run > /dev/null 2>&1; python $R/scripts/single_proof_timeline.py report /tmp/tl > $O/${RND}_single_proof_timeline.txt 2>&1 )

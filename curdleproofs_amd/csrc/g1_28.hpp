@@ -248,12 +248,19 @@ CPX_HD F28 f28_sqrt_candidate(const F28& a) {
     while (!bit(j)) j++;
     uint32_t v = 0;
     for (int t = i; t >= j; t--) v = (v << 1) | bit(t);
-    const F28& f = v == 1 ? a : v == 3 ? a3 : v == 5 ? a5 : a7;
+    // (one call per table entry instead of a reference picked among the four: hipcc turned `const F28& f = v == 1 ? a : ...` into a
+    // select between flat pointers to spilled limbs, and the device function then read garbage — the CPU build was fine)
     if (started) {
       for (int t = i; t >= j; t--) r = f28_sqr(r);
-      r = f28_mul(r, f);
+      if (v == 1) r = f28_mul(r, a);
+      else if (v == 3) r = f28_mul(r, a3);
+      else if (v == 5) r = f28_mul(r, a5);
+      else r = f28_mul(r, a7);
     } else {
-      r = f;
+      if (v == 1) r = a;
+      else if (v == 3) r = a3;
+      else if (v == 5) r = a5;
+      else r = a7;
       started = true;
     }
     i = j - 1;

@@ -36,7 +36,7 @@ struct Options {
   long late_min_batch = 2048;      // ... for batches of at least this many proofs (n <= 256; scaled by 256 / n above: 512 at ell = 1020); the lane-per-output kernels need a full GPU to pay
   long late_slices = 8;            // lanes per cross term of a late round (1, 2, 4, 8): 15.3 k proofs/s at 8, 14.9 k at 4 and 2, 14.3 k at 1
   long rs_pairs = 1;               // 1: the prover's R and S MSMs of a proof share their waves (same scalars: one digit sort for both); 0: two separate tasks
-  long transcript_lane_min_batch = 2048;   // batches of at least this many proofs hash the transcript prefix with one LANE per proof (k_transcript_step1_lane: a fifth of the wave instructions, hidden behind the table build / the decompression; +1.6 % at 2 x 8192 proofs)
+  long transcript_lane_min_batch = 8192;   // batches of at least this many proofs (n <= 256; scaled by n / 256 above) hash the transcript prefix with one LANE per proof (k_transcript_step1_lane): a fifth of the wave instructions but a chain of 19 ms at ell = 252 — only where the table build (prover) and the decompression (verifier: 18.7 ms per 8192 proofs) hide it; +2.2 % at 2 x 8192 proofs
   long p1_split = 1;               // 1: phase 1 without A (it only needs the prover's randomness) runs before the main stream waits for the transcript prefix, A alone behind it: 128 proofs 41.7 -> 40.6 ms per pass, nothing at 8192
   long serial_streams = 0;         // 1 (measurement aid): the side stream's kernels run in line on the main stream — every kernel's duration is its own
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form

@@ -1313,21 +1313,17 @@ __global__ __launch_bounds__(128) void k_smsm_round_fold(Fr* __restrict__ vec, i
 // hashed here and only the transcript state (25 lanes + pos + pos_begin) and vec_a travel to the host, which
 // continues from the state (host::Transcript::load_state).
 //
-// Lane-parallel STROBE: half a wave (32 lanes) per proof, lane l < 25 holds 64-bit lane l of the Keccak state
-// (x = l % 5, y = l / 5); a round is 9 cross-lane shuffles (theta 6, rho+pi 1, chi 2) instead of ~150 dependent
-// 64-bit operations on one lane (a single GPU lane needs ~17 us per permutation, the 32-lane form ~4 us).  Message bytes
-// are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.hpp (the host's code),
-// pinned by the bit-exact proof tests.
+// Lane-parallel STROBE (wave_strobe.hpp): one wave per proof, the 25 state words bit-interleaved over the two halves of the wave
+// (a single GPU lane needs ~17 us per permutation).  Message bytes are absorbed by the lanes that own their position in the rate.
+// Same semantics as strobe.hpp (the host's code), pinned by the bit-exact proof tests.
 // out_state: [nproofs][27] u64, out_vec_a: [nproofs][ell] Fr (Montgomery wire form)
 __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restrict__ inst_comp, const uint8_t* __restrict__ m_comp, int nproofs, int ell,
                                                          uint64_t* __restrict__ out_state, Fr* __restrict__ out_vec_a) {
-  __shared__ uint8_t scratch_all[2][64];
-  const int grp = threadIdx.x >> 5;
-  const int p = blockIdx.x * 2 + grp;
-  uint8_t* scratch = scratch_all[grp];
-  if (p >= nproofs) return;   // whole 32-lane groups leave together
+  __shared__ uint8_t scratch[64];
+  const int p = blockIdx.x;
+  if (p >= nproofs) return;
   WaveStrobe t;
-  t.set_lane(threadIdx.x & 31);
+  t.set_lane(threadIdx.x);
   t.init("curdleproofs", 12, scratch);
   for (int v = 0; v < 4; v++) {   // Vec<G1Affine>: u64-LE length prefix, then the compressed points, as one message
     t.append_begin("curdleproofs_step1", 18, 8 + 48 * (size_t)ell, scratch);
@@ -1338,43 +1334,11 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
   }
   t.append_begin("curdleproofs_step1", 18, 48, scratch);
   t.absorb(m_comp + (size_t)p * 48, 48);
-  for (int i = 0; i < ell; i++) {
-    // get_and_append_challenge (transcript.rs:40-60): 64 PRF bytes, Fr::from_random_bytes on the first 32 with the top
-    // bit cleared, retried until canonical and non-zero, then appended back under the same label
-    for (;;) {
-      t.meta_ad("curdleproofs_vec_a", 18, false);
-      t.len4(64, scratch);
-      t.begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
-      // squeeze 64 bytes = lanes 0..7 of the state, which the PRF operation overwrites with zero (pos is 0 here)
-      uint64_t sq[4];
-      CPX_UNROLL for (int j = 0; j < 4; j++) sq[j] = t.shfl(t.a, WaveStrobe::lane_of_word(j));
-      if (t.w >= 0 && t.w < 8) t.a = 0;
-      t.pos = 64;
-      sq[3] &= 0x7fffffffffffffffULL;
-      Fr c;
-      CPX_UNROLL for (int j = 0; j < 4; j++) {
-        c.v[2 * j] = (uint32_t)sq[j];
-        c.v[2 * j + 1] = (uint32_t)(sq[j] >> 32);
-      }
-      bool nz = false, lt = false;
-      for (int j = 0; j < 8; j++) nz |= c.v[j] != 0;
-      for (int j = 7; j >= 0; j--) {
-        if (c.v[j] != FrCfg::P[j]) {
-          lt = c.v[j] < FrCfg::P[j];
-          break;
-        }
-      }
-      if (lt && nz) {
-        if (t.l < 4) {
-          CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * t.l + j] = (uint8_t)(sq[t.l] >> (8 * j));
-        }
-        wave_lds_sync();
-        t.append_begin("curdleproofs_vec_a", 18, 32, scratch);
-        t.absorb(scratch + 16, 32);
-        if (t.l == 0) out_vec_a[(size_t)p * ell + i] = fe_to_mont(c);
-        break;
-      }
+  for (int i = 0; i < ell; i++) {   // get_and_append_challenge (transcript.rs:40-60)
+    Fr c;
+    while (!t.challenge_attempt("curdleproofs_vec_a", 18, scratch, c)) {
     }
+    if (threadIdx.x == 0) out_vec_a[(size_t)p * ell + i] = fe_to_mont(c);
   }
   t.store(out_state + (size_t)p * 27);
 }
@@ -1848,7 +1812,7 @@ void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp
     CPX_LAUNCH(k_transcript_step1_lane, dim3((nproofs + 63) / 64), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
     return;
   }
-  CPX_LAUNCH(k_transcript_step1, dim3((nproofs + 1) / 2), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
+  CPX_LAUNCH(k_transcript_step1, dim3(nproofs), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
 }
 void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s) { CPX_LAUNCH(k_sum_jac, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_flag); }
 void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s) {

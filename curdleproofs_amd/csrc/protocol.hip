@@ -1,7 +1,7 @@
 // Device-resident protocol steps of the MI355X Curdleproofs core (gfx950) — product code.  See protocol.h.
 //
 // One 64-lane wave per proof.  The transcript (merlin / STROBE-128, transcript.rs:28-60) runs in the lane-parallel form of
-// wave_strobe.hpp — both 32-lane halves of the wave perform the same operations and hold identical copies of the state —
+// wave_strobe.hpp — the state bit-interleaved over the two 32-lane halves of the wave, values the callers see uniform over the wave —
 // and the scalar-field vectors of a proof (n = ell + 4 entries) are spread over the 64 lanes: elementwise work is
 // lane-strided, products and sums are wave reductions, prefix products (the grand-product vector c, powers of beta) are
 // chunked scans through LDS.  Every kernel reads the transcript state of its proof, continues it and writes it back;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void k_ps_sameperm(const ProveDev d) {
   const Fr* veca = d.veca + (size_t)v.p * ell;
   const uint32_t* perm = d.perm + (size_t)v.p * ell;
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   t.append_message(LBL("same_perm_step1"), v.slot(SL_A), 48, scratch);
   t.append_message(LBL("same_perm_step1"), d.mcomp + (size_t)v.p * 48, 48, scratch);
   // vec_a as Vec<Fr>: u64-LE length, then the canonical scalars, one message
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void k_ps_sameperm(const ProveDev d) {
     sc[SC_BETA_SP] = beta;
     sc[SC_GPROD] = buf[ell - 1];
   }
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
 }
 
 // S3 (after phase 2: B, A', C): grand-product challenges, the IPA witness vectors and blinders.
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void k_ps_gprod(const ProveDev d) {
   Fr* sc = v.sc();
   const Fr alpha_sp = sc[SC_ALPHA_SP], gprod = sc[SC_GPROD];
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   t.append_message(LBL("gprod_step1"), v.slot(SL_B), 48, scratch);
   t.append_scalar(LBL("gprod_step1"), gprod, scratch);
   const Fr alpha_g = t.challenge_scalar(LBL("gprod_alpha"), scratch);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void k_ps_gprod(const ProveDev d) {
   t.append_message(LBL("gprod_step2"), v.slot(SL_C), 48, scratch);
   t.append_scalar(LBL("gprod_step2"), r_p, scratch);
   const Fr beta = t.challenge_scalar(LBL("gprod_beta"), scratch);
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
   const Fr beta_inv = fr_inv_divsteps(beta);
   __syncthreads();
   // powers of beta: buf[i] = beta^(i+1), i <= ell
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void k_ps_ipa_setup(const ProveDev d) {
   const RandIdx ri(n);
   Fr* sc = v.sc();
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   t.append_message(LBL("ipa_step1"), v.slot(SL_C), 48, scratch);
   t.append_message(LBL("ipa_step1"), v.slot(sm.D()), 48, scratch);
   t.append_scalar(LBL("ipa_step1"), sc[SC_ZIP], scratch);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void k_ps_ipa_setup(const ProveDev d) {
   t.append_message(LBL("ipa_step1"), v.slot(SL_BD), 48, scratch);
   const Fr alpha = t.challenge_scalar(LBL("ipa_alpha"), scratch);
   const Fr beta = t.challenge_scalar(LBL("ipa_beta"), scratch);
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
   const Fr* r = v.rnd() + ri.IR();
   const Fr *c = v.vec(V_C), *dd = v.vec(V_D), *zz = v.vec(V_ZZ), *u = v.vec(V_U);
   Fr* rv = d.rvec + (size_t)v.p * 4 * n;
@@ -274,13 +274,13 @@ __global__ __launch_bounds__(64) void k_ps_ipa_round(const ProveDev d, int j) {
   const int lane = threadIdx.x;
   const SlotMap sm(d.L);
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   t.append_message(LBL("ipa_loop"), v.slot(sm.LC(j)), 48, scratch);
   t.append_message(LBL("ipa_loop"), v.slot(sm.LD(j)), 48, scratch);
   t.append_message(LBL("ipa_loop"), v.slot(sm.RC(j)), 48, scratch);
   t.append_message(LBL("ipa_loop"), v.slot(sm.RD(j)), 48, scratch);
   const Fr gamma = t.challenge_scalar(LBL("ipa_gamma"), scratch);
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
   const Fr gi = fr_inv_divsteps(gamma);
   if (lane == 0) {
     d.rgam[2 * (size_t)v.p] = gamma;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_ps_smsm_setup(const ProveDev d) {
     sc[SC_DFIN] = d.rvec[(size_t)v.p * 4 * n + n];
   }
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   const int pts[10] = {SL_R, SL_S, SL_CMT1, SL_CMT2, SL_CMU1, SL_CMU2, sm.CMA1(), sm.CMA2(), sm.CMB1(), sm.CMB2()};
   for (int q = 0; q < 10; q++) t.append_message(LBL("sameexp_points"), v.slot(pts[q]), 48, scratch);
   const Fr alpha_s = t.challenge_scalar(LBL("same_scalar_alpha"), scratch);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64) void k_ps_smsm_setup(const ProveDev d) {
   t.append_message(LBL("same_msm_step1"), v.slot(sm.BT()), 48, scratch);
   t.append_message(LBL("same_msm_step1"), v.slot(sm.BU()), 48, scratch);
   const Fr alpha_m = t.challenge_scalar(LBL("same_msm_alpha"), scratch);
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
   // x = vec_r + alpha (a_perm | a_blinders | r_t | r_u); fold coefficients S_M = 1
   const Fr* vr = rnd + ri.VR();
   const Fr* ap = v.vec(V_APERM);
@@ -363,11 +363,11 @@ __global__ __launch_bounds__(64) void k_ps_smsm_round(const ProveDev d, int j) {
   const int lane = threadIdx.x;
   const SlotMap sm(d.L);
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   const int six[6] = {sm.LA(j), sm.LT(j), sm.LU(j), sm.RA(j), sm.RT(j), sm.RU(j)};
   for (int q = 0; q < 6; q++) t.append_message(LBL("same_msm_loop"), v.slot(six[q]), 48, scratch);
   const Fr gamma = t.challenge_scalar(LBL("same_msm_gamma"), scratch);
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
   const Fr gi = fr_inv_divsteps(gamma);
   if (lane == 0) {
     d.rgam[2 * (size_t)v.p] = gamma;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64) void k_vs_prefix(const VerifyDev d) {
   const bool reject = ic[(size_t)2 * ell * 48] == 0xc0;   // curdleproofs.rs:218: the randomiser must not have wiped the ciphertexts
   const Fr* veca = d.veca + (size_t)v.p * ell;
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   t.append_message(LBL("same_perm_step1"), v.P(SL_A), 48, scratch);
   t.append_message(LBL("same_perm_step1"), d.mcomp + (size_t)v.p * 48, 48, scratch);
   uint32_t* w = reinterpret_cast<uint32_t*>(buf);
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64) void k_vs_prefix(const VerifyDev d) {
   t.append_message(LBL("gprod_step2"), v.P(SL_C), 48, scratch);
   t.append_scalar(LBL("gprod_step2"), r_p, scratch);
   const Fr beta_g = t.challenge_scalar(LBL("gprod_beta"), scratch);
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
   const Fr beta_g_inv = fr_inv_divsteps(beta_g);
   if (lane == 0) {
     Fr* sc = v.vsc();
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64) void k_vs_scalars(const VerifyDev d) {
   const Fr beta_l = fr_pow_u32(beta_g, (uint32_t)ell), beta_l1 = fe_mul(beta_l, beta_g);
   const Fr z_ip = fe_sub(fe_add(fe_mul(r_p, beta_l1), fe_mul(gprod, beta_l)), Fr::one());
   WaveStrobe t;
-  t.load(v.tstate(), lane & 31);
+  t.load(v.tstate(), lane);
   t.append_message(LBL("ipa_step1"), v.P(SL_C), 48, scratch);
   t.append_message(LBL("ipa_step1"), v.slot(sm.D()), 48, scratch);
   t.append_scalar(LBL("ipa_step1"), z_ip, scratch);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void k_vs_scalars(const VerifyDev d) {
     const Fr g = t.challenge_scalar(LBL("same_msm_gamma"), scratch);
     if (lane == 0) gam[L + j] = g;
   }
-  if (lane < 32) t.store(v.tstate());
+  t.store(v.tstate());
   __syncthreads();
   // the 2 L challenge inverses, one lane each (ark_ff::batch_inversion of the reference gives the same values)
   if (lane < 2 * L) gam[2 * L + lane] = fr_inv_divsteps(gam[lane]);

@@ -1,16 +1,26 @@
 // Lane-parallel STROBE-128 / Keccak-f[1600] for the device side of the transcripts — product code (device only).
 //
-// Half a wave (32 lanes) per transcript: 25 of the lanes hold one 64-bit word of the Keccak state each — word x + 5 y sits in lane
-// 5 y + x (+ 1 for y >= 3): lane 15 stays empty so that no plane (the five words of one y) straddles the two 16-lane DPP rows of
-// the group.  A round is then ONE ds_bpermute stage (rho + pi, a gather over the 25 lanes) and DPP / permlane stages: theta's
-// column parities (four row shifts by 5 / 10 lanes inside a 16-lane row + one v_permlane16_swap between the two rows), theta's
-// neighbour columns (a column parity is the same in every plane, so lane l - 1 / l + 1 has it) and chi's x + 1, x + 2 inside the
-// plane — instead of ~150 dependent 64-bit operations on one lane (a single GPU lane needs ~17 us per permutation; this form
-// 4.8 us alone on a SIMD and 4.9 us with 4096 groups in flight; with the parities as four ds_bpermute shuffles — rounds 1-2 — 5.4
-// and 7.1 us: scripts/micro/keccak_micro.hip, which also checks it against the host permutation; profiles/r03_keccak_micro.txt).
-// Message bytes are absorbed by the lane that owns their position in the rate.  Same semantics as strobe.hpp (the host's code, merlin 3.0.0 as used by transcript.rs:28-60 of
-// the reference), pinned by the bit-exact proof tests.  When a whole 64-lane wave drives ONE transcript, both halves run
-// the same operations on the same inputs and hold identical copies of the state.
+// ONE 64-lane wave per transcript, state bit-interleaved over the two halves of the wave: the 25 lanes 0..24 (+ the gaps below) of
+// the lower half hold the EVEN bits of one 64-bit state word each, the same lanes of the upper half (lane + 32) its ODD bits.  In
+// that form a 64-bit rotation is two independent 32-bit rotations (by r/2 on both halves for an even r; for an odd r the halves
+// change places and rotate by (r+1)/2 and (r-1)/2), every bitwise step is one 32-bit operation per lane, and nothing is computed
+// twice: 30 vector instructions per round against the 75 of the form this file held until round 4 (32 lanes per transcript, a
+// 64-bit word = two registers per lane, both halves of a wave running identical copies: 4.8 us per permutation; this form:
+// see profiles/r04_keccak_micro.txt).
+//
+// Word x + 5 y sits in lane 5 y + x (+ 1 for y >= 3) of its half: lane 15 stays empty so that no plane (the five words of one y)
+// straddles the two 16-lane DPP rows of a half.  A round:
+//   * theta's column parities: four DPP row shifts by 5 / 10 lanes inside a 16-lane row + one v_permlane16_swap between the two
+//     rows of a half; every lane then holds the parity of ITS column (its half of the bits);
+//   * theta's D, rho and pi in ONE gather stage of three ds_bpermute: rol(A ^ D, r) = rol(A, r) ^ rol(C[x-1], r) ^ rol(C[x+1], r+1)
+//     is linear, so the destination lane fetches the source word and the two neighbour-column parities from the half the rotation
+//     amount's parity selects and rotates them itself (per-lane constants) — the fetch of A is issued before the parities exist;
+//   * chi's x + 1, x + 2 of the same plane by DPP row shifts (two candidates each, the plane's wrap-around picks one);
+//   * iota: the round constant's even / odd bits into word 0 of each half.
+// Message bytes are absorbed four per lane (the lower half owns bytes 0..3 of a word, the upper half bytes 4..7), un-shuffled into
+// even | odd bits and exchanged with the partner lane.  Same semantics as strobe.hpp (the host's code, merlin 3.0.0 as used by
+// transcript.rs:28-60 of the reference), pinned by the bit-exact proof tests and by scripts/micro/keccak_micro.hip against the host
+// permutation.  Values the callers use (challenges, pos) are uniform over the wave.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mont32.hpp"
@@ -18,83 +28,143 @@
 
 namespace cpx {
 
-// bytes written to LDS by some lanes of a wave become visible to the others (no block barrier: the two proofs of a
-// work-group run divergent retry loops)
+// bytes written to LDS by some lanes of a wave become visible to the others (no block barrier needed: one wave per work-group
+// or per transcript)
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
+// perfect outer un-shuffle of 32 bits: even bits -> low 16, odd bits -> high 16 (Hacker's Delight 7-2), and its inverse
+CPX_HD uint32_t bits_unshuffle32(uint32_t x) {
+  uint32_t t;
+  t = (x ^ (x >> 1)) & 0x22222222u; x ^= t ^ (t << 1);
+  t = (x ^ (x >> 2)) & 0x0c0c0c0cu; x ^= t ^ (t << 2);
+  t = (x ^ (x >> 4)) & 0x00f000f0u; x ^= t ^ (t << 4);
+  t = (x ^ (x >> 8)) & 0x0000ff00u; x ^= t ^ (t << 8);
+  return x;
+}
+CPX_HD uint32_t bits_shuffle32(uint32_t x) {
+  uint32_t t;
+  t = (x ^ (x >> 8)) & 0x0000ff00u; x ^= t ^ (t << 8);
+  t = (x ^ (x >> 4)) & 0x00f000f0u; x ^= t ^ (t << 4);
+  t = (x ^ (x >> 2)) & 0x0c0c0c0cu; x ^= t ^ (t << 2);
+  t = (x ^ (x >> 1)) & 0x22222222u; x ^= t ^ (t << 1);
+  return x;
+}
+// 64-bit word <-> (even bits, odd bits)
+CPX_HD void bits_split64(uint64_t v, uint32_t& even, uint32_t& odd) {
+  const uint32_t lo = bits_unshuffle32((uint32_t)v), hi = bits_unshuffle32((uint32_t)(v >> 32));
+  even = (lo & 0xffffu) | (hi << 16);
+  odd = (lo >> 16) | (hi & 0xffff0000u);
+}
+CPX_HD uint64_t bits_join64(uint32_t even, uint32_t odd) {
+  const uint32_t lo = bits_shuffle32((even & 0xffffu) | (odd << 16)), hi = bits_shuffle32((even >> 16) | (odd & 0xffff0000u));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+struct KeccakRC {   // the 24 round constants as (even bits, odd bits)
+  uint32_t e[24], o[24];
+};
+constexpr KeccakRC make_keccak_rc() {
+  const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                           0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                           0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                           0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                           0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                           0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  KeccakRC t{};
+  for (int r = 0; r < 24; r++) {
+    uint32_t e = 0, o = 0;
+    for (int i = 0; i < 32; i++) {
+      e |= (uint32_t)((RC[r] >> (2 * i)) & 1) << i;
+      o |= (uint32_t)((RC[r] >> (2 * i + 1)) & 1) << i;
+    }
+    t.e[r] = e;
+    t.o[r] = o;
+  }
+  return t;
+}
+
 struct WaveStrobe {
-  uint64_t a;                 // this lane's 64-bit word of the state (lanes without a word keep 0)
-  uint32_t pos, pos_begin;    // uniform over the 32 lanes of a proof
-  int l;                      // lane within the 32-lane group
+  uint32_t a;                 // this lane's half of a state word: its even bits (lanes 0..31) or odd bits (lanes 32..63); empty lanes keep 0
+  uint32_t pos, pos_begin;    // uniform over the wave
+  int l;                      // lane within its 32-lane half
+  int h;                      // 0: even bits, 1: odd bits
   int w;                      // the state word this lane holds (0..24), -1 for the empty lanes 15 and 26..31
 
   static __device__ __forceinline__ int lane_of_word(int word) { return word + (word >= 15 ? 1 : 0); }
   static __device__ __forceinline__ int word_of_lane(int lane) { return lane < 15 ? lane : (lane >= 16 && lane <= 25 ? lane - 1 : -1); }
-  __device__ __forceinline__ void set_lane(int lane_in_group) {
-    l = lane_in_group;
+  __device__ __forceinline__ void set_lane(int lane_in_wave) {   // 0..63
+    l = lane_in_wave & 31;
+    h = (lane_in_wave >> 5) & 1;
     w = word_of_lane(l);
   }
-  template <int CTRL> static __device__ __forceinline__ uint64_t dpp64(uint64_t v) {   // out-of-row sources read as zero
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
-    return ((uint64_t)hi << 32) | lo;
+  template <int CTRL> static __device__ __forceinline__ uint32_t dpp(uint32_t v) {   // out-of-row sources read as zero
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
   }
-
-  // v ^ (the same lane of the other 16-lane row of the 32-lane group), in every lane: v_permlane16_swap_b32 swaps the odd rows of
-  // its first operand with the even rows of the second; with both operands = v the two results hold (row 0, row 0, row 2, row 2) and
+  // v ^ (the same lane of the other 16-lane row of the half), in every lane: v_permlane16_swap_b32 swaps the odd rows of its first
+  // operand with the even rows of the second; with both operands = v the two results hold (row 0, row 0, row 2, row 2) and
   // (row 1, row 1, row 3, row 3)
-  static __device__ __forceinline__ uint64_t rows_xor(uint64_t v) {
-    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)v, (uint32_t)v, false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(v >> 32), (uint32_t)(v >> 32), false, false);
-    return ((uint64_t)(hi[0] ^ hi[1]) << 32) | (uint64_t)(lo[0] ^ lo[1]);
+  static __device__ __forceinline__ uint32_t rows_xor(uint32_t v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return r[0] ^ r[1];
   }
-  __device__ __forceinline__ uint64_t shfl(uint64_t v, int src) const {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 32), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 32);
-    return ((uint64_t)hi << 32) | lo;
+  static __device__ __forceinline__ uint32_t gather(int byte_addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v); }
+  static __device__ __forceinline__ uint32_t rotr_by(uint32_t v, uint32_t sh) { return __builtin_amdgcn_alignbit(v, v, sh); }   // sh = (32 - left amount) & 31
+  // where a destination lane of half `hh` finds its bits for a 64-bit left rotation by r (0..63): source half and 32-bit amount
+  static __device__ __forceinline__ void rot_plan(int r, int hh, int& src_half, int& amount) {
+    if ((r & 1) == 0) {
+      src_half = hh;
+      amount = r >> 1;
+    } else {
+      src_half = hh ^ 1;
+      amount = hh == 0 ? (r + 1) >> 1 : (r - 1) >> 1;
+    }
   }
   __device__ void keccak() {
-    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
-                             0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
-                             0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
-                             0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
-                             0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-                             0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    static constexpr KeccakRC RC = make_keccak_rc();
     // rotation offsets r[x + 5y] of rho
     const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110;   // DPP row shifts: row_shl:n reads lane i + n, row_shr:n lane i - n (within 16 lanes)
-    const int wc = w >= 0 ? w : 0;   // empty lanes run along on word 0's indices (nobody reads them, they are cleared at the end)
+    const bool live = w >= 0;
+    const int wc = live ? w : 0;   // empty lanes run along on word 0's indices (nobody reads them, they are cleared every round)
     const int x = wc % 5, y = wc / 5;
     // rho + pi as a gather: destination (X, Y) = (y, (2x + 3y) % 5)  <=>  source x = (X + 3Y) % 5, y = X
-    const int sx = (x + 3 * y) % 5, sy = x, src = lane_of_word(sx + 5 * sy), rot = RHO[sx + 5 * sy];
-    // a column parity is the same in all planes: lane l - 1 holds column x - 1 and lane l + 1 column x + 1, except next to the
-    // row ends and the empty lanes, where the lane four further holds the same column
-    const bool m1_alt = l == 0 || l == 16, p1_alt = l == 14 || l == 25;
+    const int sx = (x + 3 * y) % 5, sy = x, rot = RHO[sx + 5 * sy];
+    int half_a, amt_a, half_p, amt_p;
+    rot_plan(rot, h, half_a, amt_a);
+    rot_plan(rot + 1, h, half_p, amt_p);
+    // a column parity is the same in every plane of its half: take the neighbour columns from the source word's own plane
+    const int addr_a = 4 * (32 * half_a + lane_of_word(sx + 5 * sy));
+    const int addr_m = 4 * (32 * half_a + lane_of_word((sx + 4) % 5 + 5 * sy));
+    const int addr_p = 4 * (32 * half_p + lane_of_word((sx + 1) % 5 + 5 * sy));
+    const uint32_t sh_a = (uint32_t)(32 - amt_a) & 31u, sh_p = (uint32_t)(32 - amt_p) & 31u;
+    const bool x_lt4 = x < 4, x_lt3 = x < 3;
+    // per-lane masks kept as opaque register values (the compiler would otherwise turn them back into selects on scalar masks, one
+    // more move each): word 0's lane of each half for iota, the lanes that hold a word
+    uint32_t iota_e = (w == 0 && h == 0) ? ~0u : 0u, iota_o = (w == 0 && h == 1) ? ~0u : 0u, live_m = live ? ~0u : 0u;
+    asm volatile("" : "+v"(iota_e), "+v"(iota_o), "+v"(live_m));
     for (int r = 0; r < 24; r++) {
-      // theta's column parities without LDS traffic: the planes of a row sit 5 lanes apart, so four DPP row shifts (out-of-row and
-      // empty lanes read as zero) add up a column inside each 16-lane row, and ONE v_permlane16_swap (gfx950) exchanges the two
-      // rows of the group: r[0] ^ r[1] = row 0's sums ^ row 1's sums in every lane.  (Until round 3 of this build: four
-      // ds_bpermute shuffles — a round had two dependent LDS round trips, now one: the rho + pi gather below.)
-      const uint64_t am = w >= 0 ? a : 0;   // (the empty lanes run along with garbage: keep it out of the sums)
-      uint64_t c = am ^ dpp64<ROW_SHL + 5>(am) ^ dpp64<ROW_SHL + 10>(am) ^ dpp64<ROW_SHR + 5>(am) ^ dpp64<ROW_SHR + 10>(am);
+      const uint32_t ga = gather(addr_a, a);
+      uint32_t c = (dpp<ROW_SHL + 5>(a) ^ dpp<ROW_SHL + 10>(a)) ^ (dpp<ROW_SHR + 5>(a) ^ dpp<ROW_SHR + 10>(a)) ^ a;   // (two short chains, not one of five)
       c = rows_xor(c);
+      const uint32_t gm = gather(addr_m, c), gp = gather(addr_p, c);
+      const uint32_t b = rotr_by(ga ^ gm, sh_a) ^ rotr_by(gp, sh_p);
       // (both candidates are fetched by every lane, then one is picked: a DPP read inside a divergent branch would see disabled lanes)
-      const uint64_t cm_a = dpp64<ROW_SHL + 4>(c), cm_b = dpp64<ROW_SHR + 1>(c), cp_a = dpp64<ROW_SHR + 4>(c), cp_b = dpp64<ROW_SHL + 1>(c);
-      const uint64_t cm1 = m1_alt ? cm_a : cm_b, cp1 = p1_alt ? cp_a : cp_b;
-      a ^= cm1 ^ rol64(cp1, 1);
-      uint64_t b = shfl(a, src);
-      b = rot ? ((b << rot) | (b >> (64 - rot))) : b;
-      const uint64_t b1_a = dpp64<ROW_SHL + 1>(b), b1_b = dpp64<ROW_SHR + 4>(b), b2_a = dpp64<ROW_SHL + 2>(b), b2_b = dpp64<ROW_SHR + 3>(b);
-      const uint64_t b1 = x < 4 ? b1_a : b1_b, b2 = x < 3 ? b2_a : b2_b;   // (x + 1) % 5, (x + 2) % 5 of the same plane
-      a = b ^ (~b1 & b2);
-      if (w == 0) a ^= RC[r];
+      const uint32_t b1_a = dpp<ROW_SHL + 1>(b), b1_b = dpp<ROW_SHR + 4>(b), b2_a = dpp<ROW_SHL + 2>(b), b2_b = dpp<ROW_SHR + 3>(b);
+      const uint32_t b1 = x_lt4 ? b1_a : b1_b, b2 = x_lt3 ? b2_a : b2_b;   // (x + 1) % 5, (x + 2) % 5 of the same plane
+      const uint32_t rc = (RC.e[r] & iota_e) | (RC.o[r] & iota_o);   // (uniform loads, per-lane masks)
+      const uint32_t n = b ^ (~b1 & b2) ^ rc;
+      a = n & live_m;   // the empty lanes are read by the parity shifts: keep them zero
     }
-    if (w < 0) a = 0;
   }
+  // state byte i ^= b (i uniform)
   __device__ __forceinline__ void xor_byte(uint32_t i, uint8_t b) {
-    if ((int)(i >> 3) == w) a ^= (uint64_t)b << (8 * (i & 7));
+    if ((int)(i >> 3) == w) {
+      const uint32_t u = bits_unshuffle32(b);   // even bits of the byte in bits 0..3, odd bits in bits 16..19
+      a ^= ((h ? u >> 16 : u) & 0xfu) << (4 * (i & 7));
+    }
   }
   __device__ void run_f() {
     xor_byte(pos, (uint8_t)pos_begin);
@@ -103,16 +173,19 @@ struct WaveStrobe {
     keccak();
     pos = pos_begin = 0;
   }
-  // absorb n bytes readable by every lane (global, constant or LDS memory)
+  // absorb n bytes readable by every lane (global, constant or LDS memory): a lane fetches the four bytes of its word that its half
+  // owns (lower half: bytes 0..3, upper half: bytes 4..7), un-shuffles them and trades 16 bits with its partner lane
   __device__ void absorb(const uint8_t* d, size_t n) {
     while (n) {
       const uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), n);
-      uint64_t v = 0;
-      CPX_UNROLL for (int j = 0; j < 8; j++) {
-        const uint32_t sidx = 8u * (uint32_t)w + j;   // state byte owned by this lane (w = -1: beyond every position)
-        if (w >= 0 && sidx >= pos && sidx < pos + k) v |= (uint64_t)d[sidx - pos] << (8 * j);
+      uint32_t v = 0;
+      CPX_UNROLL for (int j = 0; j < 4; j++) {
+        const uint32_t sidx = 8u * (uint32_t)w + 4u * (uint32_t)h + j;   // state byte owned by this lane (w = -1: beyond every position)
+        if (w >= 0 && sidx >= pos && sidx < pos + k) v |= (uint32_t)d[sidx - pos] << (8 * j);
       }
-      a ^= v;
+      const uint32_t mine = bits_unshuffle32(v), other = (uint32_t)__shfl_xor((int)mine, 32, 64);
+      // lower half: even bits of bytes 0..3 (mine) | even bits of bytes 4..7 (other) << 16; upper half: the odd bits likewise
+      a ^= h ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
       pos += k;
       d += k;
       n -= k;
@@ -133,7 +206,7 @@ struct WaveStrobe {
     begin_op(Strobe::FLAG_M | Strobe::FLAG_A, more);
     absorb(static_cast<const uint8_t*>(d), n);
   }
-  __device__ void len4(size_t len, uint8_t* scratch4) {   // LE32(len) through the group's scratch bytes
+  __device__ void len4(size_t len, uint8_t* scratch4) {   // LE32(len) through the wave's scratch bytes
     if (l < 4) scratch4[l] = (uint8_t)(len >> (8 * l));
     wave_lds_sync();
     meta_ad(scratch4, 4, true);
@@ -153,17 +226,29 @@ struct WaveStrobe {
     append_begin("dom-sep", 7, label_len, scratch);
     absorb(reinterpret_cast<const uint8_t*>(label), label_len);
   }
-  // ---- state import / export ([27] u64: 25 lanes, pos, pos_begin — the layout host::Transcript::load_state reads) ----
-  __device__ __forceinline__ void load(const uint64_t* st27, int lane_in_group) {
-    set_lane(lane_in_group);
-    a = w >= 0 ? st27[w] : 0;
+  // ---- state import / export ([27] u64: 25 plain 64-bit words, pos, pos_begin — the layout host::Transcript::load_state reads) ----
+  __device__ __forceinline__ void load(const uint64_t* st27, int lane_in_wave) {
+    set_lane(lane_in_wave);
+    uint32_t e = 0, o = 0;
+    if (w >= 0) bits_split64(st27[w], e, o);
+    a = h ? o : e;
     pos = (uint32_t)st27[25];
     pos_begin = (uint32_t)st27[26];
   }
-  __device__ __forceinline__ void store(uint64_t* st27) const {
-    if (w >= 0) st27[w] = a;
-    if (l == 26) st27[25] = pos;
-    if (l == 27) st27[26] = pos_begin;
+  __device__ __forceinline__ void store(uint64_t* st27) const {   // called by the whole wave
+    const uint32_t other = (uint32_t)__shfl_xor((int)a, 32, 64);
+    if (h == 0) {
+      if (w >= 0) st27[w] = bits_join64(a, other);
+      if (l == 26) st27[25] = pos;
+      if (l == 27) st27[26] = pos_begin;
+    }
+  }
+  // the first 32 bytes of the state (words 0..3) as plain 64-bit words, in every lane
+  __device__ __forceinline__ void peek4(uint64_t sq[4]) const {
+    CPX_UNROLL for (int j = 0; j < 4; j++) {
+      const uint32_t e = (uint32_t)__shfl((int)a, lane_of_word(j), 64), o = (uint32_t)__shfl((int)a, 32 + lane_of_word(j), 64);
+      sq[j] = bits_join64(e, o);
+    }
   }
   // append_message(label, data): data readable by every lane (global / LDS / constant)
   __device__ void append_message(const char* label, size_t label_len, const uint8_t* data, size_t len, uint8_t* scratch) {
@@ -182,44 +267,47 @@ struct WaveStrobe {
     absorb(scratch + 16, 32);
     wave_lds_sync();   // scratch may be rewritten right away by the next operation
   }
-  // get_and_append_challenge (transcript.rs:40-60): 64 PRF bytes, Fr::from_random_bytes on the first 32 with the top bit
-  // cleared, retried until canonical and non-zero, then appended back under the same label.  Returns the Montgomery form
-  // (uniform over the lanes of the group).
-  __device__ Fr challenge_scalar(const char* label, size_t label_len, uint8_t* scratch) {
-    for (;;) {
-      meta_ad(label, label_len, false);
-      len4(64, scratch);
-      begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
-      // squeeze 64 bytes = lanes 0..7 of the state, which the PRF operation overwrites with zero (pos is 0 here)
-      uint64_t sq[4];
-      CPX_UNROLL for (int j = 0; j < 4; j++) sq[j] = shfl(a, lane_of_word(j));
-      if (w >= 0 && w < 8) a = 0;
-      pos = 64;
-      sq[3] &= 0x7fffffffffffffffULL;
-      Fr c;
-      CPX_UNROLL for (int j = 0; j < 4; j++) {
-        c.v[2 * j] = (uint32_t)sq[j];
-        c.v[2 * j + 1] = (uint32_t)(sq[j] >> 32);
-      }
-      bool nz = false, lt = false;
-      for (int j = 0; j < 8; j++) nz |= c.v[j] != 0;
-      for (int j = 7; j >= 0; j--) {
-        if (c.v[j] != FrCfg::P[j]) {
-          lt = c.v[j] < FrCfg::P[j];
-          break;
-        }
-      }
-      if (lt && nz) {
-        if (l < 4) {
-          CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * l + j] = (uint8_t)(sq[l] >> (8 * j));
-        }
-        wave_lds_sync();
-        append_begin(label, label_len, 32, scratch);
-        absorb(scratch + 16, 32);
-        wave_lds_sync();
-        return fe_to_mont(c);
+  // One attempt of get_and_append_challenge (transcript.rs:40-60): 64 PRF bytes, Fr::from_random_bytes on the first 32 with the top
+  // bit cleared; when canonical and non-zero the scalar is appended back under the same label and returned in canonical form
+  // (uniform over the wave), otherwise the caller retries.
+  __device__ bool challenge_attempt(const char* label, size_t label_len, uint8_t* scratch, Fr& c) {
+    meta_ad(label, label_len, false);
+    len4(64, scratch);
+    begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
+    // squeeze 64 bytes = words 0..7 of the state, which the PRF operation overwrites with zero (pos is 0 here)
+    uint64_t sq[4];
+    peek4(sq);
+    if (w >= 0 && w < 8) a = 0;
+    pos = 64;
+    sq[3] &= 0x7fffffffffffffffULL;
+    CPX_UNROLL for (int j = 0; j < 4; j++) {
+      c.v[2 * j] = (uint32_t)sq[j];
+      c.v[2 * j + 1] = (uint32_t)(sq[j] >> 32);
+    }
+    bool nz = false, lt = false;
+    for (int j = 0; j < 8; j++) nz |= c.v[j] != 0;
+    for (int j = 7; j >= 0; j--) {
+      if (c.v[j] != FrCfg::P[j]) {
+        lt = c.v[j] < FrCfg::P[j];
+        break;
       }
     }
+    if (!(lt && nz)) return false;
+    if (l < 4) {
+      CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * l + j] = (uint8_t)(sq[l] >> (8 * j));
+    }
+    wave_lds_sync();
+    append_begin(label, label_len, 32, scratch);
+    absorb(scratch + 16, 32);
+    wave_lds_sync();
+    return true;
+  }
+  // get_and_append_challenge: retried until canonical and non-zero.  Returns the Montgomery form (uniform over the wave).
+  __device__ Fr challenge_scalar(const char* label, size_t label_len, uint8_t* scratch) {
+    Fr c;
+    while (!challenge_attempt(label, label_len, scratch, c)) {
+    }
+    return fe_to_mont(c);
   }
 };
 

@@ -1,4 +1,5 @@
-// gfx950 latency of the lane-parallel Keccak-f[1600] of wave_strobe.hpp (32 lanes per state) and of a rate block absorbed from memory.
+// gfx950 latency of the lane-parallel Keccak-f[1600] of wave_strobe.hpp (one wave per state, bit-interleaved halves) and of a rate block
+// absorbed from memory; checks one permutation and a 1000-byte absorb against the host code of strobe.hpp.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I curdleproofs_amd/csrc scripts/micro/keccak_micro.hip -o scripts/micro/keccak_micro
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -8,43 +9,60 @@ using namespace cpx;
 #define HIPCHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 __global__ __launch_bounds__(64) void k(const uint8_t* msg, size_t len, uint64_t* t, uint64_t* out, int reps) {
-  __shared__ uint8_t scratch_all[2][64];
+  __shared__ uint8_t scratch[64];
   WaveStrobe s;
-  s.set_lane(threadIdx.x & 31);
-  s.init("bench", 5, scratch_all[threadIdx.x >> 5]);
+  s.set_lane(threadIdx.x);
+  s.init("bench", 5, scratch);
   uint64_t t0 = wall_clock64();
   for (int i = 0; i < reps; i++) s.keccak();
   uint64_t t1 = wall_clock64();
   s.absorb(msg, len);
   uint64_t t2 = wall_clock64();
-  if (s.w >= 0) out[blockIdx.x * 64 + (threadIdx.x & 32) + s.w] = s.a;
+  if (s.w >= 0) out[blockIdx.x * 64 + (threadIdx.x & 32) + s.w] = s.a;   // (keeps the work alive)
   if (threadIdx.x == 0 && blockIdx.x == 0) { t[0] = t1 - t0; t[1] = t2 - t1; }
 }
-__global__ __launch_bounds__(64) void k_check(const uint64_t* in27, uint64_t* out27) {
+__global__ __launch_bounds__(64) void k_check(const uint64_t* in27, uint64_t* out27, const uint8_t* msg, size_t len) {
   WaveStrobe s;
-  s.load(in27, threadIdx.x & 31);
+  s.load(in27, threadIdx.x);
   s.keccak();
-  if (threadIdx.x < 32) s.store(out27);
-  else s.store(out27 + 27);   // the second half of the wave runs the same permutation
+  s.store(out27);
+  // a message absorbed from an odd position, then one challenge-style squeeze of the first 32 bytes
+  s.load(in27, threadIdx.x);
+  s.absorb(msg, len);
+  s.xor_byte(s.pos, 0xa7);
+  s.store(out27 + 27);
+  uint64_t sq[4];
+  s.peek4(sq);
+  if (threadIdx.x == 63) for (int j = 0; j < 4; j++) out27[54 + j] = sq[j];
 }
 int main() {
-  {   // one permutation of a non-trivial state against the host's keccak_f1600 (strobe.hpp)
-    uint64_t h[27], ref[25], got[54];
+  {   // one permutation of a non-trivial state against the host's keccak_f1600, an absorb against the host's Strobe (strobe.hpp)
+    uint64_t h[27], ref[25], got[58];
     for (int i = 0; i < 25; i++) h[i] = ref[i] = 0x9e3779b97f4a7c15ULL * (i + 1) ^ (0x0123456789abcdefULL << (i % 7));
     h[25] = 17; h[26] = 3;
     keccak_f1600(ref);
-    uint64_t *din, *dout;
-    HIPCHECK(hipMalloc(&din, sizeof h)); HIPCHECK(hipMalloc(&dout, sizeof got));
+    uint8_t msg[1000];
+    for (int i = 0; i < 1000; i++) msg[i] = (uint8_t)(i * 131 + 7);
+    Strobe hs;
+    for (int i = 0; i < 25; i++) hs.st[i] = h[i];
+    hs.pos = 17; hs.pos_begin = 3;
+    hs.absorb(msg, 1000);
+    hs.xor_byte(hs.pos, 0xa7);
+    uint64_t *din, *dout; uint8_t* dm;
+    HIPCHECK(hipMalloc(&din, sizeof h)); HIPCHECK(hipMalloc(&dout, sizeof got)); HIPCHECK(hipMalloc(&dm, 1000));
     HIPCHECK(hipMemcpy(din, h, sizeof h, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, 0, din, dout);
+    HIPCHECK(hipMemcpy(dm, msg, 1000, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, 0, din, dout, dm, (size_t)1000);
     HIPCHECK(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
     int bad = 0;
-    for (int half = 0; half < 2; half++) {
-      for (int i = 0; i < 25; i++) bad += got[27 * half + i] != ref[i];
-      bad += got[27 * half + 25] != 17 || got[27 * half + 26] != 3;
-    }
-    printf("lane-parallel keccak-f[1600] against the host permutation: %d mismatches\n", bad);
-    if (bad) return 1;
+    for (int i = 0; i < 25; i++) bad += got[i] != ref[i];
+    bad += got[25] != 17 || got[26] != 3;
+    int bad2 = 0;
+    for (int i = 0; i < 25; i++) bad2 += got[27 + i] != hs.st[i];
+    bad2 += got[27 + 25] != hs.pos || got[27 + 26] != hs.pos_begin;
+    for (int j = 0; j < 4; j++) bad2 += got[54 + j] != hs.st[j];
+    printf("lane-parallel keccak-f[1600] against the host permutation: %d mismatches; absorb / xor_byte / peek4 against the host's Strobe: %d mismatches\n", bad, bad2);
+    if (bad || bad2) return 1;
   }
   const size_t len = 166 * 256;
   uint8_t* dmsg; uint64_t *dt, *dout;

@@ -1026,13 +1026,14 @@ __global__ __launch_bounds__(64) void k_compress_cols(const Aff* __restrict__ in
 // All tasks of a launch have `cnt` elements; consecutive threads take consecutive elements so the
 // 96-byte point loads/stores of a wave are contiguous.
 // The arithmetic runs on the table form: the two input points are converted on load (2 products per coordinate)
-// and the result is converted back after the in-group batch inversion.
+// and the result is converted back after the in-group batch inversion.  The scalar is split by the endomorphism (recode.hpp
+// recode_smul_glv): a chain of 129 doublings with the non-adjacent forms of both halves instead of 257.
 constexpr int SMUL_THREADS = 64;   // single-wave groups: no whole-CU placement constraint beside the MSM waves of other contexts
 
 __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  TF* buf = reinterpret_cast<TF*>(smem);                                             // 2*256 field elements
-  uint32_t* naf = reinterpret_cast<uint32_t*>(smem + 2 * SMUL_THREADS * sizeof(TF));  // [18][256]
+  TF* buf = reinterpret_cast<TF*>(smem);                                             // 2 * SMUL_THREADS field elements
+  uint32_t* naf = reinterpret_cast<uint32_t*>(smem + 2 * SMUL_THREADS * sizeof(TF));  // [20][SMUL_THREADS]: nz / ng words of both halves
   const int tid = threadIdx.x;
   const long g = (long)blockIdx.x * blockDim.x + tid;
   const long total = (long)ntasks * cnt;
@@ -1045,20 +1046,22 @@ __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restric
     dst = task.out + e;
     Fr k = task.scalars[(size_t)e * task.scalar_stride];
     if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
-    uint32_t nz[9], ng[9];
-    recode_naf(k.v, nz, ng);
-    CPX_UNROLL for (int i = 0; i < 9; i++) {
-      naf[i * SMUL_THREADS + tid] = nz[i];
-      naf[(9 + i) * SMUL_THREADS + tid] = ng[i];
+    {
+      SmulNaf rn;
+      recode_smul_glv(k.v, rn);
+      CPX_UNROLL for (int hh = 0; hh < 2; hh++)
+        CPX_UNROLL for (int i = 0; i < 5; i++) {
+          naf[(10 * hh + i) * SMUL_THREADS + tid] = rn.nz[hh][i];
+          naf[(10 * hh + 5 + i) * SMUL_THREADS + tid] = rn.ng[hh][i];
+        }
     }
     const TAff P = t_from_std(task.mul[e]);
-    for (int i = 256; i >= 0; i--) {
+    const TAff NP = P.is_identity() ? P : TAff{t_mul(P.x, t_beta()), t_neg(P.y)};   // N P = -phi(P) (glv.hpp)
+    for (int i = 128; i >= 0; i--) {
       acc = t_dbl(acc);
-      const uint32_t nzw = naf[(i >> 5) * SMUL_THREADS + tid];
-      if ((nzw >> (i & 31)) & 1u) {
-        const uint32_t ngw = naf[(9 + (i >> 5)) * SMUL_THREADS + tid];
-        acc = t_add_mixed(acc, t_cneg(P, (ngw >> (i & 31)) & 1u));
-      }
+      const int wd = i >> 5, bt = i & 31;
+      if ((naf[wd * SMUL_THREADS + tid] >> bt) & 1u) acc = t_add_mixed(acc, t_cneg(P, (naf[(5 + wd) * SMUL_THREADS + tid] >> bt) & 1u));
+      if ((naf[(10 + wd) * SMUL_THREADS + tid] >> bt) & 1u) acc = t_add_mixed(acc, t_cneg(NP, (naf[(15 + wd) * SMUL_THREADS + tid] >> bt) & 1u));
     }
     if (task.add) acc = t_add_mixed(acc, t_from_std(task.add[e]));
   }
@@ -1781,7 +1784,7 @@ void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, in
 void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
   const long total = (long)ntasks * cnt;
   if (total <= 0) return;
-  const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 18 * SMUL_THREADS * sizeof(uint32_t);
+  const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 20 * SMUL_THREADS * sizeof(uint32_t);
   CPX_LAUNCH(k_smul, dim3((unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS)), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
 }
 void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,

@@ -1,6 +1,7 @@
 // Scalar recodings shared by the gfx950 kernels and the host-side emulation tests.
 #pragma once
 #include "mont32.hpp"
+#include "glv.hpp"
 
 namespace cpx {
 
@@ -42,6 +43,29 @@ CPX_HD void recode_naf(const uint32_t* k, uint32_t* nz /*9*/, uint32_t* ng /*9*/
     uint32_t m = (x[i] >> 1) | ((i < 8 ? x[i + 1] : 0u) << 31);
     nz[i] = p ^ m;
     ng[i] = m & ~p;
+  }
+}
+
+// ---- per-element scalar multiplication (k_smul): the endomorphism split of glv.hpp, k = +-(+-|t| + q N), N P = (beta x, -y), and a
+// non-adjacent form of each half: k P = sum_{i=0}^{128} (e_i P + f_i N P) 2^i, e_i, f_i in {-1, 0, 1} — 129 doublings and ~86
+// additions instead of 257 and ~86.  nz / ng: digit non-zero / negative (the signs of k and t folded in), bit i of word i / 32;
+// half 0 = the digits of P, half 1 = the digits of N P.
+struct SmulNaf {
+  uint32_t nz[2][5], ng[2][5];
+};
+CPX_HD void recode_smul_glv(const uint32_t* k /*canonical, 8 words*/, SmulNaf& o) {
+  uint32_t t[8], q[8], nk, nt, nz[9], ng[9];
+  for (int i = 4; i < 8; i++) t[i] = q[i] = 0;
+  glv_split(k, t, q, nk, nt);
+  recode_naf(t, nz, ng);
+  for (int i = 0; i < 5; i++) {
+    o.nz[0][i] = nz[i];
+    o.ng[0][i] = (nk ^ nt) ? (ng[i] ^ nz[i]) : ng[i];
+  }
+  recode_naf(q, nz, ng);
+  for (int i = 0; i < 5; i++) {
+    o.nz[1][i] = nz[i];
+    o.ng[1][i] = nk ? (ng[i] ^ nz[i]) : ng[i];
   }
 }
 

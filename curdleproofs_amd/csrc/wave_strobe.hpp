@@ -159,11 +159,11 @@ struct WaveStrobe {
       a = n & live_m;   // the empty lanes are read by the parity shifts: keep them zero
     }
   }
-  // state byte i ^= b (i uniform)
+  // state byte i ^= b (i, b uniform): the even (lower half) or odd (upper half) bits of the byte, four of them, at bit 4 (i % 8)
   __device__ __forceinline__ void xor_byte(uint32_t i, uint8_t b) {
     if ((int)(i >> 3) == w) {
-      const uint32_t u = bits_unshuffle32(b);   // even bits of the byte in bits 0..3, odd bits in bits 16..19
-      a ^= ((h ? u >> 16 : u) & 0xfu) << (4 * (i & 7));
+      const uint32_t v = (uint32_t)b >> h;
+      a ^= ((v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u) | ((v >> 3) & 8u)) << (4 * (i & 7));
     }
   }
   __device__ void run_f() {
@@ -173,22 +173,57 @@ struct WaveStrobe {
     keccak();
     pos = pos_begin = 0;
   }
-  // absorb n bytes readable by every lane (global, constant or LDS memory): a lane fetches the four bytes of its word that its half
-  // owns (lower half: bytes 0..3, upper half: bytes 4..7), un-shuffles them and trades 16 bits with its partner lane
-  __device__ void absorb(const uint8_t* d, size_t n) {
-    while (n) {
-      const uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), n);
+  // the lane's word of message bits `v` (bytes 0..3 of its state word in the lower half, bytes 4..7 in the upper half, zero where
+  // nothing is absorbed) into the state: un-shuffled into even | odd bits, 16 bits traded with the partner lane
+  __device__ __forceinline__ void xor_own_bytes(uint32_t v) {
+    const uint32_t mine = bits_unshuffle32(v), other = (uint32_t)__shfl_xor((int)mine, 32, 64);
+    // lower half: even bits of bytes 0..3 (mine) | even bits of bytes 4..7 (other) << 16; upper half: the odd bits likewise
+    a ^= h ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+  }
+  // absorb the n bytes at d (readable by every lane: global, constant or LDS memory) followed by the tail_n (<= 4) low bytes of `tail`,
+  // little-endian — a label and the LE32 length that follows it are one message (merlin's meta-AD with `more`), absorbed in one pass
+  // without staging the length in memory.  A lane fetches the four bytes of its word that its half owns.
+  __device__ void absorb(const uint8_t* d, size_t n, uint32_t tail = 0, uint32_t tail_n = 0) {
+    size_t left = n + tail_n, off = 0;
+    while (left) {
+      const uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), left);
       uint32_t v = 0;
       CPX_UNROLL for (int j = 0; j < 4; j++) {
         const uint32_t sidx = 8u * (uint32_t)w + 4u * (uint32_t)h + j;   // state byte owned by this lane (w = -1: beyond every position)
-        if (w >= 0 && sidx >= pos && sidx < pos + k) v |= (uint32_t)d[sidx - pos] << (8 * j);
+        if (w >= 0 && sidx >= pos && sidx < pos + k) {
+          const size_t m = off + (sidx - pos);
+          const uint32_t b = m < n ? (uint32_t)d[m] : (tail >> (8 * (uint32_t)(m - n))) & 0xffu;
+          v |= b << (8 * j);
+        }
       }
-      const uint32_t mine = bits_unshuffle32(v), other = (uint32_t)__shfl_xor((int)mine, 32, 64);
-      // lower half: even bits of bytes 0..3 (mine) | even bits of bytes 4..7 (other) << 16; upper half: the odd bits likewise
-      a ^= h ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+      xor_own_bytes(v);
       pos += k;
-      d += k;
-      n -= k;
+      off += k;
+      left -= k;
+      if (pos == Strobe::RATE) run_f();
+    }
+  }
+  // absorb the 32 bytes of eight words every lane holds (uniform): a lane picks the two words its four bytes fall into — no memory
+  __device__ void absorb_words8(const uint32_t* c) {
+    uint32_t left = 32, off = 0;
+    while (left) {
+      const uint32_t k = min(Strobe::RATE - pos, left);
+      const int s0 = 8 * w + 4 * h;                        // this lane's first state byte
+      const int o4 = s0 - (int)pos + (int)off + 4;         // its message offset + 4 (>= 1 where the lane absorbs anything)
+      const int i4 = o4 >> 2;                              // words i4 - 2 (low) and i4 - 1 (high) of c hold the window
+      uint32_t lo = 0, hi = 0;
+      CPX_UNROLL for (int t = 0; t < 8; t++) {
+        lo = i4 == t + 2 ? c[t] : lo;
+        hi = i4 == t + 1 ? c[t] : hi;
+      }
+      uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)o4 & 3u);
+      // keep the bytes j with pos <= s0 + j < pos + k
+      const int b0 = max((int)pos - s0, 0), b1 = min((int)(pos + k) - s0, 4);
+      const uint32_t m = (w >= 0 && b0 < b1) ? (uint32_t)((((uint64_t)1 << (8 * (b1 - b0))) - 1) << (8 * b0)) : 0u;
+      xor_own_bytes(v & m);
+      pos += k;
+      off += k;
+      left -= k;
       if (pos == Strobe::RATE) run_f();
     }
   }
@@ -206,14 +241,10 @@ struct WaveStrobe {
     begin_op(Strobe::FLAG_M | Strobe::FLAG_A, more);
     absorb(static_cast<const uint8_t*>(d), n);
   }
-  __device__ void len4(size_t len, uint8_t* scratch4) {   // LE32(len) through the wave's scratch bytes
-    if (l < 4) scratch4[l] = (uint8_t)(len >> (8 * l));
-    wave_lds_sync();
-    meta_ad(scratch4, 4, true);
-  }
-  __device__ void append_begin(const char* label, size_t label_len, size_t len, uint8_t* scratch) {
-    meta_ad(label, label_len, false);
-    len4(len, scratch);
+  // meta-AD(label || LE32(len)), then the operation header of the data that follows (merlin's append_message up to the data)
+  __device__ void append_begin(const char* label, size_t label_len, size_t len, uint8_t* /*scratch*/) {
+    begin_op(Strobe::FLAG_M | Strobe::FLAG_A, false);
+    absorb(reinterpret_cast<const uint8_t*>(label), label_len, (uint32_t)len, 4);
     begin_op(Strobe::FLAG_A, false);
   }
   __device__ void init(const char* label, size_t label_len, uint8_t* scratch) {
@@ -243,10 +274,10 @@ struct WaveStrobe {
       if (l == 27) st27[26] = pos_begin;
     }
   }
-  // the first 32 bytes of the state (words 0..3) as plain 64-bit words, in every lane
+  // the first 32 bytes of the state (words 0..3) as plain 64-bit words, uniform (scalar reads of the eight lanes that hold them)
   __device__ __forceinline__ void peek4(uint64_t sq[4]) const {
     CPX_UNROLL for (int j = 0; j < 4; j++) {
-      const uint32_t e = (uint32_t)__shfl((int)a, lane_of_word(j), 64), o = (uint32_t)__shfl((int)a, 32 + lane_of_word(j), 64);
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)a, lane_of_word(j)), o = (uint32_t)__builtin_amdgcn_readlane((int)a, 32 + lane_of_word(j));
       sq[j] = bits_join64(e, o);
     }
   }
@@ -259,20 +290,15 @@ struct WaveStrobe {
   // lane holds (Montgomery form)
   __device__ void append_scalar(const char* label, size_t label_len, const Fr& x_mont, uint8_t* scratch) {
     const Fr c = fe_from_mont(x_mont);
-    if (l < 8) {
-      CPX_UNROLL for (int j = 0; j < 4; j++) scratch[16 + 4 * l + j] = (uint8_t)(c.v[l] >> (8 * j));
-    }
-    wave_lds_sync();
     append_begin(label, label_len, 32, scratch);
-    absorb(scratch + 16, 32);
-    wave_lds_sync();   // scratch may be rewritten right away by the next operation
+    absorb_words8(c.v);
   }
   // One attempt of get_and_append_challenge (transcript.rs:40-60): 64 PRF bytes, Fr::from_random_bytes on the first 32 with the top
   // bit cleared; when canonical and non-zero the scalar is appended back under the same label and returned in canonical form
   // (uniform over the wave), otherwise the caller retries.
   __device__ bool challenge_attempt(const char* label, size_t label_len, uint8_t* scratch, Fr& c) {
-    meta_ad(label, label_len, false);
-    len4(64, scratch);
+    begin_op(Strobe::FLAG_M | Strobe::FLAG_A, false);
+    absorb(reinterpret_cast<const uint8_t*>(label), label_len, 64, 4);
     begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);   // forces a permutation: pos = 0 afterwards
     // squeeze 64 bytes = words 0..7 of the state, which the PRF operation overwrites with zero (pos is 0 here)
     uint64_t sq[4];
@@ -293,13 +319,8 @@ struct WaveStrobe {
       }
     }
     if (!(lt && nz)) return false;
-    if (l < 4) {
-      CPX_UNROLL for (int j = 0; j < 8; j++) scratch[16 + 8 * l + j] = (uint8_t)(sq[l] >> (8 * j));
-    }
-    wave_lds_sync();
     append_begin(label, label_len, 32, scratch);
-    absorb(scratch + 16, 32);
-    wave_lds_sync();
+    absorb_words8(c.v);
     return true;
   }
   // get_and_append_challenge: retried until canonical and non-zero.  Returns the Montgomery form (uniform over the wave).

@@ -34,10 +34,23 @@ __global__ __launch_bounds__(64) void k_check(const uint64_t* in27, uint64_t* ou
   uint64_t sq[4];
   s.peek4(sq);
   if (threadIdx.x == 63) for (int j = 0; j < 4; j++) out27[54 + j] = sq[j];
+  // a run of Merlin operations: a message with its label and length, a scalar, three challenges (positions 17 .. wrap around the rate)
+  __shared__ uint8_t scratch[64];
+  s.load(in27, threadIdx.x);
+  for (int rep = 0; rep < 3; rep++) {
+    s.append_message("some_label", 10, msg, 48, scratch);
+    Fr x;
+    for (int j = 0; j < 8; j++) x.v[j] = 0x01234567u * (j + 1 + rep);
+    x.v[7] &= 0x0fffffffu;
+    s.append_scalar("a_scalar", 8, fe_to_mont(x), scratch);
+    const Fr c = s.challenge_scalar("a_challenge", 11, scratch);
+    if (threadIdx.x == 5) for (int j = 0; j < 4; j++) out27[58 + 27 + 4 * rep + j] = (uint64_t)c.v[2 * j] | ((uint64_t)c.v[2 * j + 1] << 32);
+  }
+  s.store(out27 + 58);
 }
 int main() {
   {   // one permutation of a non-trivial state against the host's keccak_f1600, an absorb against the host's Strobe (strobe.hpp)
-    uint64_t h[27], ref[25], got[58];
+    uint64_t h[27], ref[25], got[58 + 27 + 12];
     for (int i = 0; i < 25; i++) h[i] = ref[i] = 0x9e3779b97f4a7c15ULL * (i + 1) ^ (0x0123456789abcdefULL << (i % 7));
     h[25] = 17; h[26] = 3;
     keccak_f1600(ref);
@@ -48,6 +61,25 @@ int main() {
     hs.pos = 17; hs.pos_begin = 3;
     hs.absorb(msg, 1000);
     hs.xor_byte(hs.pos, 0xa7);
+    Strobe hm;   // the Merlin run on the host
+    for (int i = 0; i < 25; i++) hm.st[i] = h[i];
+    hm.pos = 17; hm.pos_begin = 3;
+    uint64_t chal[12];
+    for (int rep = 0; rep < 3; rep++) {
+      hm.append_message("some_label", msg, 48);
+      uint32_t xv[8];
+      for (int j = 0; j < 8; j++) xv[j] = 0x01234567u * (j + 1 + rep);
+      xv[7] &= 0x0fffffffu;
+      uint8_t xb[32];
+      for (int j = 0; j < 32; j++) xb[j] = (uint8_t)(xv[j >> 2] >> (8 * (j & 3)));
+      hm.append_message("a_scalar", xb, 32);
+      uint32_t e[8];
+      hm.challenge_scalar_canonical("a_challenge", e);
+      Fr ce;
+      for (int j = 0; j < 8; j++) ce.v[j] = e[j];
+      const Fr cm = fe_to_mont(ce);
+      for (int j = 0; j < 4; j++) chal[4 * rep + j] = (uint64_t)cm.v[2 * j] | ((uint64_t)cm.v[2 * j + 1] << 32);
+    }
     uint64_t *din, *dout; uint8_t* dm;
     HIPCHECK(hipMalloc(&din, sizeof h)); HIPCHECK(hipMalloc(&dout, sizeof got)); HIPCHECK(hipMalloc(&dm, 1000));
     HIPCHECK(hipMemcpy(din, h, sizeof h, hipMemcpyHostToDevice));
@@ -61,8 +93,13 @@ int main() {
     for (int i = 0; i < 25; i++) bad2 += got[27 + i] != hs.st[i];
     bad2 += got[27 + 25] != hs.pos || got[27 + 26] != hs.pos_begin;
     for (int j = 0; j < 4; j++) bad2 += got[54 + j] != hs.st[j];
-    printf("lane-parallel keccak-f[1600] against the host permutation: %d mismatches; absorb / xor_byte / peek4 against the host's Strobe: %d mismatches\n", bad, bad2);
-    if (bad || bad2) return 1;
+    int bad3 = 0;
+    for (int i = 0; i < 25; i++) bad3 += got[58 + i] != hm.st[i];
+    bad3 += got[58 + 25] != hm.pos || got[58 + 26] != hm.pos_begin;
+    for (int j = 0; j < 12; j++) bad3 += got[58 + 27 + j] != chal[j];
+    printf("lane-parallel keccak-f[1600] against the host permutation: %d mismatches; absorb / xor_byte / peek4 against the host's Strobe: %d mismatches; "
+           "append_message / append_scalar / challenge_scalar x 3: %d mismatches\n", bad, bad2, bad3);
+    if (bad || bad2 || bad3) return 1;
   }
   const size_t len = 166 * 256;
   uint8_t* dmsg; uint64_t *dt, *dout;

@@ -125,20 +125,22 @@ void emul_msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* o
   memcpy(out, &res, sizeof res);
 }
 
-// k_smul's per-element computation: (add ? add : O) + s*mul via NAF, Jacobian (standard form) out
+// k_smul's per-element computation: (add ? add : O) + s*mul via the endomorphism split + NAF of both halves, Jacobian (standard form) out
 void emul_smul(const uint8_t* add, const uint8_t* mul, const uint8_t* scalar, uint8_t* out) {
   Fr k;
   memcpy(k.v, scalar, 32);
   k = fe_from_mont(k);
-  uint32_t nz[9], ng[9];
-  recode_naf(k.v, nz, ng);
+  SmulNaf rn;
+  recode_smul_glv(k.v, rn);
   Aff Ps;
   memcpy(&Ps, mul, sizeof Ps);
   const TAff P = t_from_std(Ps);
+  const TAff NP = P.is_identity() ? P : TAff{t_mul(P.x, t_beta()), t_neg(P.y)};
   TJac acc = TJac::identity();
-  for (int i = 256; i >= 0; i--) {
+  for (int i = 128; i >= 0; i--) {
     acc = t_dbl(acc);
-    if ((nz[i >> 5] >> (i & 31)) & 1u) acc = t_add_mixed(acc, t_cneg(P, (ng[i >> 5] >> (i & 31)) & 1u));
+    if ((rn.nz[0][i >> 5] >> (i & 31)) & 1u) acc = t_add_mixed(acc, t_cneg(P, (rn.ng[0][i >> 5] >> (i & 31)) & 1u));
+    if ((rn.nz[1][i >> 5] >> (i & 31)) & 1u) acc = t_add_mixed(acc, t_cneg(NP, (rn.ng[1][i >> 5] >> (i & 31)) & 1u));
   }
   if (add) {
     Aff A;

@@ -210,11 +210,11 @@ struct WaveStrobe {
       const uint32_t k = min(Strobe::RATE - pos, left);
       const int s0 = 8 * w + 4 * h;                        // this lane's first state byte
       const int o4 = s0 - (int)pos + (int)off + 4;         // its message offset + 4 (>= 1 where the lane absorbs anything)
-      const int i4 = o4 >> 2;                              // words i4 - 2 (low) and i4 - 1 (high) of c hold the window
+      const int i4 = o4 >> 2;                              // words i4 - 1 (low) and i4 (high) of c hold the window (zero outside 0..7)
       uint32_t lo = 0, hi = 0;
       CPX_UNROLL for (int t = 0; t < 8; t++) {
-        lo = i4 == t + 2 ? c[t] : lo;
-        hi = i4 == t + 1 ? c[t] : hi;
+        lo = i4 == t + 1 ? c[t] : lo;
+        hi = i4 == t ? c[t] : hi;
       }
       uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)o4 & 3u);
       // keep the bytes j with pos <= s0 + j < pos + k

@@ -1341,9 +1341,16 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
     Fr c;
     while (!t.challenge_attempt("curdleproofs_vec_a", 18, scratch, c)) {
     }
-    if (threadIdx.x == 0) out_vec_a[(size_t)p * ell + i] = fe_to_mont(c);
+    if (threadIdx.x == 0) out_vec_a[(size_t)p * ell + i] = c;   // canonical for now
   }
   t.store(out_state + (size_t)p * 27);
+  // Montgomery form, 64 challenges at a time (a product per challenge inside the serial loop above costs as much as half a permutation)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = threadIdx.x; i < ell; i += 64) {
+    Fr* q = out_vec_a + (size_t)p * ell + i;
+    *q = fe_to_mont(*q);
+  }
 }
 
 // The same prefix with ONE LANE per transcript (large batches: option transcript_lane_min_batch).  The lane-parallel form above is built

@@ -185,22 +185,36 @@ struct WaveStrobe {
   // without staging the length in memory.  A lane fetches the four bytes of its word that its half owns.
   __device__ void absorb(const uint8_t* d, size_t n, uint32_t tail = 0, uint32_t tail_n = 0) {
     size_t left = n + tail_n, off = 0;
-    while (left) {
-      const uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), left);
+    // the lane's bytes of the chunk that starts at message offset `o` and fills the rate from position `p` with `kk` bytes
+    auto fetch = [&](size_t o, uint32_t p, uint32_t kk) {
       uint32_t v = 0;
       CPX_UNROLL for (int j = 0; j < 4; j++) {
         const uint32_t sidx = 8u * (uint32_t)w + 4u * (uint32_t)h + j;   // state byte owned by this lane (w = -1: beyond every position)
-        if (w >= 0 && sidx >= pos && sidx < pos + k) {
-          const size_t m = off + (sidx - pos);
+        if (w >= 0 && sidx >= p && sidx < p + kk) {
+          const size_t m = o + (sidx - p);
           const uint32_t b = m < n ? (uint32_t)d[m] : (tail >> (8 * (uint32_t)(m - n))) & 0xffu;
           v |= b << (8 * j);
         }
       }
+      return v;
+    };
+    uint32_t k = (uint32_t)min((size_t)(Strobe::RATE - pos), left);
+    uint32_t v = fetch(0, pos, k);
+    while (left) {
+      // the next chunk starts at position 0 after a permutation: its bytes are fetched BEFORE the permutation runs (a long
+      // message comes from HBM, one block per permutation: the load's latency hides behind the 2.4 us of the permutation)
+      const size_t left_next = left - k;
+      const uint32_t k_next = (uint32_t)min((size_t)Strobe::RATE, left_next);
+      const bool full = pos + k == Strobe::RATE;
+      uint32_t v_next = 0;
+      if (full && left_next) v_next = fetch(off + k, 0, k_next);
       xor_own_bytes(v);
       pos += k;
       off += k;
-      left -= k;
-      if (pos == Strobe::RATE) run_f();
+      left = left_next;
+      if (full) run_f();
+      v = v_next;
+      k = k_next;
     }
   }
   // absorb the 32 bytes of eight words every lane holds (uniform): a lane picks the two words its four bytes fall into — no memory

@@ -48,6 +48,38 @@ __global__ __launch_bounds__(64) void k_check(const uint64_t* in27, uint64_t* ou
   }
   s.store(out27 + 58);
 }
+// where a challenge's time goes: the steps of WaveStrobe::challenge_attempt timed one by one (wall clock, 10 ns ticks), 252 challenges
+__global__ __launch_bounds__(64) void k_sections(const uint64_t* in27, uint64_t* tsum, Fr* out, int n) {
+  __shared__ uint8_t scratch[64];
+  WaveStrobe t;
+  t.load(in27, threadIdx.x);
+  uint64_t acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    Fr c;
+    const uint64_t t0 = wall_clock64();
+    t.begin_op(Strobe::FLAG_M | Strobe::FLAG_A, false);
+    t.absorb(reinterpret_cast<const uint8_t*>("curdleproofs_vec_a"), 18, 64, 4);
+    const uint64_t t1 = wall_clock64();
+    t.begin_op(Strobe::FLAG_I | Strobe::FLAG_A | Strobe::FLAG_C, false);
+    const uint64_t t2 = wall_clock64();
+    uint64_t sq[4];
+    t.peek4(sq);
+    if (t.w >= 0 && t.w < 8) t.a = 0;
+    t.pos = 64;
+    sq[3] &= 0x7fffffffffffffffULL;
+    for (int j = 0; j < 4; j++) { c.v[2 * j] = (uint32_t)sq[j]; c.v[2 * j + 1] = (uint32_t)(sq[j] >> 32); }
+    const uint64_t t3 = wall_clock64();
+    t.append_begin("curdleproofs_vec_a", 18, 32, scratch);
+    const uint64_t t4 = wall_clock64();
+    t.absorb_words8(c.v);
+    const uint64_t t5 = wall_clock64();
+    if (threadIdx.x == 0) out[i] = fe_to_mont(c);
+    const uint64_t t6 = wall_clock64();
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3; acc[4] += t5 - t4; acc[5] += t6 - t5;
+  }
+  t.store(tsum + 8);
+  if (threadIdx.x == 0 && blockIdx.x == 0) for (int j = 0; j < 6; j++) tsum[j] = acc[j];
+}
 int main() {
   {   // one permutation of a non-trivial state against the host's keccak_f1600, an absorb against the host's Strobe (strobe.hpp)
     uint64_t h[27], ref[25], got[58 + 27 + 12];
@@ -113,6 +145,25 @@ int main() {
     uint64_t t[2];
     HIPCHECK(hipMemcpy(t, dt, sizeof t, hipMemcpyDeviceToHost));
     printf("%5d work-groups: keccak-f %.2f us each; absorbing a 166-byte block (+ its permutation) %.2f us\n", blocks, t[0] / 100.0 / reps, t[1] / 100.0 / 256);
+  }
+  {
+    uint64_t h[27];
+    for (int i = 0; i < 25; i++) h[i] = 0x9e3779b97f4a7c15ULL * (i + 1);
+    h[25] = 17; h[26] = 3;
+    uint64_t *din, *dts; Fr* dfr;
+    HIPCHECK(hipMalloc(&din, sizeof h)); HIPCHECK(hipMalloc(&dts, 64 * 8)); HIPCHECK(hipMalloc(&dfr, 252 * sizeof(Fr)));
+    HIPCHECK(hipMemcpy(din, h, sizeof h, hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 2; rep++) {
+      hipLaunchKernelGGL(k_sections, dim3(1), dim3(64), 0, 0, din, dts, dfr, 252);
+      HIPCHECK(hipDeviceSynchronize());
+    }
+    uint64_t ts[6];
+    HIPCHECK(hipMemcpy(ts, dts, sizeof ts, hipMemcpyDeviceToHost));
+    const char* names[6] = {"meta-AD(label || len)", "PRF header + forced permutation", "squeeze (peek4 + join)", "append_begin (label || len, AD header)", "absorb_words8", "fe_to_mont + store"};
+    double tot = 0;
+    for (int j = 0; j < 6; j++) tot += ts[j] / 100.0 / 252;
+    printf("one challenge of the vec_a loop, alone on the GPU: %.2f us\n", tot);
+    for (int j = 0; j < 6; j++) printf("  %-42s %.2f us\n", names[j], ts[j] / 100.0 / 252);
   }
   return 0;
 }

@@ -503,7 +503,7 @@ void Engine::enqueue_prove_device() {
   CPX_HIP(hipEventRecord(dp.ev_a, stream_));
   CPX_HIP(hipStreamWaitEvent(side, dp.ev_a, 0));
   tick("k_transcript_step1", 0, (double)B);
-  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256));
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256), (long)B <= opt_.transcript_excl_max);
   tock();
   CPX_HIP(hipEventRecord(dp.ev_b, side));
   {
@@ -787,7 +787,7 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
   hipStream_t const side = opt_.serial_streams ? stream_ : side_.stream;
   CPX_HIP(hipStreamWaitEvent(side, dv.ev_a, 0));
   tick("k_transcript_step1", 0, (double)B);
-  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256));
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256), (long)B <= opt_.transcript_excl_max);
   tock();
   CPX_HIP(hipEventRecord(dv.ev_b, side));
   tick("k_decompress", 0, (double)(B * NPP));

@@ -1320,11 +1320,19 @@ __global__ __launch_bounds__(128) void k_smsm_round_fold(Fr* __restrict__ vec, i
 // (a single GPU lane needs ~17 us per permutation).  Message bytes are absorbed by the lanes that own their position in the rate.
 // Same semantics as strobe.hpp (the host's code), pinned by the bit-exact proof tests.
 // out_state: [nproofs][27] u64, out_vec_a: [nproofs][ell] Fr (Montgomery wire form)
+// EXCL (small batches, option transcript_excl_max): the wave claims all 512 registers of its SIMD, so no wave of the kernels that run
+// beside the prefix (table build, phase 1, decompression) is placed on the same SIMD — a lone dependent chain that shares its SIMD
+// takes 1.7 times as long, and the slowest wave is the kernel.
+template <bool EXCL>
 __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restrict__ inst_comp, const uint8_t* __restrict__ m_comp, int nproofs, int ell,
                                                          uint64_t* __restrict__ out_state, Fr* __restrict__ out_vec_a) {
   __shared__ uint8_t scratch[64];
   const int p = blockIdx.x;
   if (p >= nproofs) return;
+  if (EXCL) {
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+  }
   WaveStrobe t;
   t.set_lane(threadIdx.x);
   t.init("curdleproofs", 12, scratch);
@@ -1532,6 +1540,7 @@ const OptField kOptFields[] = {
     {"p1_split", &Options::p1_split, 0, 1},                      {"transcript_lane_min_batch", &Options::transcript_lane_min_batch, 1, 1L << 30},
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
+    {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;
@@ -1816,13 +1825,15 @@ void launch_smsm_round_scalars(const Fr* d_vec, int nproofs, int n, int half, Fr
 void launch_smsm_round_fold(Fr* d_vec, int nproofs, int n, int half, const Fr* d_gam, hipStream_t s, int active) {
   if (nproofs > 0) CPX_LAUNCH(k_smsm_round_fold, dim3(nproofs), dim3(128), 0, s, d_vec, n, active > 0 ? active : n, half, d_gam);
 }
-void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s, bool lane_per_proof) {
+void launch_transcript_step1(const uint8_t* d_inst_comp, const uint8_t* d_m_comp, int nproofs, int ell, uint64_t* d_state, Fr* d_vec_a, hipStream_t s, bool lane_per_proof,
+                             bool exclusive_simd) {
   if (nproofs <= 0) return;
   if (lane_per_proof) {
     CPX_LAUNCH(k_transcript_step1_lane, dim3((nproofs + 63) / 64), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
     return;
   }
-  CPX_LAUNCH(k_transcript_step1, dim3(nproofs), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
+  if (exclusive_simd) CPX_LAUNCH(k_transcript_step1<true>, dim3(nproofs), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
+  else CPX_LAUNCH(k_transcript_step1<false>, dim3(nproofs), dim3(64), 0, s, d_inst_comp, d_m_comp, nproofs, ell, d_state, d_vec_a);
 }
 void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s) { CPX_LAUNCH(k_sum_jac, dim3(1), dim3(64), 0, s, d_in, n, d_out, d_flag); }
 void launch_bench_f28mul(Fp* d_data, int blocks, int iters, hipStream_t s) {

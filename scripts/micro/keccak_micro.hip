@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cmath>
 #include "wave_strobe.hpp"
 using namespace cpx;
 #define HIPCHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -79,6 +80,39 @@ __global__ __launch_bounds__(64) void k_sections(const uint64_t* in27, uint64_t*
   }
   t.store(tsum + 8);
   if (threadIdx.x == 0 && blockIdx.x == 0) for (int j = 0; j < 6; j++) tsum[j] = acc[j];
+}
+// the transcript prefix of k_transcript_step1 (kernels.hip) with its two stretches timed: instance absorbed / challenges drawn
+template <bool EXCL> __global__ __launch_bounds__(64) void k_prefix(const uint8_t* inst_comp, const uint8_t* m_comp, int nproofs, int ell, uint64_t* out_state, Fr* out_vec_a, uint64_t* tsum) {
+  __shared__ uint8_t scratch[64];
+  const int p = blockIdx.x;
+  if (p >= nproofs) return;
+  if (EXCL) {   // the whole register file of the SIMD: no other wave can be placed beside this one
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+  }
+  WaveStrobe t;
+  t.set_lane(threadIdx.x);
+  const uint64_t t0 = wall_clock64();
+  t.init("curdleproofs", 12, scratch);
+  for (int v = 0; v < 4; v++) {
+    t.append_begin("curdleproofs_step1", 18, 8 + 48 * (size_t)ell, scratch);
+    if (t.l < 8) scratch[8 + t.l] = (uint8_t)((uint64_t)ell >> (8 * t.l));
+    wave_lds_sync();
+    t.absorb(scratch + 8, 8);
+    t.absorb(inst_comp + ((size_t)p * 4 + v) * ell * 48, 48 * (size_t)ell);
+  }
+  t.append_begin("curdleproofs_step1", 18, 48, scratch);
+  t.absorb(m_comp + (size_t)p * 48, 48);
+  const uint64_t t1 = wall_clock64();
+  for (int i = 0; i < ell; i++) {
+    Fr c;
+    while (!t.challenge_attempt("curdleproofs_vec_a", 18, scratch, c)) {
+    }
+    if (threadIdx.x == 0) out_vec_a[(size_t)p * ell + i] = c;
+  }
+  const uint64_t t2 = wall_clock64();
+  t.store(out_state + (size_t)p * 27);
+  if (threadIdx.x == 0) { tsum[2 * p] = t1 - t0; tsum[2 * p + 1] = t2 - t1; }
 }
 int main() {
   {   // one permutation of a non-trivial state against the host's keccak_f1600, an absorb against the host's Strobe (strobe.hpp)
@@ -164,6 +198,26 @@ int main() {
     for (int j = 0; j < 6; j++) tot += ts[j] / 100.0 / 252;
     printf("one challenge of the vec_a loop, alone on the GPU: %.2f us\n", tot);
     for (int j = 0; j < 6; j++) printf("  %-42s %.2f us\n", names[j], ts[j] / 100.0 / 252);
+  }
+  {
+    const int np = 128, ell = 252;
+    uint8_t *dinst, *dm; uint64_t *dst, *dts; Fr* dva;
+    HIPCHECK(hipMalloc(&dinst, (size_t)np * 4 * ell * 48)); HIPCHECK(hipMalloc(&dm, np * 48)); HIPCHECK(hipMalloc(&dst, np * 27 * 8)); HIPCHECK(hipMalloc(&dts, np * 16));
+    HIPCHECK(hipMalloc(&dva, (size_t)np * ell * sizeof(Fr)));
+    HIPCHECK(hipMemset(dinst, 0x3c, (size_t)np * 4 * ell * 48)); HIPCHECK(hipMemset(dm, 0x11, np * 48));
+    for (int excl = 0; excl < 2; excl++) {
+      for (int rep = 0; rep < 2; rep++) {
+        if (excl) hipLaunchKernelGGL(k_prefix<true>, dim3(np), dim3(64), 0, 0, dinst, dm, np, ell, dst, dva, dts);
+        else hipLaunchKernelGGL(k_prefix<false>, dim3(np), dim3(64), 0, 0, dinst, dm, np, ell, dst, dva, dts);
+        HIPCHECK(hipDeviceSynchronize());
+      }
+      uint64_t ts[2 * 128];
+      HIPCHECK(hipMemcpy(ts, dts, sizeof ts, hipMemcpyDeviceToHost));
+      double a = 0, b = 0, mx = 0;
+      for (int i = 0; i < np; i++) { a += ts[2 * i] / 100.0; b += ts[2 * i + 1] / 100.0; mx = fmax(mx, (ts[2 * i] + ts[2 * i + 1]) / 100.0); }
+      printf("transcript prefix, 128 proofs of ell = 252 alone on the GPU%s: instance absorbed in %.0f us, 252 challenges in %.0f us (means over the waves), slowest wave %.0f us\n",
+             excl ? " (a SIMD's whole register file per wave)" : "", a / np, b / np, mx);
+    }
   }
   return 0;
 }

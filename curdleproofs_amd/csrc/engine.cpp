@@ -58,9 +58,11 @@ Engine::~Engine() {
   for (hipEvent_t e : {tab_.ev_start, tab_.ev_m, tab_.ev_done})
     if (e) (void)hipEventDestroy(e);
   if (tab_.stream) (void)hipStreamDestroy(tab_.stream);
-  for (hipEvent_t e : {dprove_.ev_a, dprove_.ev_b, dprove_.ev_c, dprove_.ev_d, dverify_.ev_a, dverify_.ev_b})
+  if (tab_.dstream) (void)hipStreamDestroy(tab_.dstream);
+  for (hipEvent_t e : {dprove_.ev_a, dprove_.ev_b, dprove_.ev_c, dprove_.ev_d, dprove_.ev_t1, dprove_.ev_t2, dprove_.ev_a2, dverify_.ev_a, dverify_.ev_b})
     if (e) (void)hipEventDestroy(e);
   if (side_.stream) (void)hipStreamDestroy(side_.stream);
+  if (side_.hi_stream) (void)hipStreamDestroy(side_.hi_stream);
   if (side_.lat_stream) (void)hipStreamDestroy(side_.lat_stream);
   if (side_.lat_main) (void)hipStreamDestroy(side_.lat_main);
   if (side_.lat_ev) (void)hipEventDestroy(side_.lat_ev);

@@ -182,6 +182,7 @@ class Engine {
   // second stream + private staging for work that is off the critical path of the phase sequence
   struct SideBufs {
     hipStream_t stream = nullptr;
+    hipStream_t hi_stream = nullptr;   // high-priority stream: the transcript prefix of a small batch (its waves are placed before those of the table build)
     hipStream_t lat_stream = nullptr, lat_main = nullptr;   // the host-driven prover's side / main stream: CU-masked (create_masked_stream)
     hipEvent_t lat_ev = nullptr;
     hipEvent_t ev = nullptr, ev2 = nullptr;
@@ -203,6 +204,7 @@ class Engine {
   // and the IPA rounds
   struct TabBufs {
     hipStream_t stream = nullptr;
+    hipStream_t dstream = nullptr;   // the device-resident prover's table stream (plain): table build + B_t, B_u beside phase 1 (engine_device.cpp)
     hipEvent_t ev_start = nullptr, ev_m = nullptr, ev_done = nullptr;   // M finalised (main) / M's table row built / B_t, B_u compressed
     DevBuf<uint8_t> blob;      // vec_r scalars | TblTask | first | count | dst
     PinBuf<uint8_t> stage;
@@ -220,6 +222,7 @@ class Engine {
 
   void set_crs_impl(size_t ell, const uint8_t* points);
   hipStream_t create_masked_stream(bool upper);
+  hipStream_t prefix_stream();
   const Aff& generator();
   void compress_affine(const Aff* pts, size_t n, uint8_t* out);
   bool unzip_trackers(const uint8_t* trackers, size_t n, std::vector<Aff>& vec_r, std::vector<Aff>& vec_s);
@@ -242,7 +245,7 @@ class Engine {
     DevBuf<uint32_t> perm, mdst;
     DevBuf<Fr> k, mbl, rnd, vec, sc, rvec2;
     DevBuf<uint8_t> slotcomp, proofs;
-    TblPlan p1, p1b, p2, p3;
+    TblPlan p1, p1b, p1t, p2, p3;   // p1t: B_t, B_u — the two commitments of phase 1 over per-proof tables, on the table stream
     std::vector<std::unique_ptr<TblPlan>> ipa, smsm;
     // the last log rounds on materialised folded bases (late.hip; options late_rounds, late_min_batch)
     struct Late {
@@ -259,7 +262,7 @@ class Engine {
       const uint32_t* gb_cols = nullptr;
     } late;
     const uint32_t* side_cols = nullptr;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_t1 = nullptr, ev_t2 = nullptr, ev_a2 = nullptr;   // t1: tables built, t2: B_t, B_u in the registry, a2: the prefix stream is about to launch
   };
   DevProver dprove_;
   void enqueue_prove_device();
@@ -281,7 +284,7 @@ class Engine {
   void prepare_device_verifier(size_t rand_stride);
   void verify_core_device(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid);
   void build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std::vector<uint32_t>& comp_index);
-  void exec_plan(const TblPlan& pl, uint8_t* d_comp_registry);
+  void exec_plan(const TblPlan& pl, uint8_t* d_comp_registry, bool on_table_stream = false);
   void prepare_device_prover();
   void batch_prove_device(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
 

@@ -95,24 +95,34 @@ void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std:
   if (nt) CPX_HIP(hipMemcpy(pl.meta.p, meta.data(), meta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 }
 
-void Engine::exec_plan(const TblPlan& pl, uint8_t* d_comp_registry) {
+void Engine::exec_plan(const TblPlan& pl, uint8_t* d_comp_registry, bool on_table_stream) {
   if (!pl.nt) return;
-  d_tpart_.ensure(std::max<size_t>(pl.nparts, 1));
-  ensure_raw_sets(pl.fix_sets + pl.tbl_sets);
+  // (a plan on the table stream works in the table stream's own scratch, sized by prepare_device_prover: it runs beside the plans
+  // of the main stream)
+  const bool tl = on_table_stream && !opt_.serial_streams;
+  hipStream_t const st = tl ? tab_.dstream : stream_;
+  if (!tl) {
+    d_tpart_.ensure(std::max<size_t>(pl.nparts, 1));
+    ensure_raw_sets(pl.fix_sets + pl.tbl_sets);
+  }
+  uint32_t* const raw = tl ? tab_.raw.p : d_raw_.p;
+  uint32_t* const rawslot = tl ? tab_.rawslot.p : d_rawslot_.p;
+  TJac* const part = tl ? tab_.part.p : d_tpart_.p;
   if (pl.nft) {
     tick(fix_kernel_name(fix_bits_, pl.fix_wpw), 128.0 * pl.pts_fix, pl.pts_fix);
-    launch_msm_fix(pl.ftasks.p, (int)pl.nft, fixtab(), fix_bits_, pl.fix_wpw, (int)nc(), d_raw_.p, d_rawslot_.p, stream_);
+    launch_msm_fix(pl.ftasks.p, (int)pl.nft, fixtab(), fix_bits_, pl.fix_wpw, (int)nc(), raw, rawslot, st);
     tock();
   }
   if (pl.ntt) {
     tick(tblw_kernel_name(pl.tbl_wpw), 128.0 * pl.pts_tbl, pl.pts_tbl);
-    launch_msm_tblw(pl.ttasks.p, (int)pl.ntt, pl.tbl_wpw, d_raw_.p + pl.fix_sets * raw_set_words(), d_rawslot_.p + pl.fix_sets, stream_);
+    launch_msm_tblw(pl.ttasks.p, (int)pl.ntt, pl.tbl_wpw, raw + pl.fix_sets * raw_set_words(), rawslot + pl.fix_sets, st);
     tock();
   }
-  reduce_sets(pl.fix_sets, pl.tbl_sets);
+  if (tl) launch_reduce_sets(opt_, raw, rawslot, (int)pl.fix_sets, (int)pl.tbl_sets, tab_.mid.p, part, st, (int)B_);   // (not timed: a span is bracketed on the main stream)
+  else reduce_sets(pl.fix_sets, pl.tbl_sets);
   const uint32_t* m = pl.meta.p;
   tick("k_finalize_ranges", 0, (double)pl.nt);
-  launch_finalize_ranges(opt_, d_tpart_.p, m, m + pl.nt, (int)pl.nt, d_pp_.p, m + 2 * pl.nt, d_comp_registry, stream_, pl.any_add ? m + 4 * pl.nt : nullptr, m + 3 * pl.nt);
+  launch_finalize_ranges(opt_, part, m, m + pl.nt, (int)pl.nt, d_pp_.p, m + 2 * pl.nt, d_comp_registry, st, pl.any_add ? m + 4 * pl.nt : nullptr, m + 3 * pl.nt);
   tock();
 }
 
@@ -249,10 +259,6 @@ void Engine::prepare_device_prover() {
     }
     reqs.push_back(req(cseg(0, (uint32_t)n, iGb), none, rnd(p, ri.VR())));                            // B_a
     ci.push_back(cidx(p, sm.BA()));
-    reqs.push_back(req(pseg(p, O_T, (uint32_t)n), none, rnd(p, ri.VR())));                            // B_t
-    ci.push_back(cidx(p, sm.BT()));
-    reqs.push_back(req(pseg(p, O_U, (uint32_t)n), none, rnd(p, ri.VR())));                            // B_u
-    ci.push_back(cidx(p, sm.BU()));
     reqs.push_back(req(cseg(0, (uint32_t)n), none, rnd(p, ri.IR())));                                 // B_c = msm(G | Hvec, r_c)
     ci.push_back(cidx(p, SL_BC));
     reqs.push_back(req(cseg(0, 1, iGt), none, rnd(p, ri.RT()), slot_index(p, SL_CMT1)));              // cm_T.T_1 = r_t G_t
@@ -270,6 +276,22 @@ void Engine::prepare_device_prover() {
     }
   }
   build_plan(dp.p1, reqs, ci);
+  // -- phase 1t: B_t = msm(T_b, r), B_u = msm(U_b, r) (same_multiscalar_argument.rs:81-82) — the two commitments of phase 1 over the
+  //    per-proof tables.  Nothing reads them before the SameMSM transcript step: they follow the table build on the table stream, and
+  //    the main stream goes on with the CRS-only commitments at once
+  reqs.clear();
+  ci.clear();
+  for (size_t p = 0; p < B; p++) {
+    reqs.push_back(req(pseg(p, O_T, (uint32_t)n), none, rnd(p, ri.VR())));
+    ci.push_back(cidx(p, sm.BT()));
+    reqs.push_back(req(pseg(p, O_U, (uint32_t)n), none, rnd(p, ri.VR())));
+    ci.push_back(cidx(p, sm.BU()));
+  }
+  build_plan(dp.p1t, reqs, ci);
+  tab_.raw.ensure(std::max<size_t>(dp.p1t.fix_sets + dp.p1t.tbl_sets, 1) * raw_set_words());
+  tab_.rawslot.ensure(std::max<size_t>(dp.p1t.fix_sets + dp.p1t.tbl_sets, 1));
+  tab_.mid.ensure(std::max<size_t>(dp.p1t.fix_sets + dp.p1t.tbl_sets, 1) * reduce_mid_per_set());
+  tab_.part.ensure(std::max<size_t>(dp.p1t.nparts, 1));
   // -- phase 1b (option p1_split): A = msm(G | Hvec, a_sigma | blinders) (curdleproofs.rs:93) alone — the one commitment of phase 1
   //    that needs vec_a; the rest of the phase then runs before the main stream waits for the transcript prefix
   reqs.clear();
@@ -452,6 +474,12 @@ void Engine::prepare_device_prover() {
     CPX_HIP(hipMemcpy(side_.stasks.p, st.data(), st.size() * sizeof(SmulTask), hipMemcpyHostToDevice));
     dp.side_cols = idx_list({(uint32_t)SL_R, (uint32_t)SL_S, (uint32_t)SL_CMT2, (uint32_t)SL_CMU2, (uint32_t)sm.CMA2(), (uint32_t)sm.CMB2()});
   }
+  if (!tab_.dstream) CPX_HIP(hipStreamCreateWithFlags(&tab_.dstream, hipStreamNonBlocking));
+  if (!dp.ev_t1) {
+    CPX_HIP(hipEventCreateWithFlags(&dp.ev_t1, hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&dp.ev_t2, hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&dp.ev_a2, hipEventDisableTiming));
+  }
   if (!dp.ev_a) {
     CPX_HIP(hipEventCreateWithFlags(&dp.ev_a, hipEventDisableTiming));
     CPX_HIP(hipEventCreateWithFlags(&dp.ev_b, hipEventDisableTiming));
@@ -482,6 +510,22 @@ void Engine::prepare_device_prover() {
   dp.signature = sig;
 }
 
+// The high-priority stream of a small batch's transcript prefix (created on first use; a plain stream where priorities are not offered)
+hipStream_t Engine::prefix_stream() {
+  if (!side_.hi_stream) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) {
+      (void)hipGetLastError();
+      lo = hi = 0;
+    }
+    if (hipStreamCreateWithPriority(&side_.hi_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+      (void)hipGetLastError();
+      CPX_HIP(hipStreamCreateWithFlags(&side_.hi_stream, hipStreamNonBlocking));
+    }
+  }
+  return side_.hi_stream;
+}
+
 // The kernel launches of one device-resident prove (everything between the upload of the witnesses and the download of the proofs),
 // on the main stream and — forked and joined through events — the side stream.  No host synchronisation, no allocation.
 void Engine::enqueue_prove_device() {
@@ -502,10 +546,21 @@ void Engine::enqueue_prove_device() {
   launch_finalize(d_Mjac_.p, Bi, d_psrc_.p, dp.mdst.p, d_mcomp_.p, stream_);
   CPX_HIP(hipEventRecord(dp.ev_a, stream_));
   CPX_HIP(hipStreamWaitEvent(side, dp.ev_a, 0));
+  // (a small batch: the prefix's waves claim whole SIMDs and go through a high-priority queue, so that they are placed before the
+  // waves of the table build that becomes ready at the same moment — otherwise they wait for SIMDs to drain)
+  const bool excl = (long)B <= opt_.transcript_excl_max && !opt_.serial_streams;
+  hipStream_t const pre = excl ? prefix_stream() : side;
+  if (pre != side) {
+    // head start: the main and the table stream continue behind an event the prefix stream records just before it launches — one
+    // more hop between queues (~80 us) than the prefix kernel needs to place its waves on empty SIMDs
+    CPX_HIP(hipStreamWaitEvent(pre, dp.ev_a, 0));
+    CPX_HIP(hipEventRecord(dp.ev_a2, pre));
+  }
   tick("k_transcript_step1", 0, (double)B);
-  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256), (long)B <= opt_.transcript_excl_max);
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, pre, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256), excl);
   tock();
-  CPX_HIP(hipEventRecord(dp.ev_b, side));
+  CPX_HIP(hipEventRecord(dp.ev_b, pre));
+  if (pre != side) CPX_HIP(hipStreamWaitEvent(side, dp.ev_b, 0));
   {
     const int nt = 2 * Bi;
     // (R and S of a proof share the scalars vec_a: one wave per (proof, window) serves both, kernels.h launch_msm_endo_pairs)
@@ -521,9 +576,17 @@ void Engine::enqueue_prove_device() {
     tock();
     launch_finalize(side_.res.p, nt, d_pp_.p, side_.dst.p, nullptr, side);
   }
+  // table stream: the per-proof tables, then B_t and B_u (phase 1t) — nothing on the main stream needs a table before phase 2 (M's row)
+  // nor B_t, B_u before the SameMSM transcript step
+  hipStream_t const tabs = opt_.serial_streams ? stream_ : tab_.dstream;
+  if (tabs != stream_) CPX_HIP(hipStreamWaitEvent(tabs, pre != side ? dp.ev_a2 : dp.ev_a, 0));
+  if (pre != side) CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_a2, 0));
   tick("k_table_build", 0, (double)(B * NP));
-  launch_table_build(opt_, d_psrc_.p, NP, d_ptab_.p, Bi, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, stream_);
+  launch_table_build(opt_, d_psrc_.p, NP, d_ptab_.p, Bi, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, tabs);
   tock();
+  CPX_HIP(hipEventRecord(dp.ev_t1, tabs));
+  exec_plan(dp.p1t, dp.slotcomp.p, true);
+  CPX_HIP(hipEventRecord(dp.ev_t2, tabs));
   if (opt_.p1_split) {   // the randomness-only commitments beside the prefix, A behind it
     exec_plan(dp.p1, dp.slotcomp.p);
     CPX_HIP(hipEventRecord(dp.ev_c, stream_));
@@ -545,6 +608,7 @@ void Engine::enqueue_prove_device() {
   CPX_HIP(hipEventRecord(dp.ev_d, side));
   launch_ps_sameperm(d, Bi, stream_);
   // -- P2, P3
+  if (tabs != stream_) CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_t1, 0));   // M's table row
   exec_plan(dp.p2, dp.slotcomp.p);
   launch_ps_gprod(d, Bi, stream_);
   exec_plan(dp.p3, dp.slotcomp.p);
@@ -579,6 +643,7 @@ void Engine::enqueue_prove_device() {
   }
   // -- SameScalar, SameMSM step 1 (needs R, S and the T_2 commitments of the side stream)
   CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_d, 0));
+  if (tabs != stream_) CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_t2, 0));   // B_t, B_u in the slot registry
   launch_ps_smsm_setup(d, Bi, stream_);
   for (size_t j = 0; j < L; j++) {
     const int half = (int)(n >> (j + 1));
@@ -787,7 +852,7 @@ void Engine::verify_core_device(const uint8_t* proofs, const uint8_t* rand, size
   hipStream_t const side = opt_.serial_streams ? stream_ : side_.stream;
   CPX_HIP(hipStreamWaitEvent(side, dv.ev_a, 0));
   tick("k_transcript_step1", 0, (double)B);
-  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256), (long)B <= opt_.transcript_excl_max);
+  launch_transcript_step1(d_bytes_.p, d_mcomp_.p, Bi, (int)ell, d_tstate_.p, d_veca_.p, side, (long)B * 256 >= opt_.transcript_lane_min_batch * (long)std::max<size_t>(n, 256), (long)B <= opt_.transcript_excl_max && !opt_.serial_streams);
   tock();
   CPX_HIP(hipEventRecord(dv.ev_b, side));
   tick("k_decompress", 0, (double)(B * NPP));

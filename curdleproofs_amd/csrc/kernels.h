@@ -14,7 +14,7 @@ enum : uint32_t { MSM_SCALARS_CANONICAL = 1u };
 struct Options {
   // kernel selection (kernels.hip); *_max: largest launch that still takes the latency (wave / quad per item) form of a kernel
   long tail_wave_max = 256;
-  long tbw_min_waves = 2048;       // k_msm_tblw: smallest grid that still gets the widest window grouping
+  long tbw_min_waves = 1024;       // k_msm_tblw: smallest grid that still gets the widest window grouping (one wave per SIMD: 2048 cost 1-5 % between 128 and 384 proofs)
   long tbw_wpw = 0;                // 2|4|8|16|32 pins the windows per wave of k_msm_tblw (0 = by grid size)
   long tbw_lat_waves = 2048;
   long tbw_slices = 0;             // 1|2|4 pins the point slices of the bucket-list MSM (0 = by grid size)

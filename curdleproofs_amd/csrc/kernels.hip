@@ -1030,8 +1030,17 @@ __global__ __launch_bounds__(64) void k_compress_cols(const Aff* __restrict__ in
 // recode_smul_glv): a chain of 129 doublings with the non-adjacent forms of both halves instead of 257.
 constexpr int SMUL_THREADS = 64;   // single-wave groups: no whole-CU placement constraint beside the MSM waves of other contexts
 
+// EXCL (launches of at most 16 waves: the T_2 commitments of a small batch on the side stream): the wave claims the whole register file
+// of its SIMD — the 215-operation chain is not slowed by a neighbour and, more to the point, does not slow the waves of the main
+// stream's phase kernels that would otherwise share its SIMD for 3 ms (the slowest wave is the kernel: 605 instead of 302 us per
+// k_msm_fix of the first IPA rounds at 128 proofs).
+template <bool EXCL>
 __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (EXCL) {
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+  }
   TF* buf = reinterpret_cast<TF*>(smem);                                             // 2 * SMUL_THREADS field elements
   uint32_t* naf = reinterpret_cast<uint32_t*>(smem + 2 * SMUL_THREADS * sizeof(TF));  // [20][SMUL_THREADS]: nz / ng words of both halves
   const int tid = threadIdx.x;
@@ -1801,7 +1810,9 @@ void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
   const long total = (long)ntasks * cnt;
   if (total <= 0) return;
   const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 20 * SMUL_THREADS * sizeof(uint32_t);
-  CPX_LAUNCH(k_smul, dim3((unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS)), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
+  const unsigned groups = (unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS);
+  if (groups <= 16) CPX_LAUNCH(k_smul<true>, dim3(groups), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
+  else CPX_LAUNCH(k_smul<false>, dim3(groups), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
 }
 void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,
                        const uint32_t* d_src_offset) {

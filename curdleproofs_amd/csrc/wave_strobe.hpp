@@ -23,6 +23,7 @@
 // permutation.  Values the callers use (challenges, pos) are uniform over the wave.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "mont32.hpp"
 #include "strobe.hpp"
 
@@ -86,6 +87,69 @@ constexpr KeccakRC make_keccak_rc() {
   return t;
 }
 
+// Keccak-f[1600] on the wave's bit-interleaved state (layout and round structure: the header of this file).  `a`: this lane's half word
+// (empty lanes zero), lane = 0..63.  ONE out-of-line copy per code object, all 24 rounds unrolled with their constants as literals: a
+// kernel that hashes in a dozen places stays a few KB instead of 50-120 KB, and a round loads nothing.
+__device__ __noinline__ static uint32_t wave_keccak_f1600(uint32_t a, uint32_t lane) {
+  constexpr KeccakRC RC = make_keccak_rc();
+  // rotation offsets r[x + 5y] of rho
+  const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110;   // DPP row shifts: row_shl:n reads lane i + n, row_shr:n lane i - n (within 16 lanes)
+  auto lane_of_word = [](int word) { return word + (word >= 15 ? 1 : 0); };
+  auto dpp = [](uint32_t v, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, true); };   // out-of-row sources read as zero
+  const int l = (int)(lane & 31u), h = (int)((lane >> 5) & 1u);
+  const int w = l < 15 ? l : (l >= 16 && l <= 25 ? l - 1 : -1);
+  const bool live = w >= 0;
+  const int wc = live ? w : 0;   // empty lanes run along on word 0's indices (nobody reads them, they are cleared every round)
+  const int x = wc % 5, y = wc / 5;
+  // rho + pi as a gather: destination (X, Y) = (y, (2x + 3y) % 5)  <=>  source x = (X + 3Y) % 5, y = X
+  const int sx = (x + 3 * y) % 5, sy = x, rot = RHO[sx + 5 * sy];
+  // where a destination lane of half hh finds its bits for a 64-bit left rotation by r (0..63): source half and 32-bit amount
+  auto rot_plan = [](int r, int hh, int& src_half, int& amount) {
+    if ((r & 1) == 0) {
+      src_half = hh;
+      amount = r >> 1;
+    } else {
+      src_half = hh ^ 1;
+      amount = hh == 0 ? (r + 1) >> 1 : (r - 1) >> 1;
+    }
+  };
+  int half_a, amt_a, half_p, amt_p;
+  rot_plan(rot, h, half_a, amt_a);
+  rot_plan(rot + 1, h, half_p, amt_p);
+  // a column parity is the same in every plane of its half: take the neighbour columns from the source word's own plane
+  const int addr_a = 4 * (32 * half_a + lane_of_word(sx + 5 * sy));
+  const int addr_m = 4 * (32 * half_a + lane_of_word((sx + 4) % 5 + 5 * sy));
+  const int addr_p = 4 * (32 * half_p + lane_of_word((sx + 1) % 5 + 5 * sy));
+  const uint32_t sh_a = (uint32_t)(32 - amt_a) & 31u, sh_p = (uint32_t)(32 - amt_p) & 31u;   // v_alignbit amounts: (32 - left amount) & 31
+  const bool x_lt4 = x < 4, x_lt3 = x < 3;
+  // per-lane masks kept as opaque register values (the compiler would otherwise turn them back into selects on scalar masks, one
+  // more move each): word 0's lane of each half for iota, the lanes that hold a word
+  uint32_t iota_e = (w == 0 && h == 0) ? ~0u : 0u, iota_o = (w == 0 && h == 1) ? ~0u : 0u, live_m = live ? ~0u : 0u;
+  asm volatile("" : "+v"(iota_e), "+v"(iota_o), "+v"(live_m));
+  using std::integral_constant;
+  CPX_UNROLL for (int r = 0; r < 24; r++) {
+    const uint32_t ga = (uint32_t)__builtin_amdgcn_ds_bpermute(addr_a, (int)a);
+    uint32_t c = dpp(a, integral_constant<int, ROW_SHL + 5>{}) ^ dpp(a, integral_constant<int, ROW_SHL + 10>{}) ^ dpp(a, integral_constant<int, ROW_SHR + 5>{}) ^
+                 dpp(a, integral_constant<int, ROW_SHR + 10>{}) ^ a;
+    {   // c ^= the same lane of the other 16-lane row of the half: v_permlane16_swap_b32 swaps the odd rows of its first operand with the
+        // even rows of the second; with both = c the two results hold (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3)
+      const auto sw = __builtin_amdgcn_permlane16_swap(c, c, false, false);
+      c = sw[0] ^ sw[1];
+    }
+    const uint32_t gm = (uint32_t)__builtin_amdgcn_ds_bpermute(addr_m, (int)c), gp = (uint32_t)__builtin_amdgcn_ds_bpermute(addr_p, (int)c);
+    const uint32_t t = ga ^ gm;
+    const uint32_t b = __builtin_amdgcn_alignbit(t, t, sh_a) ^ __builtin_amdgcn_alignbit(gp, gp, sh_p);
+    // (both candidates are fetched by every lane, then one is picked: a DPP read inside a divergent branch would see disabled lanes)
+    const uint32_t b1_a = dpp(b, integral_constant<int, ROW_SHL + 1>{}), b1_b = dpp(b, integral_constant<int, ROW_SHR + 4>{});
+    const uint32_t b2_a = dpp(b, integral_constant<int, ROW_SHL + 2>{}), b2_b = dpp(b, integral_constant<int, ROW_SHR + 3>{});
+    const uint32_t b1 = x_lt4 ? b1_a : b1_b, b2 = x_lt3 ? b2_a : b2_b;   // (x + 1) % 5, (x + 2) % 5 of the same plane
+    const uint32_t rc = (RC.e[r] & iota_e) | (RC.o[r] & iota_o);
+    a = (b ^ (~b1 & b2) ^ rc) & live_m;   // the empty lanes are read by the parity shifts: keep them zero
+  }
+  return a;
+}
+
 struct WaveStrobe {
   uint32_t a;                 // this lane's half of a state word: its even bits (lanes 0..31) or odd bits (lanes 32..63); empty lanes keep 0
   uint32_t pos, pos_begin;    // uniform over the wave
@@ -122,43 +186,7 @@ struct WaveStrobe {
       amount = hh == 0 ? (r + 1) >> 1 : (r - 1) >> 1;
     }
   }
-  __device__ void keccak() {
-    static constexpr KeccakRC RC = make_keccak_rc();
-    // rotation offsets r[x + 5y] of rho
-    const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110;   // DPP row shifts: row_shl:n reads lane i + n, row_shr:n lane i - n (within 16 lanes)
-    const bool live = w >= 0;
-    const int wc = live ? w : 0;   // empty lanes run along on word 0's indices (nobody reads them, they are cleared every round)
-    const int x = wc % 5, y = wc / 5;
-    // rho + pi as a gather: destination (X, Y) = (y, (2x + 3y) % 5)  <=>  source x = (X + 3Y) % 5, y = X
-    const int sx = (x + 3 * y) % 5, sy = x, rot = RHO[sx + 5 * sy];
-    int half_a, amt_a, half_p, amt_p;
-    rot_plan(rot, h, half_a, amt_a);
-    rot_plan(rot + 1, h, half_p, amt_p);
-    // a column parity is the same in every plane of its half: take the neighbour columns from the source word's own plane
-    const int addr_a = 4 * (32 * half_a + lane_of_word(sx + 5 * sy));
-    const int addr_m = 4 * (32 * half_a + lane_of_word((sx + 4) % 5 + 5 * sy));
-    const int addr_p = 4 * (32 * half_p + lane_of_word((sx + 1) % 5 + 5 * sy));
-    const uint32_t sh_a = (uint32_t)(32 - amt_a) & 31u, sh_p = (uint32_t)(32 - amt_p) & 31u;
-    const bool x_lt4 = x < 4, x_lt3 = x < 3;
-    // per-lane masks kept as opaque register values (the compiler would otherwise turn them back into selects on scalar masks, one
-    // more move each): word 0's lane of each half for iota, the lanes that hold a word
-    uint32_t iota_e = (w == 0 && h == 0) ? ~0u : 0u, iota_o = (w == 0 && h == 1) ? ~0u : 0u, live_m = live ? ~0u : 0u;
-    asm volatile("" : "+v"(iota_e), "+v"(iota_o), "+v"(live_m));
-    for (int r = 0; r < 24; r++) {
-      const uint32_t ga = gather(addr_a, a);
-      uint32_t c = (dpp<ROW_SHL + 5>(a) ^ dpp<ROW_SHL + 10>(a)) ^ (dpp<ROW_SHR + 5>(a) ^ dpp<ROW_SHR + 10>(a)) ^ a;   // (two short chains, not one of five)
-      c = rows_xor(c);
-      const uint32_t gm = gather(addr_m, c), gp = gather(addr_p, c);
-      const uint32_t b = rotr_by(ga ^ gm, sh_a) ^ rotr_by(gp, sh_p);
-      // (both candidates are fetched by every lane, then one is picked: a DPP read inside a divergent branch would see disabled lanes)
-      const uint32_t b1_a = dpp<ROW_SHL + 1>(b), b1_b = dpp<ROW_SHR + 4>(b), b2_a = dpp<ROW_SHL + 2>(b), b2_b = dpp<ROW_SHR + 3>(b);
-      const uint32_t b1 = x_lt4 ? b1_a : b1_b, b2 = x_lt3 ? b2_a : b2_b;   // (x + 1) % 5, (x + 2) % 5 of the same plane
-      const uint32_t rc = (RC.e[r] & iota_e) | (RC.o[r] & iota_o);   // (uniform loads, per-lane masks)
-      const uint32_t n = b ^ (~b1 & b2) ^ rc;
-      a = n & live_m;   // the empty lanes are read by the parity shifts: keep them zero
-    }
-  }
+  __device__ __forceinline__ void keccak() { a = wave_keccak_f1600(a, (uint32_t)(32 * h + l)); }
   // state byte i ^= b (i, b uniform): the even (lower half) or odd (upper half) bits of the byte, four of them, at bit 4 (i % 8)
   __device__ __forceinline__ void xor_byte(uint32_t i, uint8_t b) {
     if ((int)(i >> 3) == w) {

@@ -545,6 +545,10 @@ VARIANTS = {
     "lane_per_transcript_prefix": {"transcript_lane_min_batch": 1, "device_min_batch": 1},   # k_transcript_step1_lane: one lane per proof hashes the instance
     "phase1_in_one_piece": {"p1_split": 0, "device_min_batch": 1},   # A inside phase 1 (default: phase 1 without A before the transcript prefix is awaited, A behind it)
     "rs_as_two_tasks": {"rs_pairs": 0, "device_min_batch": 1},     # R = <a, vec_R>, S = <a, vec_S> as separate tasks (default: one wave serves both)
+    # the wave-per-transcript prefix without SIMDs of its own (default up to 256 proofs: k_transcript_step1<true> on a high-priority stream)
+    "prefix_shares_its_simds": {"transcript_excl_max": 0, "device_min_batch": 1},
+    # every stream's work in line on the main stream (measurement aid of bench.py): table stream, side stream, prefix stream
+    "serial_streams_device_resident": {"serial_streams": 1, "device_min_batch": 1},
 }
 
 

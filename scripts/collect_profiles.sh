@@ -40,4 +40,9 @@ for m in ${MICRO:-}; do   # MICRO="quad_micro lat_micro place_micro keccak_micro
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I curdleproofs_amd/csrc scripts/micro/$m.hip -o /tmp/$m > /dev/null 2>&1 && timeout 120 /tmp/$m > $O/${RND}_$m.txt 2>&1
 done
 python scripts/shape_sweep.py 128 2>&1 | tail -1 > $O/${RND}_shape_128.txt
+CPX_TRANSCRIPT_EXCL_MAX=0 python scripts/shape_sweep.py 128 2>&1 | tail -1 >> $O/${RND}_shape_128.txt   # A/B: the prefix sharing its SIMDs
+python scripts/shape_sweep.py 256 2>&1 | tail -1 >> $O/${RND}_shape_128.txt
+python scripts/shape_sweep.py 1024 2>&1 | tail -1 >> $O/${RND}_shape_128.txt
+# kernel timeline of one 128-proof pass (what the chain consists of, launch by launch)
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl128 -- python $R/scripts/batch_timeline.py run 128 > /dev/null 2>&1; python $R/scripts/batch_timeline.py report /tmp/tl128 > $O/${RND}_batch128_timeline.txt 2>&1 )
 cut -c1-300 $O/${RND}_bench.json; head -3 $O/${RND}_gpu_busy.txt

@@ -26,7 +26,7 @@ struct Options {
   long decompress_quad_max = 2048;
   // host engine (engine.cpp)
   long fix_bits = 16;              // radix of the fixed-base CRS table of multiples: 16 (17.5 GB at ell = 252), 8 (0.1 GB) or 19 (14 windows, 122 GB); read by set_crs
-  long device_min_batch = 96;      // batches of at least this many proofs run the whole protocol on the device
+  long device_min_batch = 56;      // batches of at least this many proofs run the whole protocol on the device (ell = 252: host-driven 22.1 / 25.5 ms per pass at 48 / 64 proofs, device-resident 23.0 / 24.4)
   long spin_team = 1;              // 0: no spinning helper threads for small batches
   long spin_team_threads = 8;
   long inline_below = 16;          // host loops shorter than this run inline

@@ -379,7 +379,7 @@ def test_prove_verify_ell60(ctx, orc):
 
 def test_prove_verify_batch40_ell28(ctx, orc):
     # 40 independent instances (BASELINE config 4 recipe: instance i from StdRng(i)): large enough for the engine's
-    # batch paths (host-driven protocol on the spin team below 96 proofs, multi-chunk host loops; the device-resident form of this
+    # batch paths (host-driven protocol on the spin team below 56 proofs, multi-chunk host loops; the device-resident form of this
     # test runs in test_engine_variants_stay_bit_exact); every proof must equal
     # the oracle's bytes and verify
     _prove_and_check(ctx, orc, 28, list(range(100, 140)))
@@ -564,7 +564,7 @@ def _variant_checks(c, orc, whisk_kat, oracle_vectors):
 
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_engine_variants_stay_bit_exact(name, orc, whisk_kat, oracle_vectors):
-    # the 8-bit fixed-base table, the device-resident protocol (step kernels of protocol.hip; normally used from 96 proofs per
+    # the 8-bit fixed-base table, the device-resident protocol (step kernels of protocol.hip; normally used from 56 proofs per
     # batch on) forced on single proofs, the host-driven protocol forced on a batch of 40, and the throughput instantiations
     # of the MSM / reduction / finalisation kernels, the point slices of the bucket-list MSM (msm_tblw_slices: by default only
     # tasks of >= 512 points of a lone proof are sliced) and the latency kernels forced onto every batch size
@@ -1124,7 +1124,7 @@ def test_configs_4_and_5_in_process_over_the_visible_devices(orc, ndev):
     import curdleproofs_amd as cpx
     if cpx.device_count() < ndev:
         pytest.skip("needs %d GPUs, %d visible" % (ndev, cpx.device_count()))
-    ell, per_dev = 28, 100   # >= 96 proofs per device: the device-resident protocol
+    ell, per_dev = 28, 100   # >= 56 proofs per device: the device-resident protocol
     crs, shares = _multi_device_shares(orc, ell, 4, ndev)
     shares = [[sh[i % len(sh)] for i in range(per_dev)] for sh in shares]
     partials, partials_bad, errors = [None] * ndev, [None] * ndev, []

@@ -4,9 +4,9 @@
 // the lower half hold the EVEN bits of one 64-bit state word each, the same lanes of the upper half (lane + 32) its ODD bits.  In
 // that form a 64-bit rotation is two independent 32-bit rotations (by r/2 on both halves for an even r; for an odd r the halves
 // change places and rotate by (r+1)/2 and (r-1)/2), every bitwise step is one 32-bit operation per lane, and nothing is computed
-// twice: 30 vector instructions per round against the 75 of the form this file held until round 4 (32 lanes per transcript, a
-// 64-bit word = two registers per lane, both halves of a wave running identical copies: 4.8 us per permutation; this form:
-// see profiles/r04_keccak_micro.txt).
+// twice: 27 vector instructions per round against the 75 of the form this file held until round 4 (32 lanes per transcript, a
+// 64-bit word = two registers per lane, both halves of a wave running identical copies: 4.8 us per permutation; this form: 2.4 us,
+// profiles/r04_keccak_micro.txt).
 //
 // Word x + 5 y sits in lane 5 y + x (+ 1 for y >= 3) of its half: lane 15 stays empty so that no plane (the five words of one y)
 // straddles the two 16-lane DPP rows of a half.  A round:

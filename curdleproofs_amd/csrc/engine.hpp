@@ -223,6 +223,7 @@ class Engine {
   void set_crs_impl(size_t ell, const uint8_t* points);
   hipStream_t create_masked_stream(bool upper);
   hipStream_t prefix_stream();
+  bool table_stream_on() const;
   const Aff& generator();
   void compress_affine(const Aff* pts, size_t n, uint8_t* out);
   bool unzip_trackers(const uint8_t* trackers, size_t n, std::vector<Aff>& vec_r, std::vector<Aff>& vec_s);

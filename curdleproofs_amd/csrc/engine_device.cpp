@@ -99,7 +99,7 @@ void Engine::exec_plan(const TblPlan& pl, uint8_t* d_comp_registry, bool on_tabl
   if (!pl.nt) return;
   // (a plan on the table stream works in the table stream's own scratch, sized by prepare_device_prover: it runs beside the plans
   // of the main stream)
-  const bool tl = on_table_stream && !opt_.serial_streams;
+  const bool tl = on_table_stream && table_stream_on();
   hipStream_t const st = tl ? tab_.dstream : stream_;
   if (!tl) {
     d_tpart_.ensure(std::max<size_t>(pl.nparts, 1));
@@ -510,6 +510,9 @@ void Engine::prepare_device_prover() {
   dp.signature = sig;
 }
 
+// Whether the loaded batch runs its table build and phase 1t on the table stream (option table_stream_max, stated for n <= 256)
+bool Engine::table_stream_on() const { return !opt_.serial_streams && (long)(B_ * std::max<size_t>(n_, 256)) <= opt_.table_stream_max * 256L; }
+
 // The high-priority stream of a small batch's transcript prefix (created on first use; a plain stream where priorities are not offered)
 hipStream_t Engine::prefix_stream() {
   if (!side_.hi_stream) {
@@ -578,7 +581,7 @@ void Engine::enqueue_prove_device() {
   }
   // table stream: the per-proof tables, then B_t and B_u (phase 1t) — nothing on the main stream needs a table before phase 2 (M's row)
   // nor B_t, B_u before the SameMSM transcript step
-  hipStream_t const tabs = opt_.serial_streams ? stream_ : tab_.dstream;
+  hipStream_t const tabs = table_stream_on() ? tab_.dstream : stream_;
   if (tabs != stream_) CPX_HIP(hipStreamWaitEvent(tabs, pre != side ? dp.ev_a2 : dp.ev_a, 0));
   if (pre != side) CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_a2, 0));
   tick("k_table_build", 0, (double)(B * NP));

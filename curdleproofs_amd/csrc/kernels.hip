@@ -1549,7 +1549,7 @@ const OptField kOptFields[] = {
     {"p1_split", &Options::p1_split, 0, 1},                      {"transcript_lane_min_batch", &Options::transcript_lane_min_batch, 1, 1L << 30},
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
-    {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30},
+    {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;

@@ -1215,6 +1215,61 @@ def test_four_contexts_switching_crs_concurrently_stay_bit_exact(orc):
     assert not errors, errors
 
 
+def test_small_batch_beside_a_gpu_filling_batch_on_another_context(orc):
+    """The prefix and the T_2 scalar multiplications of a batch of <= 256 proofs run in waves that claim a whole SIMD
+    (k_transcript_step1<true>, k_smul<true>): such a wave is only placed on a SIMD with no resident wave.  Beside ANOTHER context that
+    keeps the GPU full the small batch must still make progress (its work-groups get in whenever SIMDs drain) and stay bit-exact: one
+    thread proves / verifies 4096-proof batches in a loop while a second one runs 128-proof passes on its own context, every proof
+    and verdict of both against the oracle.  A hang here is a failure (pytest-timeout / the driver's limit)."""
+    import threading
+    import time
+    import curdleproofs_amd as cpx
+    ell = 28
+    pts = orc.generate_crs_points(ell)
+    base = [orc.make_instance(ell, 900 + s, pts) for s in range(4)]
+    errors, stop, small_passes = [], threading.Event(), []
+
+    def run(nb, passes, tag):
+        try:
+            insts = [base[i % 4] for i in range(nb)]
+            cat = lambda k_: b"".join(i[k_] for i in insts)
+            c = cpx.Context(0)
+            c.set_crs(ell, pts)
+            c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+            perm = [x for i in insts for x in i["permutation"]]
+            args = (perm, cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+            n = 0
+            while (passes is None and not stop.is_set()) or (passes is not None and n < passes):
+                t0 = time.perf_counter()
+                proofs = c.prove_batch(*args)
+                if [p == i["proof"] for p, i in zip(proofs, insts)] != [True] * nb:
+                    errors.append("%s: proof bytes differ from the oracle's" % tag)
+                bad = list(proofs)
+                bad[5] = proofs[6]
+                got = c.verify_batch(bad, cat("verifier_rand"))
+                if got != [cpx.CPX_OK] * 5 + [cpx.CPX_ERR_VERIFY] + [cpx.CPX_OK] * (nb - 6):
+                    errors.append("%s: verdicts %s" % (tag, [j for j, v in enumerate(got) if v != cpx.CPX_OK]))
+                if passes is not None:
+                    small_passes.append(time.perf_counter() - t0)
+                n += 1
+            c.close()
+        except Exception as e:
+            errors.append("%s: %r" % (tag, e))
+
+    big = threading.Thread(target=run, args=(4096, None, "4096-proof context"))
+    big.start()
+    time.sleep(1.0)   # the large context is in its loop
+    small = threading.Thread(target=run, args=(128, 12, "128-proof context"))
+    small.start()
+    small.join(timeout=600)
+    hung = small.is_alive()
+    stop.set()
+    big.join(timeout=600)
+    assert not hung and not big.is_alive(), "a context did not finish"
+    assert not errors, errors
+    assert len(small_passes) == 12
+
+
 @pytest.mark.parametrize("fused", [False, True], ids=["prove_verify", "config5_fused_verify"])
 def test_bench_two_ranks_on_one_gpu(fused):
     """`python bench.py --gpus 2` end to end on real hardware: bench.py starts its two ranks itself (torch.distributed.run), both

@@ -84,6 +84,11 @@ void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std:
     pl.pts_fix += (f0 ? r.seg0.n : 0) + (f1 ? r.seg1.n : 0);
     pl.pts_tbl += (f0 ? 0 : r.seg0.n) + (f1 ? 0 : r.seg1.n);
   }
+  // Long tasks first: a work-group's task is its index in these arrays, partial-sum slots travel with the task (out_first / pad).  With the
+  // requests in protocol order a launch ended with the long waves of the last proofs and the GPU drained behind them (~0.8 ms of a
+  // 7.6-ms k_msm_fix launch at 8192 proofs); now the one-point tasks fill the tail.
+  std::stable_sort(hf.begin(), hf.end(), [](const FixTask& a, const FixTask& b) { return a.n > b.n; });
+  std::stable_sort(ht.begin(), ht.end(), [](const TblTask& a, const TblTask& b) { return a.seg[0].n + a.seg[1].n > b.seg[0].n + b.seg[1].n; });
   pl.nparts = nparts;
   pl.fix_sets = nft * fix_parts;
   pl.tbl_sets = ntt * tbl_parts;

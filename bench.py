@@ -56,26 +56,52 @@ def synth_batch(ctx, ell, B, seed):
                 k=k_wire, mbl=b"".join(mbl), prand=pr.random_fr_wire(rng, B * (3 * n + 9)), vrand=pr.random_fr_wire(rng, B * 8))
 
 
-def cpu_baseline(ell, data, gpu_proof0, budget_s=12.0):
-    """Times the CPU oracle ('port' of the reference's algorithm) on instance 0, single thread."""
-    from tests.oracle_lib import Oracle
+def _instance(data, ell, i):
+    """instance i of the synthetic batch in the oracle's argument form"""
     import curdleproofs_amd as cpx
-    orc = Oracle()
     n = ell + 4
     AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
-    inst = dict(ell=ell, vec_R=data["vec_R"][:ell * AFF], vec_S=data["vec_S"][:ell * AFF], vec_T=data["vec_T"][:ell * AFF],
-                vec_U=data["vec_U"][:ell * AFF], M=data["M"][:JAC], permutation=data["perms"][:ell], k=data["k"][:FR],
-                vec_m_blinders=data["mbl"][:4 * FR], prover_rand=data["prand"][:(3 * n + 9) * FR], verifier_rand=data["vrand"][:8 * FR])
-    proof = orc.prove(ell, data["crs"], inst["vec_R"], inst["vec_S"], inst["vec_T"], inst["vec_U"], inst["M"], inst["permutation"],
-                      inst["k"], inst["vec_m_blinders"], inst["prover_rand"])
-    parity = gpu_proof0 is None or proof == gpu_proof0
-    ok, tp, tv = orc.time_prove_verify(inst, data["crs"], 1)
-    reps = max(1, min(30, int(budget_s / max(tp + tv, 1e-3))))
-    ok, tp, tv = orc.time_prove_verify(inst, data["crs"], reps)
-    return dict(value=reps / (tp + tv), unit="proofs/s", cores=1, kind="port",
+    cut = lambda key, unit: data[key][i * unit:(i + 1) * unit]
+    return dict(ell=ell, vec_R=cut("vec_R", ell * AFF), vec_S=cut("vec_S", ell * AFF), vec_T=cut("vec_T", ell * AFF), vec_U=cut("vec_U", ell * AFF), M=cut("M", JAC),
+                permutation=data["perms"][i * ell:(i + 1) * ell], k=cut("k", FR), vec_m_blinders=cut("mbl", 4 * FR), prover_rand=cut("prand", (3 * n + 9) * FR),
+                verifier_rand=cut("vrand", 8 * FR))
+
+
+def cpu_baseline(ell, data, gpu_proofs, budget_s=12.0, sample=8):
+    """Times the CPU oracle ('port' of the reference's algorithm) on instance 0, single thread: the build with the Montgomery product of
+    ark-ff's `asm` feature (mulx / adcx / adox, oracle/Makefile FASTFLAGS) where the host CPU has BMI2 + ADX — `value` — and the portable
+    x86-64-v2 build beside it.  gpu_proofs (the timed region's proofs of context 0, or None): a sample of `sample` of them spread over the
+    batch is compared with the oracle's bytes."""
+    from tests.oracle_lib import Oracle, fast_build_runs_here, oracle_build_flags
+    psz = 48 * (18 + 10 * ((ell + 4).bit_length() - 1)) + 7 * 32
+    builds = [("portable", Oracle())]
+    if fast_build_runs_here():
+        builds.append(("mulx_adx", Oracle(fast=True)))
+    inst = _instance(data, ell, 0)
+    res = {}
+    for name, orc in builds:
+        ok, tp, tv = orc.time_prove_verify(inst, data["crs"], 1)
+        reps = max(1, min(30, int(budget_s / len(builds) / max(tp + tv, 1e-3))))
+        ok, tp, tv = orc.time_prove_verify(inst, data["crs"], reps)
+        res[name] = dict(value=reps / (tp + tv), prove_s=tp / reps, verify_s=tv / reps, reps=reps, accepted=bool(ok), build_flags=oracle_build_flags(fast=orc.fast))
+    best_name, orc = builds[-1]
+    checked, parity = [], True
+    if gpu_proofs is not None:
+        gpu_proofs = bytes(gpu_proofs)
+        nb = len(gpu_proofs) // psz
+        checked = sorted(set(int(round(j * (nb - 1) / max(1, sample - 1))) for j in range(min(sample, nb))))
+        for i in checked:
+            it = _instance(data, ell, i)
+            want = orc.prove(ell, data["crs"], it["vec_R"], it["vec_S"], it["vec_T"], it["vec_U"], it["M"], it["permutation"], it["k"], it["vec_m_blinders"], it["prover_rand"])
+            parity &= bytes(gpu_proofs[i * psz:(i + 1) * psz]) == want
+    b = res[best_name]
+    return dict(value=b["value"], unit="proofs/s", cores=1, kind="port", build=best_name, build_flags=b["build_flags"],
                 sample="%d x (CurdleproofsProof::new + verify) of instance 0 of the bench batch at ell=%d, oracle/ single thread "
-                       "(prove %.3f s, verify %.3f s each)" % (reps, ell, tp / reps, tv / reps),
-                prove_s=tp / reps, verify_s=tv / reps, accepted=bool(ok), gpu_proof_bit_exact=bool(parity))
+                       "(prove %.3f s, verify %.3f s each)" % (b["reps"], ell, b["prove_s"], b["verify_s"]),
+                prove_s=b["prove_s"], verify_s=b["verify_s"], accepted=all(r["accepted"] for r in res.values()), by_build=res,
+                gpu_proof_bit_exact=bool(parity), gpu_proofs_compared=checked,
+                note="value = the faster build (ark-ff's asm-feature product where the host has BMI2 + ADX); by_build.portable = x86-64-v2 with unsigned __int128 products "
+                     "(what rounds 1-4 reported)")
 
 
 def effective_cores():
@@ -111,14 +137,9 @@ def cpu_baseline_all_cores(ell, data, budget_s=10.0):
     (the embarrassingly parallel form of BASELINE configs[3]; the oracle is a C library behind ctypes, so Python threads run it in
     parallel).  Returns proofs/s over all threads."""
     import threading
-    from tests.oracle_lib import Oracle
-    import curdleproofs_amd as cpx
-    orc = Oracle()
-    n = ell + 4
-    AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
-    inst = dict(ell=ell, vec_R=data["vec_R"][:ell * AFF], vec_S=data["vec_S"][:ell * AFF], vec_T=data["vec_T"][:ell * AFF],
-                vec_U=data["vec_U"][:ell * AFF], M=data["M"][:JAC], permutation=data["perms"][:ell], k=data["k"][:FR],
-                vec_m_blinders=data["mbl"][:4 * FR], prover_rand=data["prand"][:(3 * n + 9) * FR], verifier_rand=data["vrand"][:8 * FR])
+    from tests.oracle_lib import Oracle, fast_build_runs_here, oracle_build_flags
+    orc = Oracle(fast=fast_build_runs_here())
+    inst = _instance(data, ell, 0)
     cores = effective_cores()
     ok, tp, tv = orc.time_prove_verify(inst, data["crs"], 1)
     reps = max(1, int(budget_s / max(tp + tv, 1e-3) / 1.5))
@@ -140,7 +161,7 @@ def cpu_baseline_all_cores(ell, data, budget_s=10.0):
             model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except Exception:
         pass
-    return dict(value=sum(done) / dt, unit="proofs/s", cores=cores, logical_cpus=os.cpu_count(), kind="port", cpu_model=model,
+    return dict(value=sum(done) / dt, unit="proofs/s", cores=cores, logical_cpus=os.cpu_count(), kind="port", cpu_model=model, build_flags=oracle_build_flags(fast=orc.fast),
                 sample="%d threads x %d x (CurdleproofsProof::new + verify) of instance 0 at ell=%d, oracle/ (one independent proof per thread), %.1f s wall"
                        % (cores, reps, ell, dt))
 
@@ -609,7 +630,8 @@ def main():
                    config=dict(workload="ell=%d (n=%d, log2 n=%d): %d independent shuffle instances per GPU per step, each proven "
                                         "(CurdleproofsProof::new) then verified; BASELINE configs[1] instance shape, per-GPU share "
                                         "of configs[3]" % (ell, n, L, B),
-                               ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads, parallelism="proofs sharded over %d GPU(s), no collective" % world),
+                               ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads,
+                               fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), parallelism="proofs sharded over %d GPU(s), no collective" % world),
                    all_verified=all_ok, algorithmic_bytes_per_proof=b_prove + b_verify,
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
@@ -618,8 +640,6 @@ def main():
         # literal BASELINE shapes, the batched verifier, the other proof sizes and the CPU baseline belong to every line.
         AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
         c0, n_ = ctxs[0], ell + 4
-        psz_bench = c0.proof_size
-        proof0 = bytes(proofs[0])[:psz_bench]
         if not args.no_extra_shapes:
             # BASELINE configs[4] (the batched verifier), driver-visible: context 0 still holds its share of the timed batch and the proofs
             # of the last pass; ONE accumulated check over all of them, verdict included (cpx_batch_verify_fused + cpx_g1_sum_jac; with
@@ -663,7 +683,7 @@ def main():
                 out["ell_508"] = other_ell(c0, 508, 4096, 5081, "the reference's in-tree criterion bench shape (benches/perf.rs:29, N = 512)")
                 out["ell_1020"] = other_ell(c0, 1020, 2048, 4321, "BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput")
         if not args.no_cpu_baseline:   # the CPU oracle beside the GPU number in the same run, on rank 0 at every N
-            out["cpu_baseline"] = cpu_baseline(ell, data, proof0)
+            out["cpu_baseline"] = cpu_baseline(ell, data, proofs[0])   # (+ a sample of 8 proofs of context 0's last pass against the oracle's bytes)
             if "config5" in out:
                 vs = out["cpu_baseline"]["verify_s"]
                 out["config5"]["cpu_verify_per_proof"] = dict(value=1.0 / vs, unit="proofs/s", cores=1, kind="port",

@@ -77,9 +77,19 @@ def generate_random_points(ctx, num_points, seed):
     smaller y) times the cofactor, provided it lies in the subgroup.  Returns (num_points affine points of 96 bytes, increments
     consumed).  The hashing is host work (hashlib); square roots, cofactor multiplication and the subgroup test run on the
     GPU in batches of candidates through the C-ABI: cpx_g1_decompress_status, cpx_g1_scale, cpx_g1_normalize."""
-    import hashlib
     seed = seed.encode() if isinstance(seed, str) else bytes(seed)
-    h_wire = whisk.pr.fr_to_wire(COFACTOR)          # the cofactor as a scalar (< r): cpx_g1_scale's plain double-and-add holds on all of E(Fp)
+    h_wire = whisk.pr.fr_to_wire(COFACTOR)          # the cofactor as a scalar (< r)
+    # The candidates are points of E(Fp), not of the order-r subgroup: cpx_g1_scale's default form splits the scalar by the G1 endomorphism,
+    # an identity of the subgroup only.  Option scale_any_point selects the plain 257-step double-and-add, which holds on all of E(Fp).
+    ctx.set_option("scale_any_point", 1)
+    try:
+        return _generate_random_points(ctx, num_points, seed, h_wire)
+    finally:
+        ctx.set_option("scale_any_point", 0)
+
+
+def _generate_random_points(ctx, num_points, seed, h_wire):
+    import hashlib
     points, increment = [], 0
     while len(points) < num_points:
         batch = max(16, 2 * (num_points - len(points)) + 8)      # about half of the candidates have a square root

@@ -667,7 +667,7 @@ void Engine::fold(uint8_t* PL, const uint8_t* PR, const uint8_t* gamma, size_t h
   CPX_HIP(hipMemcpyAsync(dl.p, PL, half * sizeof(Aff), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(dr.p, PR, half * sizeof(Aff), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(dg.p, gamma, sizeof(Fr), hipMemcpyHostToDevice, stream_));
-  SmulTask t{dl.p, dr.p, dl.p, dg.p, 0, 0};
+  SmulTask t{dl.p, dr.p, dl.p, dg.p, 0, opt_.scale_any_point ? SMUL_PLAIN : 0u};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
   tick("k_smul", 288.0 * half, (double)half);
   launch_smul(dt.p, 1, (int)half, stream_);
@@ -689,7 +689,7 @@ void Engine::scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_strid
   dt.ensure(1);
   CPX_HIP(hipMemcpyAsync(dp.p, P, n * sizeof(Aff), hipMemcpyHostToDevice, stream_));
   CPX_HIP(hipMemcpyAsync(dsc.p, scalars, ns * sizeof(Fr), hipMemcpyHostToDevice, stream_));
-  SmulTask t{nullptr, dp.p, dout.p, dsc.p, scalar_stride ? 1u : 0u, 0};
+  SmulTask t{nullptr, dp.p, dout.p, dsc.p, scalar_stride ? 1u : 0u, opt_.scale_any_point ? SMUL_PLAIN : 0u};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
   tick("k_smul", 224.0 * n, (double)n);
   launch_smul(dt.p, 1, (int)n, stream_);

@@ -236,6 +236,7 @@ class Engine {
     int fix_wpw = 16, tbl_wpw = 32;
     double pts_fix = 0, pts_tbl = 0;
     bool any_add = false;
+    bool table_stream = false;   // runs beside the main stream's plans (phase 1t): its own write-only dummy slot
     DevBuf<TblTask> ttasks;
     DevBuf<FixTask> ftasks;
     DevBuf<uint32_t> meta;   // first partial | partial count | affine destination | compressed-bytes slot | addends[3], per request

@@ -1,6 +1,6 @@
 // Device-resident batch prover / verifier of the engine — product code (see engine.hpp, protocol.h).
 //
-// For batches of >= 96 proofs (CPX_DEVICE_MIN_BATCH) the whole protocol runs on the GPU: the MSM phases read their
+// For batches of >= 56 proofs (option device_min_batch) the whole protocol runs on the GPU: the MSM phases read their
 // scalars from device memory through task descriptors that are built ONCE per loaded batch shape ("plans"), the
 // finalisation kernels leave the compressed results in a per-proof slot registry, and one-wave-per-proof step kernels
 // (protocol.hip) hash them into the transcripts and derive the next phase's scalars.  The host only enqueues: no
@@ -42,7 +42,9 @@ void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std:
   std::vector<TblTask> ht(ntt);
   std::vector<FixTask> hf(nft);
   std::vector<uint32_t> meta(7 * nt);   // pfirst | pcount | dst | comp_index | addends[3]
-  const uint32_t dummy_dst = slot_index(0, SlotMap(L_).TMP(7));
+  // requests without a destination scatter their affine point to a write-only slot of proof 0 that NOTHING ever reads: TMP(7) for plans of the
+  // main stream, TMP(5) for the plan that runs beside them on the table stream (phase 1t) — two streams never write the same slot
+  const uint32_t dummy_dst = slot_index(0, SlotMap(L_).TMP(pl.table_stream ? 5 : 7));
   const TblSeg none{nullptr, nullptr, 0, 0};
   size_t it = 0, jf = 0, nparts = 0;
   pl.pts_fix = pl.pts_tbl = 0;
@@ -255,7 +257,7 @@ void Engine::prepare_device_prover() {
     CPX_HIP(hipMemcpy(dp.mdst.p, md.data(), B * 4, hipMemcpyHostToDevice));
   }
   // -- phase 1: everything that depends only on vec_a and the prover's randomness (curdleproofs.rs:93,110-116,
-  //    same_multiscalar_argument.rs:80-82, inner_product_argument.rs:126, same_scalar_argument.rs:60-61).
+  //    same_multiscalar_argument.rs:80 (B_a; B_t and B_u are phase 1t), inner_product_argument.rs:126, same_scalar_argument.rs:60-61).
   for (size_t p = 0; p < B; p++) {
     const int TMPX = sm.TMP(6);   // compressed bytes nobody reads
     if (!opt_.p1_split) {
@@ -292,6 +294,7 @@ void Engine::prepare_device_prover() {
     reqs.push_back(req(pseg(p, O_U, (uint32_t)n), none, rnd(p, ri.VR())));
     ci.push_back(cidx(p, sm.BU()));
   }
+  dp.p1t.table_stream = true;
   build_plan(dp.p1t, reqs, ci);
   tab_.raw.ensure(std::max<size_t>(dp.p1t.fix_sets + dp.p1t.tbl_sets, 1) * raw_set_words());
   tab_.rawslot.ensure(std::max<size_t>(dp.p1t.fix_sets + dp.p1t.tbl_sets, 1));
@@ -501,6 +504,7 @@ void Engine::prepare_device_prover() {
     };
     upd(dp.p1);
     upd(dp.p1b);
+    upd(dp.p1t);   // (in line on the main stream when the table stream is off: large batches, serial_streams)
     upd(dp.p2);
     upd(dp.p3);
     for (auto& pl : dp.ipa)
@@ -610,7 +614,7 @@ void Engine::enqueue_prove_device() {
   }
   CPX_HIP(hipStreamWaitEvent(side, dp.ev_c, 0));
   tick("k_smul", 0, (double)(4 * B));
-  launch_smul(side_.stasks.p, 4 * Bi, 1, side);
+  launch_smul(side_.stasks.p, 4 * Bi, 1, side, /*exclusive_simd=*/side != stream_);   // (a small batch: at most 16 waves, each on a SIMD of its own)
   tock();
   launch_compress_cols(d_pp_.p + 4 * ell, dp.side_cols, 6, (int)pp_stride_, Bi, dp.slotcomp.p, (int)NS, side);
   CPX_HIP(hipEventRecord(dp.ev_d, side));

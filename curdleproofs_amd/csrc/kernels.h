@@ -6,7 +6,13 @@
 
 namespace cpx {
 
-enum : uint32_t { MSM_SCALARS_CANONICAL = 1u };
+enum : uint32_t {
+  MSM_SCALARS_CANONICAL = 1u,
+  // SmulTask::flags: multiply by the plain non-adjacent form of the 255-bit scalar (257 doublings) instead of the endomorphism split.  The split
+  // k P = t P + q (-phi(P)) is an identity of the order-r subgroup only; points of E(Fp) outside it (the cofactor multiplication of a
+  // hash-to-curve CRS, tests/crs.rs:38) need this form.
+  SMUL_PLAIN = 2u
+};
 
 // Tunables of the launchers and of the host engine.  They belong to an engine context (cpx_ctx_set_option, include/cpx.h): two
 // contexts of one process may run different settings.  The environment (CPX_<NAME>) only provides the defaults a new context
@@ -42,6 +48,7 @@ struct Options {
   long p1_split = 1;               // 1: phase 1 without A (it only needs the prover's randomness) runs before the main stream waits for the transcript prefix, A alone behind it: 128 proofs 41.7 -> 40.6 ms per pass, nothing at 8192
   long serial_streams = 0;         // 1 (measurement aid): the side stream's kernels run in line on the main stream — every kernel's duration is its own
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
+  long scale_any_point = 0;        // 1: cpx_g1_scale / cpx_g1_fold take ANY point of E(Fp) (plain 257-step double-and-add, SMUL_PLAIN); 0: points of the order-r subgroup (endomorphism split, 129 steps)
 };
 const Options& default_options();                               // built-in defaults overridden by CPX_<NAME> environment variables
 bool set_option(Options& o, const char* key, long value);       // false: unknown key or value out of range
@@ -179,7 +186,8 @@ void launch_finalize(const Jac* d_in, int n, Aff* d_aff, const uint32_t* d_dst_i
 void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_out, hipStream_t s, int out_stride = 0);   // out_stride (points per output row), 0 = dense
 // `batch` strided rows; only the columns d_cols[0..ncols) are compressed, each to the same column of the output row
 void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, int stride, int batch, uint8_t* d_out, int out_stride, hipStream_t s);
-void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s);
+// exclusive_simd (the T_2 commitments of a small batch on the side stream, at most 16 waves): every wave claims the whole register file of its SIMD
+void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s, bool exclusive_simd = false);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
 // d_src_offset (optional): encoding i starts at byte d_src_offset[i] of d_in (points inside serialized proofs) instead of 48 i
 void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,

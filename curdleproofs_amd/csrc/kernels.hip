@@ -1034,13 +1034,19 @@ constexpr int SMUL_THREADS = 64;   // single-wave groups: no whole-CU placement 
 // of its SIMD — the 215-operation chain is not slowed by a neighbour and, more to the point, does not slow the waves of the main
 // stream's phase kernels that would otherwise share its SIMD for 3 ms (the slowest wave is the kernel: 605 instead of 302 us per
 // k_msm_fix of the first IPA rounds at 128 proofs).
+// (The claim rests on gfx950's unified 512-entry VGPR file — 256 architectural + 256 accumulation registers per lane — and on the compiler
+// sizing a wave's allocation by the highest register a clobber names: checked for this target only.)
 template <bool EXCL>
 __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#if defined(__gfx950__)
   if (EXCL) {
     asm volatile("v_mov_b32 v255, 0" ::: "v255");
     asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
   }
+#elif defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!EXCL, "the exclusive-SIMD form is written for gfx950's register file");
+#endif
   TF* buf = reinterpret_cast<TF*>(smem);                                             // 2 * SMUL_THREADS field elements
   uint32_t* naf = reinterpret_cast<uint32_t*>(smem + 2 * SMUL_THREADS * sizeof(TF));  // [20][SMUL_THREADS]: nz / ng words of both halves
   const int tid = threadIdx.x;
@@ -1055,7 +1061,17 @@ __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restric
     dst = task.out + e;
     Fr k = task.scalars[(size_t)e * task.scalar_stride];
     if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
-    {
+    // SMUL_PLAIN: the non-adjacent form of the whole scalar (rows 0..8 non-zero bits, 9..17 signs) — valid on all of E(Fp); otherwise the
+    // endomorphism split, valid on the order-r subgroup (rows 0..4 / 5..9: t, rows 10..14 / 15..19: q)
+    const bool plain = (task.flags & SMUL_PLAIN) != 0;
+    if (plain) {
+      uint32_t nz[9], ng[9];
+      recode_naf(k.v, nz, ng);
+      CPX_UNROLL for (int i = 0; i < 9; i++) {
+        naf[i * SMUL_THREADS + tid] = nz[i];
+        naf[(9 + i) * SMUL_THREADS + tid] = ng[i];
+      }
+    } else {
       SmulNaf rn;
       recode_smul_glv(k.v, rn);
       CPX_UNROLL for (int hh = 0; hh < 2; hh++)
@@ -1066,9 +1082,13 @@ __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restric
     }
     const TAff P = t_from_std(task.mul[e]);
     const TAff NP = P.is_identity() ? P : TAff{t_mul(P.x, t_beta()), t_neg(P.y)};   // N P = -phi(P) (glv.hpp)
-    for (int i = 128; i >= 0; i--) {
+    for (int i = plain ? 256 : 128; i >= 0; i--) {
       acc = t_dbl(acc);
       const int wd = i >> 5, bt = i & 31;
+      if (plain) {
+        if ((naf[wd * SMUL_THREADS + tid] >> bt) & 1u) acc = t_add_mixed(acc, t_cneg(P, (naf[(9 + wd) * SMUL_THREADS + tid] >> bt) & 1u));
+        continue;
+      }
       if ((naf[wd * SMUL_THREADS + tid] >> bt) & 1u) acc = t_add_mixed(acc, t_cneg(P, (naf[(5 + wd) * SMUL_THREADS + tid] >> bt) & 1u));
       if ((naf[(10 + wd) * SMUL_THREADS + tid] >> bt) & 1u) acc = t_add_mixed(acc, t_cneg(NP, (naf[(15 + wd) * SMUL_THREADS + tid] >> bt) & 1u));
     }
@@ -1338,10 +1358,14 @@ __global__ __launch_bounds__(64) void k_transcript_step1(const uint8_t* __restri
   __shared__ uint8_t scratch[64];
   const int p = blockIdx.x;
   if (p >= nproofs) return;
-  if (EXCL) {
+#if defined(__gfx950__)
+  if (EXCL) {   // (gfx950's unified 512-register file: see k_smul)
     asm volatile("v_mov_b32 v255, 0" ::: "v255");
     asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
   }
+#elif defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!EXCL, "the exclusive-SIMD form is written for gfx950's register file");
+#endif
   WaveStrobe t;
   t.set_lane(threadIdx.x);
   t.init("curdleproofs", 12, scratch);
@@ -1550,6 +1574,7 @@ const OptField kOptFields[] = {
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
     {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
+    {"scale_any_point", &Options::scale_any_point, 0, 1},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;
@@ -1806,12 +1831,12 @@ void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, in
   if (ncols <= 0 || batch <= 0) return;
   CPX_LAUNCH(k_compress_cols, dim3(batch), dim3(64), 0, s, d_in, d_cols, ncols, stride, d_out, out_stride);
 }
-void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s) {
+void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s, bool exclusive_simd) {
   const long total = (long)ntasks * cnt;
   if (total <= 0) return;
   const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 20 * SMUL_THREADS * sizeof(uint32_t);
   const unsigned groups = (unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS);
-  if (groups <= 16) CPX_LAUNCH(k_smul<true>, dim3(groups), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
+  if (exclusive_simd && groups <= 16) CPX_LAUNCH(k_smul<true>, dim3(groups), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
   else CPX_LAUNCH(k_smul<false>, dim3(groups), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
 }
 void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,

@@ -80,7 +80,11 @@ int cpx_g1_msm_jac(cpx_ctx* ctx, const uint8_t* bases /* n*144 */, const uint8_t
  *   PL[i] <- (PL[i] + PR[i] * gamma).into_affine(), i < half, in place */
 int cpx_g1_fold(cpx_ctx* ctx, uint8_t* PL /* half*96 */, const uint8_t* PR /* half*96 */, const uint8_t gamma[32], size_t half);
 /* grand_product_argument.rs:90-102 (per-element scalars, scalar_stride = 32) and util.rs:94-95
- * (one shared scalar, scalar_stride = 0):  out[i] <- (P[i] * s_i).into_affine() */
+ * (one shared scalar, scalar_stride = 0):  out[i] <- (P[i] * s_i).into_affine()
+ * PRECONDITION of cpx_g1_fold / cpx_g1_scale (as of arkworks' G1Affine, whose deserialisation checks it): the points lie in the order-r
+ * subgroup — the scalar is split by the G1 endomorphism, k P = t P + q (-phi(P)), an identity of that subgroup only; on a point of
+ * E(Fp) outside it a scalar >= z^2 / 2 gives a wrong result.  Context option "scale_any_point" = 1 selects the plain 257-step
+ * double-and-add for both calls, valid on all of E(Fp) (the cofactor multiplication of the hash-to-curve CRS, tests/crs.rs:38). */
 int cpx_g1_scale(cpx_ctx* ctx, const uint8_t* P /* n*96 */, const uint8_t* scalars, size_t scalar_stride, size_t n, uint8_t* out /* n*96 */);
 /* ark_ec `CurveGroup::normalize_batch` (+ optional `serialize_compressed`); either output may be NULL */
 int cpx_g1_normalize(cpx_ctx* ctx, const uint8_t* jac /* n*144 */, size_t n, uint8_t* out_affine /* n*96 */, uint8_t* out_compressed /* n*48 */);

@@ -20,7 +20,11 @@ const COFACTOR: u128 = 0x396c8c005555e1568c00aaab0000aaab;
 /// number of hash attempts equals the reference's.
 pub fn generate_random_points(num_points: usize, seed: &str) -> (Vec<G1Affine>, u64) {
     let h = ctx();
-    let cofactor = [Fr::from(COFACTOR)]; // < r: a plain scalar for cpx_g1_scale, whose double-and-add holds on all of E(Fp)
+    let cofactor = [Fr::from(COFACTOR)]; // < r
+    // The candidates are points of E(Fp), not of the order-r subgroup: cpx_g1_scale's default form splits the scalar by the G1
+    // endomorphism (an identity of the subgroup only); option scale_any_point selects the plain double-and-add for this context.
+    let key = std::ffi::CString::new("scale_any_point").unwrap();
+    assert_eq!(unsafe { cpx_ctx_set_option(h, key.as_ptr(), 1) }, CPX_OK);
     let mut points: Vec<G1Affine> = vec![];
     let mut increment = 0u64;
     while points.len() != num_points {

@@ -20,12 +20,35 @@ AFF = 96
 JAC = 144
 
 
-def build_oracle(force=False):
-    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".h", ".cpp"))]
-    stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+_LIB_FAST = os.path.join(_ORACLE_DIR, "_build", "liborc_fast.so")
+
+
+def fast_build_runs_here():
+    """liborc_fast.so is compiled with -march=x86-64-v3 -madx (mulx / adcx / adox): only loadable where the CPU has BMI2 and ADX"""
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next(l for l in f if l.startswith("flags")).split()
+        return "bmi2" in flags and "adx" in flags and "avx2" in flags
+    except Exception:
+        return False
+
+
+def oracle_build_flags(fast=False):
+    """the compiler flags of the (fast) oracle build, as oracle/Makefile states them"""
+    with open(os.path.join(_ORACLE_DIR, "Makefile")) as f:
+        for l in f:
+            if l.startswith("FASTFLAGS ?=" if fast else "CXXFLAGS ?="):
+                return "g++ " + l.split("?=", 1)[1].strip()
+    return None
+
+
+def build_oracle(force=False, fast=False):
+    lib = _LIB_FAST if fast else _LIB
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".h", ".cpp")) or f == "Makefile"]
+    stale = (not os.path.exists(lib)) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "_build/liborc.so"] + (["-B"] if force else []))
-    return _LIB
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "_build/" + os.path.basename(lib)] + (["-B"] if force else []))
+    return lib
 
 
 def _buf(n):
@@ -37,8 +60,11 @@ def _cb(b):
 
 
 class Oracle:
-    def __init__(self):
-        self.lib = ctypes.CDLL(build_oracle())
+    def __init__(self, fast=False):
+        """fast: the ORC_FAST build (ark-ff's unrolled no-carry CIOS on mulx + dedicated squaring, -march=x86-64-v3 -madx) — the CPU
+        baseline of bench.py; the tests check it against the same known-answer vectors as the portable build"""
+        self.fast = bool(fast)
+        self.lib = ctypes.CDLL(build_oracle(fast=fast))
         L = self.lib
         L.orc_rng_new.restype = ctypes.c_void_p
         L.orc_rng_new.argtypes = [ctypes.c_uint64]

@@ -162,6 +162,47 @@ def test_scale_matches_oracle(ctx, orc, n):
         assert ctx.scale(P, shared) == orc.g1_scale(P, shared)
 
 
+def test_scale_and_fold_on_curve_points_outside_the_subgroup(orc):
+    """cpx_g1_scale / cpx_g1_fold on points of E(Fp) that are NOT in the order-r subgroup (what the hash-to-curve CRS ceremony multiplies by
+    the cofactor, tests/crs.rs:32-38): with option scale_any_point = 1 (plain double-and-add) the results equal the oracle's double-and-add
+    for full-width scalars; the default form (endomorphism split, include/cpx.h states the subgroup precondition) still agrees for the
+    cofactor itself, whose split has no upper half, and for points inside the subgroup either setting gives the same bytes."""
+    import hashlib
+    import curdleproofs_amd as cpx
+    from curdleproofs_amd import params as pr
+    from curdleproofs_amd.crs import COFACTOR
+    c = cpx.Context(0)
+    cands = []
+    for inc in range(64):
+        hsh = hashlib.sha256(b"outside the subgroup" + inc.to_bytes(8, "big")).digest()
+        x = sum(int.from_bytes(hsh[8 * i:8 * i + 8], "big") << (64 * i) for i in range(4))
+        cands.append(bytes([0x80 | (x >> 376)]) + (x & ((1 << 376) - 1)).to_bytes(47, "big"))
+    aff, status = c.decompress_status(b"".join(cands), check_subgroup=False)
+    pts = b"".join(aff[AFF * j:AFF * (j + 1)] for j in range(64) if status[j] == 0)
+    n = len(pts) // AFF
+    assert n >= 16
+    comp = c.normalize(b"".join(pts[AFF * t:AFF * (t + 1)] + pr.fp_to_wire(1) for t in range(n)), compressed=True)[1]
+    assert all(s == 2 for s in c.decompress_status(comp, check_subgroup=True)[1])          # on the curve, outside the subgroup
+    rng = orc.rng(4242)
+    big = rng.fr(n)                                                                         # full-width scalars: the split would use phi
+    c.set_option("scale_any_point", 1)
+    assert c.scale(pts, big) == orc.g1_scale(pts, big)
+    shared = rng.fr(1)
+    assert c.scale(pts, shared) == orc.g1_scale(pts, shared)
+    h = pr.fr_to_wire(COFACTOR)
+    cleared = c.scale(pts, h)
+    assert cleared == orc.g1_scale(pts, h)
+    half = n // 2
+    assert c.fold(pts[:half * AFF], pts[half * AFF:2 * half * AFF], shared) == orc.g1_fold(pts[:half * AFF], pts[half * AFF:2 * half * AFF], shared)
+    inside = rng.g1_affine(8)
+    k8 = rng.fr(8)
+    plain = c.scale(inside, k8)
+    c.set_option("scale_any_point", 0)
+    assert c.scale(pts, h) == cleared                                                       # q = 0: nothing of phi is used
+    assert c.scale(inside, k8) == plain == orc.g1_scale(inside, k8)
+    assert c.scale(pts, big) != orc.g1_scale(pts, big)                                      # the documented precondition is a real one
+
+
 def test_normalize_compress_decompress(ctx, orc):
     rng = orc.rng(17)
     n = 70

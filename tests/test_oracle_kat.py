@@ -179,3 +179,25 @@ def test_hash_to_curve_points_match_an_independent_big_integer_restatement(orc):
         gy = int.from_bytes(rec[48:], "little") * pow(R, -1, p) % p
         assert (gx, gy) == (x, y), i
         assert orc.g1_on_curve(rec) and orc.g1_in_subgroup(rec)
+
+
+def test_fast_build_of_the_cpu_baseline_reproduces_the_known_answers(whisk_kat, oracle_vectors):
+    """bench.py's `cpu_baseline` times the ORC_FAST build of the oracle (oracle/Makefile: -march=x86-64-v3 -madx, the Montgomery product of
+    ark-ff's `asm` feature on mulx / adcx / adox, oracle/mont_asm.h).  A baseline that computes something else is no baseline: the same
+    sources, the same known answers — the reference's tracker proof and its 4496-byte shuffle proof (whisk.rs:381-456), Merlin's vector,
+    the field products against Python integers, and the ell = 28 README proof against the portable build's bytes."""
+    from tests.oracle_lib import Oracle, fast_build_runs_here, oracle_build_flags
+    if not fast_build_runs_here():
+        pytest.skip("this CPU has no BMI2 + ADX")
+    assert "-DORC_FAST" in oracle_build_flags(fast=True) and "-DORC_FAST" not in oracle_build_flags(fast=False)
+    fast, port = Oracle(fast=True), Oracle()
+    assert fast.merlin_test_vector() == port.merlin_test_vector()
+    test_field_arithmetic_against_python_ints(fast)
+    test_tracker_proof_kat(fast, whisk_kat)
+    test_whisk_shuffle_proof_kat(fast, whisk_kat)
+    crs = port.generate_crs_points(28)
+    assert fast.generate_crs_points(28) == crs
+    a, b = fast.make_instance(28, 0, crs), port.make_instance(28, 0, crs)
+    assert a["proof"] == b["proof"] and a["vec_T"] == b["vec_T"] and a["M"] == b["M"]
+    ok, tp, tv = fast.time_prove_verify(a, crs, 1)
+    assert ok == 1 and tp > 0 and tv > 0

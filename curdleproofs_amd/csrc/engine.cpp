@@ -698,9 +698,42 @@ void Engine::scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_strid
   CPX_HIP(hipStreamSynchronize(stream_));
   flush_timers();
 }
+// Encodings with the infinity flag set (include/cpx.h, option strict_infinity).  ark-bls12-381 ^0.4's `read_g1_compressed` — the
+// deserialiser behind `G1Affine::deserialize_compressed`, whisk.rs:313-320 — returns the identity as soon as the compression and the
+// infinity flag are set, without looking at the sort flag or the other bits (recalled from the 0.4.0 source; 0.5 added both checks), and the
+// verifier then hashes the point's CANONICAL serialisation (transcript.rs:28-36 append the deserialised points).  The device kernels
+// accept exactly the canonical form, so with strict_infinity = 0 the host rewrites a non-canonical infinity encoding to 0xc0 || 0^47 in a
+// copy of the input before anything reads it; with strict_infinity = 1 the bytes go through untouched and such an encoding is a
+// deserialisation error.  Returns true if `enc` was rewritten.
+static inline bool infinity_is_noncanonical(const uint8_t* enc) {
+  if ((enc[0] & 0xc0) != 0xc0) return false;
+  if (enc[0] != 0xc0) return true;
+  for (int i = 1; i < 48; i++)
+    if (enc[i]) return true;
+  return false;
+}
+const uint8_t* Engine::canonical_infinities(const uint8_t* bytes, size_t nbytes, size_t nrec, size_t rec_stride, const std::vector<size_t>& offsets) {
+  if (opt_.strict_infinity) return bytes;
+  bool copied = false;
+  for (size_t r = 0; r < nrec; r++)
+    for (size_t off : offsets) {
+      const size_t at = r * rec_stride + off;
+      if (!(bytes[at] & 0x40) || !infinity_is_noncanonical(bytes + at)) continue;   // (one byte per encoding on the common path)
+      if (!copied) {
+        canon_bytes_.assign(bytes, bytes + nbytes);
+        bytes = canon_bytes_.data();
+        copied = true;
+      }
+      canon_bytes_[at] = 0xc0;
+      memset(&canon_bytes_[at + 1], 0, 47);
+    }
+  return bytes;
+}
+
 int Engine::decompress(const uint8_t* comp, size_t n, uint8_t* out_aff, int check_subgroup, uint8_t* status_out) {
   CPX_HIP(hipSetDevice(device_));
   if (!n) return CPX_OK;
+  comp = canonical_infinities(comp, n * 48, n, 48, {0});
   DevBuf<uint8_t> dc, dst;
   DevBuf<Aff> da;
   dc.ensure(n * 48);
@@ -1485,6 +1518,11 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
   // a zero (or non-reduced) factor would silently drop the check it weights
   for (size_t i = 0; i < B * rand_stride; i++)
     if (!host::is_valid_factor(rand + 32 * i)) throw ArgError("verifier random factors must be non-zero reduced field elements");
+  {   // infinity encodings as ark-bls12-381 ^0.4 reads them (option strict_infinity = 0): canonical before anything hashes or decodes them
+    std::vector<size_t> offs((size_t)NPP);
+    for (size_t q = 0; q < (size_t)NPP; q++) offs[q] = 48 * q + (q >= 9 ? 32 : 0) + (q >= 11 + 4 * L ? 64 : 0) + (q >= 15 + 4 * L ? 96 : 0);
+    proofs = canonical_infinities(proofs, B * psz, B, psz, offs);
+  }
   if (device_prefix(B)) {   // the whole verifier on the GPU (engine_device.cpp); a few proofs: host-driven Fiat-Shamir below
     verify_core_device(proofs, rand, rand_stride, verdict, fused_partial, fused_invalid);
     return;

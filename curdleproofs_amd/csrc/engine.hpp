@@ -296,6 +296,10 @@ class Engine {
   void reduce_sets(size_t nplain, size_t nweighted, TJac* part = nullptr);
   void verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand_stride, int* verdict, uint8_t* fused_partial, int* fused_invalid);
   void batch_prove_tables(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
+  // option strict_infinity = 0: `bytes` with every non-canonical infinity encoding (at `offsets` of each of the nrec records) rewritten to
+  // the canonical one, in canon_bytes_ (valid until the next call); `bytes` itself when there is none or the option is set
+  const uint8_t* canonical_infinities(const uint8_t* bytes, size_t nbytes, size_t nrec, size_t rec_stride, const std::vector<size_t>& offsets);
+  std::vector<uint8_t> canon_bytes_;
   void run_smul(const std::vector<SmulTask>& tasks, int cnt, const host::S* scalars, size_t nscalars, double alg_bytes);
   const uint32_t* idx_list(const std::vector<uint32_t>& v);
   void tick(const char* name, double bytes, double units, bool span = false);

@@ -48,6 +48,7 @@ struct Options {
   long p1_split = 1;               // 1: phase 1 without A (it only needs the prover's randomness) runs before the main stream waits for the transcript prefix, A alone behind it: 128 proofs 41.7 -> 40.6 ms per pass, nothing at 8192
   long serial_streams = 0;         // 1 (measurement aid): the side stream's kernels run in line on the main stream — every kernel's duration is its own
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
+  long strict_infinity = 0;        // point encodings with the infinity flag set: 0 = the identity whatever the other 382 bits say (ark-bls12-381 ^0.4 `read_g1_compressed`, as recalled: include/cpx.h), 1 = only 0xc0 || 0^47 (the zcash specification's wording; ark-bls12-381 0.5)
   long scale_any_point = 0;        // 1: cpx_g1_scale / cpx_g1_fold take ANY point of E(Fp) (plain 257-step double-and-add, SMUL_PLAIN); 0: points of the order-r subgroup (endomorphism split, 129 steps)
 };
 const Options& default_options();                               // built-in defaults overridden by CPX_<NAME> environment variables

@@ -1574,7 +1574,7 @@ const OptField kOptFields[] = {
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
     {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
-    {"scale_any_point", &Options::scale_any_point, 0, 1},
+    {"scale_any_point", &Options::scale_any_point, 0, 1},         {"strict_infinity", &Options::strict_infinity, 0, 1},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;

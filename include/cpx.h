@@ -134,10 +134,14 @@ int cpx_batch_prove(cpx_ctx* ctx, const uint32_t* permutation, const uint8_t* k,
  * probability <= 2/r (Schwartz-Zippel) — the same bound every other check of `MsmAccumulator` already rests on.  The
  * verdict therefore equals the reference's except with probability < 2^-253 over the caller's factors
  * (tests/test_gpu_parity.py::test_same_scalar_relations_are_checked isolates these relations).
- * Point encodings are validated strictly, as the zcash serialisation spec words it: an encoding with the infinity flag set
- * must be exactly 0xc0 || 0^47, anything else (sort flag set, non-zero x bits) is CPX_ERR_DESERIALIZE.  ark-bls12-381 ^0.4 is
- * not available in the build image, so its treatment of such NON-CANONICAL infinity encodings could not be checked; if it
- * accepts them as the identity, this library is stricter on those (never produced by an honest serialiser) inputs. */
+ * Point encodings with the INFINITY FLAG set (context option "strict_infinity"): ark-bls12-381 ^0.4's `read_g1_compressed` — behind
+ * `G1Affine::deserialize_compressed`, curdleproofs.rs:312-323, whisk.rs:313-320 — returns the identity as soon as the compression and
+ * the infinity flag are set and looks at neither the sort flag nor the remaining 381 bits (ark-bls12-381 0.4.0 `curves/util.rs`, recalled:
+ * the crate is not in the build image; version 0.5 rejects both).  strict_infinity = 0 (default) reproduces that: such an encoding IS the
+ * identity — and is hashed in its canonical form 0xc0 || 0^47, as the reference hashes the deserialised point — so a proof carrying one
+ * gets the verdict the reference gives it (normally CPX_ERR_VERIFY, not CPX_ERR_DESERIALIZE).  strict_infinity = 1: only 0xc0 || 0^47
+ * is the identity, anything else with the flag set is CPX_ERR_DESERIALIZE (the zcash specification's wording).  The option also governs
+ * cpx_g1_decompress / cpx_g1_decompress_status and the cpx_whisk_* entry points. */
 int cpx_batch_verify(cpx_ctx* ctx, const uint8_t* proofs, const uint8_t* rand, int* verdict);
 /* BASELINE config 5: the batched verifier.  Every `accumulate_check` of every loaded proof goes into
  * ONE accumulated MSM — the reference's `MsmAccumulator` (msm_accumulator.rs:22-68; `new` is pub(crate), :28, and

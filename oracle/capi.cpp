@@ -240,6 +240,7 @@ void orc_g1_compress(const uint8_t* aff, size_t n, uint8_t* out) {
 void orc_g1_compress_jac(const uint8_t* jac, size_t n, uint8_t* out) {
   for (size_t i = 0; i < n; i++) g1_compress(jac_from_wire(jac + 144 * i), out + 48 * i);
 }
+void orc_set_strict_infinity(int strict) { g1_strict_infinity() = strict != 0; }
 int orc_g1_decompress(const uint8_t* in, size_t n, uint8_t* out) {
   for (size_t i = 0; i < n; i++) {
     G1Aff p;

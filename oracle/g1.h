@@ -195,6 +195,15 @@ static inline bool g1_point_from_x(const Fp& x, bool greatest, G1Aff* out) {
   return true;
 }
 
+// Encodings with the infinity flag set.  ark-bls12-381 ^0.4 `read_g1_compressed` (curves/util.rs of 0.4.0, a crates.io dependency that is
+// not vendored under /root/reference — recalled, not re-read): `if flags.is_infinity { return Ok(G1Affine::zero()); }` right after the
+// compression-flag test, i.e. neither the sort flag nor the other bits are looked at; 0.5 rejects both.  strict = false restates 0.4,
+// strict = true the zcash specification's wording (only 0xc0 || 0^47).  Process-wide switch for the tests (orc_set_strict_infinity).
+static inline bool& g1_strict_infinity() {
+  static bool strict = false;
+  return strict;
+}
+
 // returns false on any malformed / off-curve / out-of-subgroup encoding
 // (ark `deserialize_compressed` = Compress::Yes, Validate::Yes)
 static inline bool g1_decompress(const uint8_t in[48], G1Aff* out, bool check_subgroup = true) {
@@ -204,9 +213,11 @@ static inline bool g1_decompress(const uint8_t in[48], G1Aff* out, bool check_su
   memcpy(b, in, 48);
   b[0] &= 0x1f;
   if (infinity) {
-    if (sort) return false;
-    for (int i = 0; i < 48; i++)
-      if (b[i]) return false;
+    if (g1_strict_infinity()) {
+      if (sort) return false;
+      for (int i = 0; i < 48; i++)
+        if (b[i]) return false;
+    }
     *out = G1Aff::identity();
     return true;
   }

@@ -111,6 +111,11 @@ class Oracle:
         L.orc_time_prove_verify.argtypes = [sz] + [vp] * 10 + [sz, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                                                 ctypes.POINTER(ctypes.c_double)]
 
+    def set_strict_infinity(self, strict):
+        """how encodings with the infinity flag are read (oracle/g1.h): False = ark-bls12-381 ^0.4 (the identity whatever the other bits say),
+        True = only 0xc0 || 0^47.  Process-wide for this library."""
+        self.lib.orc_set_strict_infinity(1 if strict else 0)
+
     # ---- self checks ----
     def merlin_test_vector(self):
         o = _buf(32)

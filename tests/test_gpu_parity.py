@@ -220,11 +220,11 @@ def test_decompress_rejects_bad_encodings(ctx, orc):
     import curdleproofs_amd as cpx
     good = orc.g1_compress(orc.g1_generator())
     for bad in (bytes(48),                                  # compression flag missing
-                bytes([0xE0]) + bytes(47),                  # infinity with sort flag
-                bytes([0xC0]) + bytes(46) + b"\x01",        # infinity with non-zero x
+                bytes([0x40]) + bytes(47),                  # infinity flag without the compression flag
                 bytes([0x9F]) + b"\xff" * 47):              # x >= p
         with pytest.raises(cpx.CpxError):
             ctx.decompress(bad)
+    # (encodings with the infinity flag set and other bits beside it: test_noncanonical_infinity_encodings_follow_the_option)
     # a point on the curve but outside the r-torsion subgroup must fail the subgroup check only
     x = 0
     for cand in range(1, 200):
@@ -485,6 +485,67 @@ def test_verify_rejects_corrupted_proof_bytes(ctx, orc):
     v = ctx.verify_batch([bad], inst["verifier_rand"])[0]
     o = orc.verify(ell, crs, inst["vec_R"], inst["vec_S"], inst["vec_T"], inst["vec_U"], inst["M"], bad, inst["verifier_rand"])
     assert (v == cpx.CPX_ERR_DESERIALIZE and o == -1) or (v == cpx.CPX_ERR_VERIFY and o == 0)
+
+
+@pytest.mark.parametrize("copies", [1, 60], ids=["host_driven", "device_resident"])
+def test_noncanonical_infinity_encodings_follow_the_option(orc, copies):
+    """Point encodings whose infinity flag is set but which are not 0xc0 || 0^47 (sort flag set, x bits set).  ark-bls12-381 ^0.4's
+    `read_g1_compressed` — behind curdleproofs.rs:312-323 / whisk.rs:313-320 — takes the infinity flag at its word (include/cpx.h states
+    the source of that knowledge and its limits): the point IS the identity, and what the verifier hashes is the identity's canonical
+    serialisation.  Option strict_infinity = 0 (default) must therefore give such a proof exactly the verdict the oracle gives it in its
+    ^0.4 mode — the verdict of the same proof with the canonical 0xc0 encoding in that place, i.e. VerificationError —, and
+    strict_infinity = 1 the oracle's strict verdict, SerializationError.  Tier 0 (cpx_g1_decompress) follows the same option.
+    Per-proof verdicts and the fused verifier, host-driven and device-resident path."""
+    import curdleproofs_amd as cpx
+    ell = 28
+    crs = orc.generate_crs_points(ell)
+    inst = orc.make_instance(ell, 5, crs)
+    proof = inst["proof"]
+    L = 5
+    canon = bytes([0xc0]) + bytes(47)
+    variants = [bytes([0xe0]) + bytes(47), bytes([0xc0]) + bytes(46) + b"\x01", bytes([0xff]) + b"\xff" * 47, bytes([0xc0, 0x01]) + bytes(46)]
+    # places: A (the first point), L_C[1] (inside the IPA block, after the r_p scalar), R_U[last] (the last point)
+    q_lc1 = 9 + 2 + 1
+    places = [0, 48 * q_lc1 + 32, len(proof) - 32 - 48]
+    cases = [(off, v) for off in places for v in variants]
+    put = lambda off, enc: proof[:off] + enc + proof[off + 48:]
+    c = cpx.Context(0)
+    try:
+        c.set_crs(ell, crs)
+        B = copies * len(cases)
+        rep = lambda key: inst[key] * B
+        c.load_batch(rep("vec_R"), rep("vec_S"), rep("vec_T"), rep("vec_U"), rep("M"))
+        vr = inst["verifier_rand"] * B
+        V = lambda o: {1: cpx.CPX_OK, 0: cpx.CPX_ERR_VERIFY, -1: cpx.CPX_ERR_DESERIALIZE}[o]
+        over = lambda pr: orc.verify(ell, crs, inst["vec_R"], inst["vec_S"], inst["vec_T"], inst["vec_U"], inst["M"], pr, inst["verifier_rand"])
+        assert c.get_option("strict_infinity") == 0
+        for strict in (0, 1, 0):
+            c.set_option("strict_infinity", strict)
+            orc.set_strict_infinity(bool(strict))
+            try:
+                bad = [put(off, v) for off, v in cases] * copies
+                want = [V(over(b)) for b in bad[:len(cases)]] * copies
+                if strict:
+                    assert set(want) == {cpx.CPX_ERR_DESERIALIZE}
+                else:   # the identity in that place: the verdict of the canonical encoding there
+                    assert want[:len(cases)] == [V(over(put(off, canon))) for off, _ in cases] and set(want) == {cpx.CPX_ERR_VERIFY}
+                assert c.verify_batch(bad, vr) == want
+                good_but_one = [proof] * (B - 1) + [bad[0]]
+                frand = orc.rng(77).fr(12 * B)
+                assert c.verify_batch_fused([proof] * B, frand) and not c.verify_batch_fused(good_but_one, frand)
+                for v in variants:
+                    if strict:
+                        with pytest.raises(cpx.CpxError):
+                            c.decompress(v)
+                        with pytest.raises(ValueError):
+                            orc.g1_decompress(v)
+                    else:
+                        assert c.decompress(v) == bytes(AFF) == orc.g1_decompress(v)
+                assert c.decompress(canon) == bytes(AFF)
+            finally:
+                orc.set_strict_infinity(False)
+    finally:
+        c.close()
 
 
 def test_not_power_of_two_is_an_error(ctx, orc):
@@ -990,6 +1051,57 @@ def test_bench_code_path_one_context_default_options_every_proof_matches_oracle(
         frand = orc.rng(9300 + ell).fr(12 * N)
         assert c.verify_batch_fused(good, frand)
         assert not c.verify_batch_fused(bad, frand)
+    finally:
+        c.close()
+
+
+def test_bench_batch_8192_on_one_context_and_config5_literal_4096_in_one_check(orc):
+    """(1) The headline's per-context shape with NOTHING lowered: 8192 ell = 252 proofs on ONE engine context with default options — the
+    one-lane transcript prefix (k_transcript_step1_lane takes over at 8192), the late rounds, k_msm_fix<16, 16>, k_msm_tblw<32, false> at
+    the grid sizes the bench launches.  The batch is instances 0..2047 of BASELINE configs[3]'s recipe four times over (instance j mod 2048
+    in place j: the oracle's proof of every place is known), and EVERY proof is compared with the oracle's bytes — the random sample of
+    64 the review asked for is a subset.  (2) BASELINE configs[4] at its literal size: the first 4096 of those proofs in ONE accumulated
+    check (msm_accumulator.rs:55-68 shared by all verify calls) with fresh factors — accepted; with one proof replaced by a neighbour's
+    (a valid proof of another instance) — refused; and the per-proof verifier's verdicts on the same 4096."""
+    import random
+    import curdleproofs_amd as cpx
+    ell, D, N, NF = 252, 2048, 8192, 4096
+    crs = orc.generate_crs_points(ell)
+    insts = _instance_list(orc, ell, D, crs)
+    rep = N // D
+    cat = lambda key: b"".join(i[key] for i in insts) * rep
+    c = cpx.Context(0)
+    try:
+        assert c.get_option("transcript_lane_min_batch") == 8192 and c.get_option("late_rounds") == 4 and c.get_option("fix_bits") == 16
+        c.set_crs(ell, crs)
+        if c.get_option("fix_bits_effective") != 16:
+            pytest.skip("not enough free HBM for the 16-bit fixed-base table")
+        c.load_batch(cat("vec_R"), cat("vec_S"), cat("vec_T"), cat("vec_U"), cat("M"))
+        c.set_profiling(True)
+        c.reset_stats()
+        proofs = c.prove_batch([x for i in insts for x in i["permutation"]] * rep, cat("k"), cat("vec_m_blinders"), cat("prover_rand"))
+        for name in ("k_late_msm", "k_msm_fix<16, 16>", "k_msm_tblw<32, false>", "k_transcript_step1"):
+            assert c.stat(name)["launches"] > 0, "%s did not run" % name
+        c.set_profiling(False)
+        wrong = [j for j in range(N) if proofs[j] != insts[j % D]["proof"]]
+        assert not wrong, "%d of %d proofs differ from the oracle's, first at place %d" % (len(wrong), N, wrong[0])
+        sample = random.Random(5).sample(range(N), 64)
+        assert all(proofs[j] == insts[j % D]["proof"] for j in sample)
+        assert c.verify_batch(proofs, cat("verifier_rand")) == [cpx.CPX_OK] * N
+        # config 5, literally: 4096 proofs, one accumulated check
+        cut = lambda key: b"".join(i[key] for i in insts) * (NF // D)
+        c.load_batch(cut("vec_R"), cut("vec_S"), cut("vec_T"), cut("vec_U"), cut("M"))
+        good = proofs[:NF]
+        frand = orc.rng(9401).fr(12 * NF)
+        assert c.verify_batch_fused(good, frand)
+        bad = list(good)
+        bad[3000] = good[3001]
+        assert not c.verify_batch_fused(bad, frand)
+        assert c.verify_batch_fused(good, orc.rng(9402).fr(12 * NF))          # fresh factors, same verdict
+        got = c.verify_batch(bad, cut("verifier_rand"))
+        x = insts[3000 % D]
+        assert orc.verify(ell, crs, x["vec_R"], x["vec_S"], x["vec_T"], x["vec_U"], x["M"], bad[3000], x["verifier_rand"]) == 0
+        assert got == [cpx.CPX_OK] * 3000 + [cpx.CPX_ERR_VERIFY] + [cpx.CPX_OK] * (NF - 3001)
     finally:
         c.close()
 

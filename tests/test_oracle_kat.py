@@ -5,6 +5,8 @@ import hashlib
 import os
 import struct
 
+import pytest
+
 P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 
@@ -201,3 +203,24 @@ def test_fast_build_of_the_cpu_baseline_reproduces_the_known_answers(whisk_kat, 
     assert a["proof"] == b["proof"] and a["vec_T"] == b["vec_T"] and a["M"] == b["M"]
     ok, tp, tv = fast.time_prove_verify(a, crs, 1)
     assert ok == 1 and tp > 0 and tv > 0
+
+
+def test_infinity_flag_encodings_in_both_reading_modes(orc):
+    """oracle/g1.h g1_decompress: the ark-bls12-381 ^0.4 reading (default: compression + infinity flag set = the identity, whatever else the
+    48 bytes hold) and the strict one (only 0xc0 || 0^47) — the two behaviours the product's option strict_infinity selects between."""
+    canon = bytes([0xc0]) + bytes(47)
+    odd = [bytes([0xe0]) + bytes(47), bytes([0xc0]) + bytes(46) + b"\x01", b"\xff" * 48]
+    try:
+        for strict in (False, True):
+            orc.set_strict_infinity(strict)
+            assert orc.g1_decompress(canon) == bytes(96)
+            for enc in odd:
+                if strict:
+                    with pytest.raises(ValueError):
+                        orc.g1_decompress(enc)
+                else:
+                    assert orc.g1_decompress(enc) == bytes(96)
+            with pytest.raises(ValueError):
+                orc.g1_decompress(bytes([0x40]) + bytes(47))   # no compression flag: an error in both modes
+    finally:
+        orc.set_strict_infinity(False)

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(OUT_DIR, "libcpx.so")
 ARCH = "gfx950"
-SOURCES = ["kernels.hip", "late.hip", "protocol.hip", "engine.cpp", "engine_device.cpp", "whisk.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "late.hip", "protocol.hip", "round.hip", "engine.cpp", "engine_device.cpp", "whisk.cpp", "capi.cpp"]
 # host side: x86-64-v3 + ADX (BMI2 mulx / andn / rorx: the Keccak permutation of the transcripts runs 1.7x faster, the
 # 64-bit-limb Fr products use mulx); every host of an MI355X (EPYC 9005) has them
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-ffp-contract=off",

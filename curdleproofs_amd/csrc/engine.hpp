@@ -237,6 +237,8 @@ class Engine {
     double pts_fix = 0, pts_tbl = 0;
     bool any_add = false;
     bool table_stream = false;   // runs beside the main stream's plans (phase 1t): its own write-only dummy slot
+    bool keep_order = false;     // tasks stay in request (= proof-major) order: the fused round kernels address them by proof (round.hip)
+    int force_fix_wpw = 0, force_tbl_wpw = 0;   // != 0: the windows per wave instead of the launch-size heuristics
     DevBuf<TblTask> ttasks;
     DevBuf<FixTask> ftasks;
     DevBuf<uint32_t> meta;   // first partial | partial count | affine destination | compressed-bytes slot | addends[3], per request
@@ -249,6 +251,10 @@ class Engine {
     DevBuf<uint8_t> slotcomp, proofs;
     TblPlan p1, p1b, p1t, p2, p3;   // p1t: B_t, B_u — the two commitments of phase 1 over per-proof tables, on the table stream
     std::vector<std::unique_ptr<TblPlan>> ipa, smsm;
+    // fused log rounds (round.hip; options fused_rounds_max, fused_fix_wpw, fused_tbl_wpw): the plans above in proof-major order, one launch per round
+    bool fused = false;
+    DevBuf<TAcc> rpart;          // XYZZ partial sums of a round's MSM waves
+    DevBuf<uint32_t> rcount;     // [B] arrival counters
     // the last log rounds on materialised folded bases (late.hip; options late_rounds, late_min_batch)
     struct Late {
       bool on = false;

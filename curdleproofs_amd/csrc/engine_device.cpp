@@ -36,8 +36,8 @@ void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std:
   pl.nt = nt;
   pl.ntt = ntt;
   pl.nft = nft;
-  pl.fix_wpw = msm_fix_windows_per_wave(opt_, (int)nft, fix_bits_);
-  pl.tbl_wpw = msm_tblw_windows_per_wave(opt_, (int)ntt);
+  pl.fix_wpw = pl.force_fix_wpw ? pl.force_fix_wpw : msm_fix_windows_per_wave(opt_, (int)nft, fix_bits_);
+  pl.tbl_wpw = pl.force_tbl_wpw ? pl.force_tbl_wpw : msm_tblw_windows_per_wave(opt_, (int)ntt);
   const uint32_t fix_parts = (uint32_t)msm_fix_parts(fix_bits_, pl.fix_wpw), tbl_parts = (uint32_t)msm_tblw_parts(pl.tbl_wpw);
   std::vector<TblTask> ht(ntt);
   std::vector<FixTask> hf(nft);
@@ -89,8 +89,10 @@ void Engine::build_plan(TblPlan& pl, const std::vector<TblReq>& reqs, const std:
   // Long tasks first: a work-group's task is its index in these arrays, partial-sum slots travel with the task (out_first / pad).  With the
   // requests in protocol order a launch ended with the long waves of the last proofs and the GPU drained behind them (~0.8 ms of a
   // 7.6-ms k_msm_fix launch at 8192 proofs); now the one-point tasks fill the tail.
-  std::stable_sort(hf.begin(), hf.end(), [](const FixTask& a, const FixTask& b) { return a.n > b.n; });
-  std::stable_sort(ht.begin(), ht.end(), [](const TblTask& a, const TblTask& b) { return a.seg[0].n + a.seg[1].n > b.seg[0].n + b.seg[1].n; });
+  if (!pl.keep_order) {
+    std::stable_sort(hf.begin(), hf.end(), [](const FixTask& a, const FixTask& b) { return a.n > b.n; });
+    std::stable_sort(ht.begin(), ht.end(), [](const TblTask& a, const TblTask& b) { return a.seg[0].n + a.seg[1].n > b.seg[0].n + b.seg[1].n; });
+  }
   pl.nparts = nparts;
   pl.fix_sets = nft * fix_parts;
   pl.tbl_sets = ntt * tbl_parts;
@@ -352,6 +354,11 @@ void Engine::prepare_device_prover() {
   const size_t late_min = n <= 256 ? (size_t)opt_.late_min_batch : std::max<size_t>(1, (size_t)opt_.late_min_batch * 256 / n);
   lt.on = opt_.late_rounds == 4 && L >= 5 && B >= late_min && late_supported((int)n, lt.m) && 4 * lt.m <= 64;
   lt.j0 = lt.on ? L - 4 : L;
+  // fused log rounds (round.hip): every round of both arguments is ONE launch — for the batches in which a round is a chain of latency-bound
+  // kernels (below the late rounds' threshold; the 16-bit table of multiples)
+  const size_t fused_max = n <= 256 ? (size_t)opt_.fused_rounds_max : (size_t)opt_.fused_rounds_max * 256 / n;
+  dp.fused = opt_.fused_rounds_max > 0 && B <= fused_max && !lt.on && fix_bits_ == 16 && !opt_.serial_streams &&
+             round_fused_supported((int)opt_.fused_fix_wpw, 0, true) && round_fused_supported(opt_.fused_fix_wpw == 4 ? 8 : (int)opt_.fused_fix_wpw, (int)opt_.fused_tbl_wpw, false);
   for (size_t j = 0; j < L; j++) {
     if (j >= lt.j0) {   // placeholders: exec_late_round takes these rounds
       dp.ipa.emplace_back(nullptr);
@@ -365,20 +372,36 @@ void Engine::prepare_device_prover() {
       ((k & half) ? ghi : glo).push_back(gb[k]);
     }
     const uint32_t *d_hi = idx_list(hi), *d_lo = idx_list(lo), *d_ghi = idx_list(ghi), *d_glo = idx_list(glo);
+    // (fused rounds: the H term of L_C / R_C rides in the same fixed-base task as the n/2 bases — one more column of the gather list, the
+    // scalar beta <c, d> follows the n/2 cross-term scalars in memory anyway — instead of a one-point task of its own: 4 tasks per proof)
+    const uint32_t *d_hiH = nullptr, *d_loH = nullptr;
+    if (dp.fused) {
+      std::vector<uint32_t> hiH(hi), loH(lo);
+      hiH.push_back((uint32_t)n);
+      loH.push_back((uint32_t)n);
+      d_hiH = idx_list(hiH);
+      d_loH = idx_list(loH);
+    }
     reqs.clear();
     ci.clear();
     for (size_t p = 0; p < B; p++) {
       const Fr* o = d_rout_.p + p * per;   // [L_C (hn), beta<c_L,d_R> | L_D (hn) | R_C (hn), beta<c_R,d_L> | R_D (hn)]
-      reqs.push_back(req(cseg(0, (uint32_t)hn, d_hi), cseg(0, 1, iH), o));
+      if (dp.fused) reqs.push_back(req(cseg(0, (uint32_t)hn + 1, d_hiH), none, o));
+      else reqs.push_back(req(cseg(0, (uint32_t)hn, d_hi), cseg(0, 1, iH), o));
       ci.push_back(cidx(p, sm.LC((int)j)));
       reqs.push_back(req(cseg(0, (uint32_t)hn, d_lo), none, o + hn + 1));
       ci.push_back(cidx(p, sm.LD((int)j)));
-      reqs.push_back(req(cseg(0, (uint32_t)hn, d_lo), cseg(0, 1, iH), o + 2 * hn + 1));
+      if (dp.fused) reqs.push_back(req(cseg(0, (uint32_t)hn + 1, d_loH), none, o + 2 * hn + 1));
+      else reqs.push_back(req(cseg(0, (uint32_t)hn, d_lo), cseg(0, 1, iH), o + 2 * hn + 1));
       ci.push_back(cidx(p, sm.RC((int)j)));
       reqs.push_back(req(cseg(0, (uint32_t)hn, d_hi), none, o + 3 * hn + 2));
       ci.push_back(cidx(p, sm.RD((int)j)));
     }
     dp.ipa.emplace_back(new TblPlan());
+    if (dp.fused) {
+      dp.ipa.back()->keep_order = true;
+      dp.ipa.back()->force_fix_wpw = (int)opt_.fused_fix_wpw;
+    }
     build_plan(*dp.ipa.back(), reqs, ci);
     reqs.clear();
     ci.clear();
@@ -399,6 +422,11 @@ void Engine::prepare_device_prover() {
       ci.push_back(cidx(p, sm.RU((int)j)));
     }
     dp.smsm.emplace_back(new TblPlan());
+    if (dp.fused) {
+      dp.smsm.back()->keep_order = true;
+      dp.smsm.back()->force_fix_wpw = opt_.fused_fix_wpw == 4 ? 8 : (int)opt_.fused_fix_wpw;
+      dp.smsm.back()->force_tbl_wpw = (int)opt_.fused_tbl_wpw;
+    }
     build_plan(*dp.smsm.back(), reqs, ci);
   }
   if (lt.on) {
@@ -512,6 +540,10 @@ void Engine::prepare_device_prover() {
     for (auto& pl : dp.smsm)
       if (pl) upd(*pl);
     if (lt.on) max_parts = std::max(max_parts, 6 * B);
+    if (dp.fused) {
+      dp.rpart.ensure(max_parts);
+      dp.rcount.ensure(B);
+    }
     d_tpart_.ensure(max_parts);
     ensure_raw_sets(max_sets);
     d_tbltmp_.ensure(B * NP * (size_t)(copies_ / 2 - 1));
@@ -629,7 +661,45 @@ void Engine::enqueue_prove_device() {
   //    bases: late.hip)
   const DevProver::Late& lt = dp.late;
   const size_t BM = B * (size_t)lt.m;
-  for (size_t j = 0; j < L; j++) {
+  // fused rounds (round.hip): the descriptor of a round's launch from its plan (the scratch pointers are read at enqueue time: a later
+  // batch of another shape may have regrown them)
+  auto round_dev = [&](const TblPlan& pl, int nreq, bool last) {
+    RoundDev rd{};
+    rd.ftasks = pl.ftasks.p;
+    rd.ttasks = pl.ttasks.p;
+    rd.nf = (int)(pl.nft / B);
+    rd.nt = (int)(pl.ntt / B);
+    rd.fix_wpw = pl.fix_wpw;
+    rd.tbl_wpw = rd.nt ? pl.tbl_wpw : 0;
+    rd.wpp = (uint32_t)(rd.nf * (16 / pl.fix_wpw) + (rd.nt ? rd.nt * (32 / pl.tbl_wpw) : 0));
+    rd.nreq = nreq;
+    rd.nproofs = Bi;
+    rd.max_count = (uint32_t)std::max(16 / pl.fix_wpw, rd.nt ? 64 / pl.tbl_wpw : 0);
+    rd.next_scalars = last ? 0 : 1;
+    rd.fixtab = fixtab();
+    rd.nc = (int)nc();
+    rd.fraw = d_raw_.p;
+    rd.fraw_slot = d_rawslot_.p;
+    rd.traw = d_raw_.p + pl.fix_sets * raw_set_words();
+    rd.traw_slot = d_rawslot_.p + pl.fix_sets;
+    rd.part = dp.rpart.p;
+    rd.meta = pl.meta.p;
+    rd.comp_index = pl.meta.p + 3 * pl.nt;
+    rd.counter = dp.rcount.p;
+    rd.scal_out = d_rout_.p;
+    return rd;
+  };
+  if (dp.fused) {
+    CPX_HIP(hipMemsetAsync(dp.rcount.p, 0, B * sizeof(uint32_t), stream_));
+    launch_ipa_round_scalars(d_rvec_.p, Bi, (int)n, (int)(n >> 1), d_rbeta_.p, d_rout_.p, stream_);   // round 0's scalars; every later round's come from the tail before it
+    for (size_t j = 0; j < L; j++) {
+      const TblPlan& pl = *dp.ipa[j];
+      tick("k_round_fused<ipa>", 128.0 * pl.pts_fix, pl.pts_fix);
+      launch_round_fused(round_dev(pl, 4, j + 1 == L), d, (int)j, true, stream_);
+      tock();
+    }
+  }
+  for (size_t j = 0; j < L && !dp.fused; j++) {
     const int half = (int)(n >> (j + 1));
     if (lt.on && j == lt.j0) {   // G^(j0) and G'^(j0) from the table of multiples (fold coefficients S_G, S_G' = u o S^-1), their small multiples
       tick("k_late_fix", 128.0 * 2 * n * B, (double)(2 * n * B));
@@ -657,7 +727,16 @@ void Engine::enqueue_prove_device() {
   CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_d, 0));
   if (tabs != stream_) CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_t2, 0));   // B_t, B_u in the slot registry
   launch_ps_smsm_setup(d, Bi, stream_);
-  for (size_t j = 0; j < L; j++) {
+  if (dp.fused) {
+    launch_smsm_round_scalars(dp.rvec2.p, Bi, (int)n, (int)(n >> 1), d_rout_.p, stream_);
+    for (size_t j = 0; j < L; j++) {
+      const TblPlan& pl = *dp.smsm[j];
+      tick("k_round_fused<smsm>", 128.0 * (pl.pts_fix + pl.pts_tbl), pl.pts_fix + pl.pts_tbl);
+      launch_round_fused(round_dev(pl, 6, j + 1 == L), d, (int)j, false, stream_);
+      tock();
+    }
+  }
+  for (size_t j = 0; j < L && !dp.fused; j++) {
     const int half = (int)(n >> (j + 1));
     if (lt.on && j == lt.j0) {   // T_b^(j0), U_b^(j0), G_b^(j0): one shared digit sequence per proof (fold coefficients S_M)
       // (T_b, U_b with two lanes per output fill a wave; G_b then comes from the table of multiples like G and G')

@@ -48,6 +48,9 @@ struct Options {
   long p1_split = 1;               // 1: phase 1 without A (it only needs the prover's randomness) runs before the main stream waits for the transcript prefix, A alone behind it: 128 proofs 41.7 -> 40.6 ms per pass, nothing at 8192
   long serial_streams = 0;         // 1 (measurement aid): the side stream's kernels run in line on the main stream — every kernel's duration is its own
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
+  long fused_rounds_max = 2048;    // batches of up to this many proofs (n <= 256; scaled by 256 / n above) run every log round as ONE launch (round.hip); 0: the chain of separate kernels
+  long fused_fix_wpw = 8;          // windows per fixed-base wave of a fused round (4 | 8 | 16; IPA rounds: 4 allowed)
+  long fused_tbl_wpw = 16;         // windows per table wave of a fused SameMSM round (8 | 16 | 32)
   long strict_infinity = 0;        // point encodings with the infinity flag set: 0 = the identity whatever the other 382 bits say (ark-bls12-381 ^0.4 `read_g1_compressed`, as recalled: include/cpx.h), 1 = only 0xc0 || 0^47 (the zcash specification's wording; ark-bls12-381 0.5)
   long scale_any_point = 0;        // 1: cpx_g1_scale / cpx_g1_fold take ANY point of E(Fp) (plain 257-step double-and-add, SMUL_PLAIN); 0: points of the order-r subgroup (endomorphism split, 129 steps)
 };
@@ -236,6 +239,31 @@ void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, siz
 void launch_late_tables(const TJac* d_jac, TAff* d_tab, TblTmp* d_tmp, int npoints, hipStream_t s);
 void launch_late_msm(const LateRound& r, hipStream_t s);
 void launch_late_restart(Fr* d_vec, int n, int m, int nproofs, hipStream_t s);
+
+// ---- fused log rounds (round.hip): one launch per round of the IPA / SameMSM argument for small and mid-size batches ----
+// grid = nproofs x wpp single-wave work-groups: per proof nf fixed-base tasks (16 / fix_wpw waves each) followed by nt table tasks
+// (32 / tbl_wpw waves each), tasks in proof-major order.  Every wave reduces its own lane accumulators and leaves one XYZZ partial sum
+// per set; the last wave of a proof to arrive adds them per request, finalises, hashes, draws the challenge and folds.
+struct ProveDev;
+struct RoundDev {
+  const FixTask* ftasks;        // [nproofs][nf]
+  const TblTask* ttasks;        // [nproofs][nt]
+  int nf, nt, fix_wpw, tbl_wpw;
+  uint32_t wpp;                 // waves per proof
+  int nreq, nproofs;            // requests (cross terms) per proof: 4 (IPA) or 6 (SameMSM)
+  uint32_t max_count;           // most partial sums of a request (<= 8)
+  int next_scalars;             // 1: the tail also writes the next round's cross-term scalars to scal_out
+  const TFix* fixtab;
+  int nc;
+  uint32_t *fraw, *fraw_slot, *traw, *traw_slot;   // raw sets of the fixed-base waves (one each) and of the table waves (two each)
+  TAcc* part;                   // partial sums, indexed like the plan's partial slots
+  const uint32_t* meta;         // [2][nproofs * nreq]: first partial | partial count of every request
+  const uint32_t* comp_index;   // [nproofs * nreq]: slot-registry index of every request's 48-byte encoding
+  uint32_t* counter;            // [nproofs] arrival counters, zero between launches
+  Fr* scal_out;                 // the cross-term scalars of a round (IPA: [nproofs][2 n + 2], SameMSM: [nproofs][n])
+};
+bool round_fused_supported(int fix_wpw, int tbl_wpw, bool ipa);
+void launch_round_fused(const RoundDev& rd, const ProveDev& d, int j, bool ipa, hipStream_t s);
 
 void launch_sum_jac(const Jac* d_in, int n, Jac* d_out, int* d_flag, hipStream_t s);
 void launch_bench_fpmul(Fp* d_data, int blocks, int iters, hipStream_t s);

@@ -630,10 +630,16 @@ VARIANTS = {
     "fix8": {"fix_bits": 8},
     "fix19": {"fix_bits": 19},                                  # 14 windows of 19 bits, 122 GB table at ell = 252 (falls back to 16 when HBM is short)
     "fix19_late_rounds_throughput_kernels": {"fix_bits": 19, "late_min_batch": 1, "device_min_batch": 1, "fix_min_waves": 1, "reduce_wave_max": 0},
-    "device_resident": {"device_min_batch": 1},
+    "device_resident": {"device_min_batch": 1},                 # (log rounds fused, round.hip: the default up to 2048 proofs)
+    # the log rounds as ONE launch each (round.hip: MSM waves that reduce their own accumulators, the last arriver of a proof finalises, hashes,
+    # draws the challenge and folds) in every wave shape the launcher offers, and switched off (the chain of separate kernels)
+    "device_resident_unfused_rounds": {"device_min_batch": 1, "fused_rounds_max": 0},
+    "fused_rounds_four_windows_per_fixed_wave": {"device_min_batch": 1, "fused_fix_wpw": 4},
+    "fused_rounds_whole_tasks_per_wave": {"device_min_batch": 1, "fused_fix_wpw": 16, "fused_tbl_wpw": 32},
+    "fused_rounds_eight_windows_per_table_wave": {"device_min_batch": 1, "fused_tbl_wpw": 8},
     "host_driven": {"device_min_batch": 1000000},
     "throughput_kernels": THROUGHPUT,
-    "throughput_kernels_device_resident": dict(THROUGHPUT, device_min_batch=1),
+    "throughput_kernels_device_resident": dict(THROUGHPUT, device_min_batch=1, fused_rounds_max=0),
     "four_point_slices_host_driven": {"tbw_slices": 4, "device_min_batch": 1000000},
     "two_point_slices_thread_tail": {"tbw_slices": 2, "tail_wave_max": 0},
     "plain_streams_wave_kernels_everywhere": {"cu_mask": 0, "reduce_wave_max": 1000000, "finalize_wave_max": 1000000},

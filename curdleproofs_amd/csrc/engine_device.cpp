@@ -424,8 +424,8 @@ void Engine::prepare_device_prover() {
     dp.smsm.emplace_back(new TblPlan());
     if (dp.fused) {
       dp.smsm.back()->keep_order = true;
-      dp.smsm.back()->force_fix_wpw = opt_.fused_fix_wpw == 4 ? 8 : (int)opt_.fused_fix_wpw;
-      dp.smsm.back()->force_tbl_wpw = (int)opt_.fused_tbl_wpw;
+      dp.smsm.back()->force_fix_wpw = opt_.fused_combine ? 4 : opt_.fused_fix_wpw == 4 ? 8 : (int)opt_.fused_fix_wpw;
+      dp.smsm.back()->force_tbl_wpw = opt_.fused_combine ? 16 : (int)opt_.fused_tbl_wpw;
     }
     build_plan(*dp.smsm.back(), reqs, ci);
   }
@@ -671,7 +671,8 @@ void Engine::enqueue_prove_device() {
     rd.nt = (int)(pl.ntt / B);
     rd.fix_wpw = pl.fix_wpw;
     rd.tbl_wpw = rd.nt ? pl.tbl_wpw : 0;
-    rd.wpp = (uint32_t)(rd.nf * (16 / pl.fix_wpw) + (rd.nt ? rd.nt * (32 / pl.tbl_wpw) : 0));
+    rd.combine = (rd.nt && opt_.fused_combine && pl.fix_wpw == 4 && pl.tbl_wpw == 16 && rd.nf * 4 == rd.nt * 2) ? 1 : 0;
+    rd.wpp = rd.combine ? (uint32_t)(rd.nt * 2) : (uint32_t)(rd.nf * (16 / pl.fix_wpw) + (rd.nt ? rd.nt * (32 / pl.tbl_wpw) : 0));
     rd.nreq = nreq;
     rd.nproofs = Bi;
     rd.max_count = (uint32_t)std::max(16 / pl.fix_wpw, rd.nt ? 64 / pl.tbl_wpw : 0);

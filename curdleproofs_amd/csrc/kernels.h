@@ -51,6 +51,7 @@ struct Options {
   long fused_rounds_max = 2048;    // batches of up to this many proofs (n <= 256; scaled by 256 / n above) run every log round as ONE launch (round.hip); 0: the chain of separate kernels
   long fused_fix_wpw = 8;          // windows per fixed-base wave of a fused round (4 | 8 | 16; IPA rounds: 4 allowed)
   long fused_tbl_wpw = 16;         // windows per table wave of a fused SameMSM round (8 | 16 | 32)
+  long fused_combine = 1;          // 1: a SameMSM wave of a fused round runs a fixed-base block (4 windows) and a table block (16 windows): 8 waves per proof instead of 12
   long strict_infinity = 0;        // point encodings with the infinity flag set: 0 = the identity whatever the other 382 bits say (ark-bls12-381 ^0.4 `read_g1_compressed`, as recalled: include/cpx.h), 1 = only 0xc0 || 0^47 (the zcash specification's wording; ark-bls12-381 0.5)
   long scale_any_point = 0;        // 1: cpx_g1_scale / cpx_g1_fold take ANY point of E(Fp) (plain 257-step double-and-add, SMUL_PLAIN); 0: points of the order-r subgroup (endomorphism split, 129 steps)
 };
@@ -253,6 +254,7 @@ struct RoundDev {
   int nreq, nproofs;            // requests (cross terms) per proof: 4 (IPA) or 6 (SameMSM)
   uint32_t max_count;           // most partial sums of a request (<= 8)
   int next_scalars;             // 1: the tail also writes the next round's cross-term scalars to scal_out
+  int combine;                  // 1 (SameMSM, fix_wpw 4, tbl_wpw 16): wave w of a proof runs fixed-base block w and table block w; wpp = nt * 2
   const TFix* fixtab;
   int nc;
   uint32_t *fraw, *fraw_slot, *traw, *traw_slot;   // raw sets of the fixed-base waves (one each) and of the table waves (two each)

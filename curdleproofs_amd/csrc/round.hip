@@ -221,28 +221,34 @@ template <bool IPA> __device__ void round_tail(const RoundDev& rd, const ProveDe
 
 }  // namespace
 
-// FW: windows per fixed-base wave (16 / FW waves per task); TW: windows per table wave (32 / TW waves per task; 0: no table tasks)
-template <int FW, int TW, bool IPA> __global__ __launch_bounds__(64, 2) void k_round_fused(const RoundDev rd, const ProveDev d, int j) {
+// FW: windows per fixed-base wave (16 / FW waves per task); TW: windows per table wave (32 / TW waves per task; 0: no table tasks).
+// COMBINE (SameMSM rounds of a batch that does not fill the GPU): nf * (16 / FW) == nt * (32 / TW) and wave w of a proof runs fixed-base
+// block w AND table block w, one after the other — as many waves per proof as SIMDs per proof (128 proofs: 8), none shares a SIMD with
+// another (a lone chain beside a second wave takes 1.7 times as long, and the slowest wave is the round).
+template <int FW, int TW, bool IPA, bool COMBINE = false> __global__ __launch_bounds__(64, 2) void k_round_fused(const RoundDev rd, const ProveDev d, int j) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t FWG = 16 / FW;
   const uint32_t bid = blockIdx.x, p = bid / rd.wpp, w = bid % rd.wpp;
   const uint32_t nfw = (uint32_t)rd.nf * FWG;
   const int lane = threadIdx.x;
   TAcc* buf = reinterpret_cast<TAcc*>(smem);
-  if (w < nfw) {
+  if (COMBINE || w < nfw) {
     const uint32_t bf = p * nfw + w;
     msm_fix_body<16, FW>(rd.ftasks, rd.fixtab, rd.nc, rd.fraw, rd.fraw_slot, bf);
     tail_sync();
     const uint32_t slot = rd.ftasks[bf / FWG].out_first + bf % FWG;
     reduce_set_inwave(rd.fraw + (size_t)bf * RAW_SET_WORDS, 0, buf, rd.part + slot);
-  } else if constexpr (TW != 0) {
-    constexpr uint32_t TWV = 32 / TW;
-    const uint32_t ntw = (uint32_t)rd.nt * TWV, bt = p * ntw + (w - nfw);
-    msm_tblw_body<TW, false>(rd.ttasks, rd.traw, rd.traw_slot, 1, bt);
-    tail_sync();
-    const uint32_t slot = rd.ttasks[bt / TWV].pad + 2 * (bt % TWV);
-    reduce_set_inwave(rd.traw + (size_t)bt * 2 * RAW_SET_WORDS, 1, buf, rd.part + slot);
-    reduce_set_inwave(rd.traw + ((size_t)bt * 2 + 1) * RAW_SET_WORDS, 2, buf, rd.part + slot + 1);
+  }
+  if constexpr (TW != 0) {
+    if (COMBINE || w >= nfw) {
+      constexpr uint32_t TWV = 32 / TW;
+      const uint32_t ntw = (uint32_t)rd.nt * TWV, bt = p * ntw + (COMBINE ? w : w - nfw);
+      msm_tblw_body<TW, false>(rd.ttasks, rd.traw, rd.traw_slot, 1, bt);
+      tail_sync();
+      const uint32_t slot = rd.ttasks[bt / TWV].pad + 2 * (bt % TWV);
+      reduce_set_inwave(rd.traw + (size_t)bt * 2 * RAW_SET_WORDS, 1, buf, rd.part + slot);
+      reduce_set_inwave(rd.traw + ((size_t)bt * 2 + 1) * RAW_SET_WORDS, 2, buf, rd.part + slot + 1);
+    }
   }
   // arrival: the partial sums above are released before the count, the last arriver acquires them
   __threadfence();
@@ -265,6 +271,7 @@ template <int FW, int TW, bool IPA> __global__ __launch_bounds__(64, 2) void k_r
 
 bool round_fused_supported(int fix_wpw, int tbl_wpw, bool ipa) {
   if (ipa) return tbl_wpw == 0 && (fix_wpw == 4 || fix_wpw == 8 || fix_wpw == 16);
+  if (fix_wpw == 4 && tbl_wpw == 16) return true;   // combined waves (RoundDev::combine)
   return (fix_wpw == 8 || fix_wpw == 16) && (tbl_wpw == 8 || tbl_wpw == 16 || tbl_wpw == 32);
 }
 size_t round_fused_lds(int tbl_wpw) {
@@ -286,6 +293,11 @@ void launch_round_fused(const RoundDev& rd, const ProveDev& d, int j, bool ipa, 
   }
 #define CASE(F, T) \
   if (rd.fix_wpw == F && rd.tbl_wpw == T) { ROUND_LAUNCH((k_round_fused<F, T, false>), grid, block, lds, s, rd, d, j); return; }
+  if (rd.combine) {   // wave w = fixed-base block w + table block w (4 windows of a CRS task, 16 windows of a table task)
+    if (rd.fix_wpw != 4 || rd.tbl_wpw != 16 || rd.nf * 4 != rd.nt * 2) throw std::invalid_argument("launch_round_fused: combined waves need 4 / 16 windows per wave");
+    ROUND_LAUNCH((k_round_fused<4, 16, false, true>), grid, block, lds, s, rd, d, j);
+    return;
+  }
   CASE(8, 8) CASE(8, 16) CASE(8, 32) CASE(16, 8) CASE(16, 16) CASE(16, 32)
 #undef CASE
 }

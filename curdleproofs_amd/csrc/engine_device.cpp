@@ -357,8 +357,13 @@ void Engine::prepare_device_prover() {
   // fused log rounds (round.hip): every round of both arguments is ONE launch — for the batches in which a round is a chain of latency-bound
   // kernels (below the late rounds' threshold; the 16-bit table of multiples)
   const size_t fused_max = n <= 256 ? (size_t)opt_.fused_rounds_max : (size_t)opt_.fused_rounds_max * 256 / n;
-  dp.fused = opt_.fused_rounds_max > 0 && B <= fused_max && !lt.on && fix_bits_ == 16 && !opt_.serial_streams &&
-             round_fused_supported((int)opt_.fused_fix_wpw, 0, true) && round_fused_supported(opt_.fused_fix_wpw == 4 ? 8 : (int)opt_.fused_fix_wpw, (int)opt_.fused_tbl_wpw, false);
+  dp.fused = opt_.fused_rounds_max > 0 && B <= fused_max && !lt.on && fix_bits_ == 16 && !opt_.serial_streams;
+  // wave shapes of the fused rounds: as many waves per proof as find a SIMD of their own (1024 SIMDs; proofs of n > 256 take n / 256 times the work)
+  const size_t simd_share = 1024 * 256 / (B * std::max<size_t>(n, 256));   // SIMDs per proof
+  const int f_fix_ipa = opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : (simd_share >= 16 ? 4 : 8);
+  const bool f_combine = opt_.fused_combine >= 0 ? opt_.fused_combine != 0 : simd_share < 12;
+  const int f_fix_smsm = f_combine ? 4 : std::max(8, opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : 8), f_tbl_smsm = f_combine ? 16 : (int)opt_.fused_tbl_wpw;
+  dp.fused = dp.fused && round_fused_supported(f_fix_ipa, 0, true) && round_fused_supported(f_fix_smsm, f_tbl_smsm, false);
   for (size_t j = 0; j < L; j++) {
     if (j >= lt.j0) {   // placeholders: exec_late_round takes these rounds
       dp.ipa.emplace_back(nullptr);
@@ -400,7 +405,7 @@ void Engine::prepare_device_prover() {
     dp.ipa.emplace_back(new TblPlan());
     if (dp.fused) {
       dp.ipa.back()->keep_order = true;
-      dp.ipa.back()->force_fix_wpw = (int)opt_.fused_fix_wpw;
+      dp.ipa.back()->force_fix_wpw = f_fix_ipa;
     }
     build_plan(*dp.ipa.back(), reqs, ci);
     reqs.clear();
@@ -424,8 +429,8 @@ void Engine::prepare_device_prover() {
     dp.smsm.emplace_back(new TblPlan());
     if (dp.fused) {
       dp.smsm.back()->keep_order = true;
-      dp.smsm.back()->force_fix_wpw = opt_.fused_combine ? 4 : opt_.fused_fix_wpw == 4 ? 8 : (int)opt_.fused_fix_wpw;
-      dp.smsm.back()->force_tbl_wpw = opt_.fused_combine ? 16 : (int)opt_.fused_tbl_wpw;
+      dp.smsm.back()->force_fix_wpw = f_fix_smsm;
+      dp.smsm.back()->force_tbl_wpw = f_tbl_smsm;
     }
     build_plan(*dp.smsm.back(), reqs, ci);
   }
@@ -671,7 +676,7 @@ void Engine::enqueue_prove_device() {
     rd.nt = (int)(pl.ntt / B);
     rd.fix_wpw = pl.fix_wpw;
     rd.tbl_wpw = rd.nt ? pl.tbl_wpw : 0;
-    rd.combine = (rd.nt && opt_.fused_combine && pl.fix_wpw == 4 && pl.tbl_wpw == 16 && rd.nf * 4 == rd.nt * 2) ? 1 : 0;
+    rd.combine = (rd.nt && pl.fix_wpw == 4 && pl.tbl_wpw == 16 && rd.nf * 4 == rd.nt * 2) ? 1 : 0;   // (4 / 16 windows per wave are only planned for combined waves)
     rd.wpp = rd.combine ? (uint32_t)(rd.nt * 2) : (uint32_t)(rd.nf * (16 / pl.fix_wpw) + (rd.nt ? rd.nt * (32 / pl.tbl_wpw) : 0));
     rd.nreq = nreq;
     rd.nproofs = Bi;

@@ -48,10 +48,13 @@ struct Options {
   long p1_split = 1;               // 1: phase 1 without A (it only needs the prover's randomness) runs before the main stream waits for the transcript prefix, A alone behind it: 128 proofs 41.7 -> 40.6 ms per pass, nothing at 8192
   long serial_streams = 0;         // 1 (measurement aid): the side stream's kernels run in line on the main stream — every kernel's duration is its own
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
-  long fused_rounds_max = 2048;    // batches of up to this many proofs (n <= 256; scaled by 256 / n above) run every log round as ONE launch (round.hip); 0: the chain of separate kernels
-  long fused_fix_wpw = 8;          // windows per fixed-base wave of a fused round (4 | 8 | 16; IPA rounds: 4 allowed)
+  long fused_rounds_max = 160;     // batches of up to this many proofs (n <= 256; scaled by 256 / n above) run every log round as ONE launch (round.hip); 0: the chain of
+                                   // separate kernels.  The in-wave reductions of a fused round pay while its waves have SIMDs of their own (128 proofs x 8 waves = the
+                                   // GPU's 1024): 64 proofs 24.4 -> 22.4 ms per pass, 128: 29.0 -> 27.3, 192: 34.5 -> 34.8, 256: 38.0 -> 43.9
+  long fused_fix_wpw = 0;          // windows per fixed-base wave of a fused round: 4 | 8 | 16, 0 = by the batch (4 while 16 waves per proof fit the SIMDs, else 8)
   long fused_tbl_wpw = 16;         // windows per table wave of a fused SameMSM round (8 | 16 | 32)
-  long fused_combine = 1;          // 1: a SameMSM wave of a fused round runs a fixed-base block (4 windows) and a table block (16 windows): 8 waves per proof instead of 12
+  long fused_combine = -1;         // 1: a SameMSM wave of a fused round runs a fixed-base block (4 windows) and a table block (16 windows): 8 waves per proof instead of
+                                   // 12; 0: separate waves; -1 = by the batch (combined from 86 proofs on: 12 waves per proof no longer find a SIMD each)
   long strict_infinity = 0;        // point encodings with the infinity flag set: 0 = the identity whatever the other 382 bits say (ark-bls12-381 ^0.4 `read_g1_compressed`, as recalled: include/cpx.h), 1 = only 0xc0 || 0^47 (the zcash specification's wording; ark-bls12-381 0.5)
   long scale_any_point = 0;        // 1: cpx_g1_scale / cpx_g1_fold take ANY point of E(Fp) (plain 257-step double-and-add, SMUL_PLAIN); 0: points of the order-r subgroup (endomorphism split, 129 steps)
 };

@@ -1247,8 +1247,8 @@ const OptField kOptFields[] = {
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
     {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
     {"scale_any_point", &Options::scale_any_point, 0, 1},         {"strict_infinity", &Options::strict_infinity, 0, 1},
-    {"fused_rounds_max", &Options::fused_rounds_max, 0, 1L << 30}, {"fused_fix_wpw", &Options::fused_fix_wpw, 4, 16},
-    {"fused_tbl_wpw", &Options::fused_tbl_wpw, 8, 32},             {"fused_combine", &Options::fused_combine, 0, 1},
+    {"fused_rounds_max", &Options::fused_rounds_max, 0, 1L << 30}, {"fused_fix_wpw", &Options::fused_fix_wpw, 0, 16},
+    {"fused_tbl_wpw", &Options::fused_tbl_wpw, 8, 32},             {"fused_combine", &Options::fused_combine, -1, 1},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;
@@ -1257,7 +1257,7 @@ bool option_value_ok(const OptField& f, long v) {
   if (!strcmp(f.key, "fix_bits")) return v == 8 || v == 16 || v == 19;
   if (!strcmp(f.key, "late_rounds")) return v == 0 || v == 4;
   if (!strcmp(f.key, "late_slices")) return v == 1 || v == 2 || v == 4 || v == 8;
-  if (!strcmp(f.key, "fused_fix_wpw")) return v == 4 || v == 8 || v == 16;
+  if (!strcmp(f.key, "fused_fix_wpw")) return v == 0 || v == 4 || v == 8 || v == 16;
   if (!strcmp(f.key, "fused_tbl_wpw")) return v == 8 || v == 16 || v == 32;
   return true;
 }

@@ -651,7 +651,7 @@ void Engine::enqueue_prove_device() {
   }
   CPX_HIP(hipStreamWaitEvent(side, dp.ev_c, 0));
   tick("k_smul", 0, (double)(4 * B));
-  launch_smul(side_.stasks.p, 4 * Bi, 1, side, /*exclusive_simd=*/side != stream_);   // (a small batch: at most 16 waves, each on a SIMD of its own)
+  launch_smul(side_.stasks.p, 4 * Bi, 1, side, /*exclusive_simd=*/side != stream_, opt_.serial_streams ? 0 : opt_.smul_quad_max);   // (a small batch: at most 16 waves, each on a SIMD of its own)
   tock();
   launch_compress_cols(d_pp_.p + 4 * ell, dp.side_cols, 6, (int)pp_stride_, Bi, dp.slotcomp.p, (int)NS, side);
   CPX_HIP(hipEventRecord(dp.ev_d, side));

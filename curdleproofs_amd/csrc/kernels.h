@@ -55,6 +55,7 @@ struct Options {
   long fused_tbl_wpw = 16;         // windows per table wave of a fused SameMSM round (8 | 16 | 32)
   long fused_combine = -1;         // 1: a SameMSM wave of a fused round runs a fixed-base block (4 windows) and a table block (16 windows): 8 waves per proof instead of
                                    // 12; 0: separate waves; -1 = by the batch (combined from 86 proofs on: 12 waves per proof no longer find a SIMD each)
+  long smul_quad_max = 1024;       // the prover's T_2 scalar multiplications of a batch of up to this many elements (4 per proof) run with a quad per element (k_smul_quad)
   long strict_infinity = 0;        // point encodings with the infinity flag set: 0 = the identity whatever the other 382 bits say (ark-bls12-381 ^0.4 `read_g1_compressed`, as recalled: include/cpx.h), 1 = only 0xc0 || 0^47 (the zcash specification's wording; ark-bls12-381 0.5)
   long scale_any_point = 0;        // 1: cpx_g1_scale / cpx_g1_fold take ANY point of E(Fp) (plain 257-step double-and-add, SMUL_PLAIN); 0: points of the order-r subgroup (endomorphism split, 129 steps)
 };
@@ -195,7 +196,9 @@ void launch_compress(const Aff* d_in, int n, int stride, int batch, uint8_t* d_o
 // `batch` strided rows; only the columns d_cols[0..ncols) are compressed, each to the same column of the output row
 void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, int stride, int batch, uint8_t* d_out, int out_stride, hipStream_t s);
 // exclusive_simd (the T_2 commitments of a small batch on the side stream, at most 16 waves): every wave claims the whole register file of its SIMD
-void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s, bool exclusive_simd = false);
+// quad_max > 0: launches of at most that many elements run with a QUAD per element (k_smul_quad: a third of the one-lane chain's latency, four times its lanes);
+// only for tasks without SMUL_PLAIN
+void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s, bool exclusive_simd = false, long quad_max = 0);
 // compressed bytes -> affine; status[i] = 0 ok, 1 malformed / not on curve, 2 not in the r-torsion subgroup
 // d_src_offset (optional): encoding i starts at byte d_src_offset[i] of d_in (points inside serialized proofs) instead of 48 i
 void launch_decompress(const Options& o, const uint8_t* d_in, int n, Aff* d_out, const uint32_t* d_dst_index, uint8_t* d_status, int check_subgroup, hipStream_t s,

@@ -772,6 +772,104 @@ __global__ __launch_bounds__(SMUL_THREADS) void k_smul(const SmulTask* __restric
   *dst = inf ? Aff::identity() : t_to_std(t_to_affine(acc, zinv));
 }
 
+// The same per-element computation with a QUAD per element (g1_28_quad.hpp) — the T_2 commitments of a small batch on the side stream
+// (curdleproofs.rs:115-116, same_scalar_argument.rs:60-61): the one-lane form is a chain of 129 doublings + ~86 additions, 4.6 ms during which
+// its waves sit beside the log rounds of the main stream; four lanes per element finish a doubling in 4.4 us and an addition in 6.1 us, and the
+// two digit streams of the endomorphism split share ONE addition per step from the table {P, N P, P + N P, P - N P} and their negatives.
+// Per step all quads of the wave double, then all add (the identity where both digits are zero): uniform control flow, operands in LDS.
+constexpr int SQ_ACC = 0, SQ_TAB = 1, SQ_PER_QUAD = 9;   // per quad: the accumulator, +-P, +-NP, +-(P + NP), +-(P - NP)
+constexpr int SQ_IDENT = 16 * SQ_PER_QUAD;
+constexpr size_t SQ_LDS = (size_t)(SQ_IDENT + 1) * sizeof(TAcc) + 2 * 64 * sizeof(TF);
+__global__ __launch_bounds__(64) void k_smul_quad(const SmulTask* __restrict__ tasks, int ntasks, int cnt) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  TAcc* buf = reinterpret_cast<TAcc*>(smem);
+  TF* inv_buf = reinterpret_cast<TF*>(smem + (size_t)(SQ_IDENT + 1) * sizeof(TAcc));
+  const int lane = threadIdx.x, quad = lane >> 2, sub = lane & 3;
+  const long g = (long)blockIdx.x * 16 + quad, total = (long)ntasks * cnt;
+  const bool live = g < total;
+  TAcc* mine = buf + quad * SQ_PER_QUAD;
+  SmulNaf rn{};
+  Aff* dst = nullptr;
+  bool has_add = false;
+  if (live) {
+    const int t = (int)(g / cnt), e = (int)(g % cnt);
+    const SmulTask task = tasks[t];
+    dst = task.out + e;
+    Fr k = task.scalars[(size_t)e * task.scalar_stride];
+    if (!(task.flags & MSM_SCALARS_CANONICAL)) k = fe_from_mont(k);
+    recode_smul_glv(k.v, rn);   // (replicated over the quad: the four lanes take identical branches)
+    if (sub == 0) {
+      const TAff P = t_from_std(task.mul[e]);
+      const bool inf = P.is_identity();
+      const TAcc XP = inf ? TAcc::identity() : TAcc{P.x, P.y, t_one(), t_one()};
+      const TAcc XN = inf ? TAcc::identity() : TAcc{t_mul(P.x, t_beta()), t_neg(P.y), t_one(), t_one()};   // N P = -phi(P) (glv.hpp)
+      mine[SQ_ACC] = TAcc::identity();
+      mine[SQ_TAB + 0] = XP;
+      mine[SQ_TAB + 2] = XN;
+    }
+    has_add = task.add != nullptr;
+  } else if (sub == 0) {
+    mine[SQ_ACC] = mine[SQ_TAB + 0] = mine[SQ_TAB + 2] = TAcc::identity();
+  }
+  if (lane == 0) buf[SQ_IDENT] = TAcc::identity();
+  __syncthreads();
+  auto neg_of = [](const TAcc& a) { return a.is_identity() ? a : TAcc{a.x, t_neg(a.y), a.zz, a.zzz}; };
+  {   // P + N P, then P - N P and the four negatives
+    const TAcc sum = xyzz28_add_quad_mem(buf, quad * SQ_PER_QUAD + SQ_TAB + 0, quad * SQ_PER_QUAD + SQ_TAB + 2);
+    if (sub == 0) {
+      mine[SQ_TAB + 4] = sum;
+      mine[SQ_TAB + 1] = neg_of(mine[SQ_TAB + 0]);
+      mine[SQ_TAB + 3] = neg_of(mine[SQ_TAB + 2]);
+    }
+    __syncthreads();
+    const TAcc dif = xyzz28_add_quad_mem(buf, quad * SQ_PER_QUAD + SQ_TAB + 0, quad * SQ_PER_QUAD + SQ_TAB + 3);
+    if (sub == 0) {
+      mine[SQ_TAB + 6] = dif;
+      mine[SQ_TAB + 5] = neg_of(sum);
+      mine[SQ_TAB + 7] = neg_of(dif);
+    }
+    __syncthreads();
+  }
+  for (int i = 128; i >= 0; i--) {
+    const TAcc dbl = xyzz28_dbl_quad(buf[quad * SQ_PER_QUAD + SQ_ACC]);
+    if (sub == 0) mine[SQ_ACC] = dbl;
+    __syncthreads();
+    const int wd = i >> 5, bt = i & 31;
+    const int dt = ((rn.nz[0][wd] >> bt) & 1u) ? (((rn.ng[0][wd] >> bt) & 1u) ? -1 : 1) : 0;
+    const int dq = ((rn.nz[1][wd] >> bt) & 1u) ? (((rn.ng[1][wd] >> bt) & 1u) ? -1 : 1) : 0;
+    // table entry of dt P + dq N P: +P 0, -P 1, +NP 2, -NP 3, +(P+NP) 4, -(P+NP) 5, +(P-NP) 6, -(P-NP) 7
+    int e = -1;
+    if (dt && !dq) e = dt > 0 ? 0 : 1;
+    else if (!dt && dq) e = dq > 0 ? 2 : 3;
+    else if (dt && dq) e = dt == dq ? (dt > 0 ? 4 : 5) : (dt > 0 ? 6 : 7);
+    if (!__any(e >= 0)) continue;   // (uniform: no quad of the wave adds in this step)
+    const TAcc sum = xyzz28_add_quad_mem(buf, quad * SQ_PER_QUAD + SQ_ACC, e >= 0 ? quad * SQ_PER_QUAD + SQ_TAB + e : SQ_IDENT);
+    if (sub == 0) mine[SQ_ACC] = sum;
+    __syncthreads();
+  }
+  if (__any(has_add)) {   // + the affine addend (r H of a T_2 commitment)
+    if (sub == 0) {
+      TAcc a = TAcc::identity();
+      if (live && has_add) {
+        const int t = (int)(g / cnt), e = (int)(g % cnt);
+        const TAff A = t_from_std(tasks[t].add[e]);
+        if (!A.is_identity()) a = TAcc{A.x, A.y, t_one(), t_one()};
+      }
+      mine[SQ_TAB + 0] = a;
+    }
+    __syncthreads();
+    const TAcc sum = xyzz28_add_quad_mem(buf, quad * SQ_PER_QUAD + SQ_ACC, quad * SQ_PER_QUAD + SQ_TAB + 0);
+    if (sub == 0) mine[SQ_ACC] = sum;
+    __syncthreads();
+  }
+  // one inversion per wave; lane 0 of every quad writes its element
+  TJac pt = TJac::identity();
+  if (sub == 0) pt = t_acc_to_jac(mine[SQ_ACC]);
+  const bool inf = pt.is_identity();
+  const TF zinv = t_block_batch_inverse(pt.z, inv_buf);
+  if (live && sub == 0) *dst = inf ? Aff::identity() : t_to_std(t_to_affine(pt, zinv));
+}
+
 // ------------------------------------------------------------------ decompression (+ subgroup check)
 // ark-bls12-381 `deserialize_compressed` (Validate::Yes) for tracker / proof ingestion
 // (/root/reference/src/whisk.rs:265-277, :318-320; curdleproofs.rs:312-323): y = sqrt(x^3 + 4) by
@@ -1248,7 +1346,7 @@ const OptField kOptFields[] = {
     {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
     {"scale_any_point", &Options::scale_any_point, 0, 1},         {"strict_infinity", &Options::strict_infinity, 0, 1},
     {"fused_rounds_max", &Options::fused_rounds_max, 0, 1L << 30}, {"fused_fix_wpw", &Options::fused_fix_wpw, 0, 16},
-    {"fused_tbl_wpw", &Options::fused_tbl_wpw, 8, 32},             {"fused_combine", &Options::fused_combine, -1, 1},
+    {"smul_quad_max", &Options::smul_quad_max, 0, 1L << 30},       {"fused_tbl_wpw", &Options::fused_tbl_wpw, 8, 32},             {"fused_combine", &Options::fused_combine, -1, 1},
 };
 bool option_value_ok(const OptField& f, long v) {
   if (v < f.lo || v > f.hi) return false;
@@ -1507,11 +1605,15 @@ void launch_compress_cols(const Aff* d_in, const uint32_t* d_cols, int ncols, in
   if (ncols <= 0 || batch <= 0) return;
   CPX_LAUNCH(k_compress_cols, dim3(batch), dim3(64), 0, s, d_in, d_cols, ncols, stride, d_out, out_stride);
 }
-void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s, bool exclusive_simd) {
+void launch_smul(const SmulTask* d_tasks, int ntasks, int cnt, hipStream_t s, bool exclusive_simd, long quad_max) {
   const long total = (long)ntasks * cnt;
   if (total <= 0) return;
   const size_t lds = 2 * SMUL_THREADS * sizeof(TF) + 20 * SMUL_THREADS * sizeof(uint32_t);
   const unsigned groups = (unsigned)((total + SMUL_THREADS - 1) / SMUL_THREADS);
+  if (quad_max > 0 && total <= quad_max) {   // a small batch's T_2 commitments: a quad per element (never with SMUL_PLAIN tasks: the side stream's only)
+    CPX_LAUNCH(k_smul_quad, dim3((unsigned)((total + 15) / 16)), dim3(64), SQ_LDS, s, d_tasks, ntasks, cnt);
+    return;
+  }
   if (exclusive_simd && groups <= 16) CPX_LAUNCH(k_smul<true>, dim3(groups), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
   else CPX_LAUNCH(k_smul<false>, dim3(groups), dim3(SMUL_THREADS), lds, s, d_tasks, ntasks, cnt);
 }

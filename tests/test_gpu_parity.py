@@ -633,7 +633,7 @@ VARIANTS = {
     "device_resident": {"device_min_batch": 1},                 # (log rounds fused, round.hip: the default up to 2048 proofs)
     # the log rounds as ONE launch each (round.hip: MSM waves that reduce their own accumulators, the last arriver of a proof finalises, hashes,
     # draws the challenge and folds) in every wave shape the launcher offers, and switched off (the chain of separate kernels)
-    "device_resident_unfused_rounds": {"device_min_batch": 1, "fused_rounds_max": 0},
+    "device_resident_unfused_rounds": {"device_min_batch": 1, "fused_rounds_max": 0, "smul_quad_max": 0},   # (and the one-lane k_smul for the T_2 commitments)
     "fused_rounds_combined_waves": {"device_min_batch": 1, "fused_combine": 1, "fused_fix_wpw": 8},
     "fused_rounds_four_windows_per_fixed_wave": {"device_min_batch": 1, "fused_fix_wpw": 4},
     "fused_rounds_whole_tasks_per_wave": {"device_min_batch": 1, "fused_fix_wpw": 16, "fused_tbl_wpw": 32, "fused_combine": 0},

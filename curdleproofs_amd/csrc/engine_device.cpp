@@ -258,6 +258,25 @@ void Engine::prepare_device_prover() {
     for (size_t p = 0; p < B; p++) md[p] = (uint32_t)(p * NP + O_M);
     CPX_HIP(hipMemcpy(dp.mdst.p, md.data(), B * 4, hipMemcpyHostToDevice));
   }
+  // (decided before the plans are laid out: the phases of a small batch differ, too)
+  const size_t hn = n / 2, per = 4 * hn + 2;
+  // the last four rounds of a large batch work on 16 materialised folded bases per family instead (late.hip)
+  DevProver::Late& lt = dp.late;
+  lt.m = 16;
+  // (late_min_batch is stated for n <= 256; larger proofs have larger grids per proof: the threshold shrinks with 256 / n)
+  const size_t late_min = n <= 256 ? (size_t)opt_.late_min_batch : std::max<size_t>(1, (size_t)opt_.late_min_batch * 256 / n);
+  lt.on = opt_.late_rounds == 4 && L >= 5 && B >= late_min && late_supported((int)n, lt.m) && 4 * lt.m <= 64;
+  lt.j0 = lt.on ? L - 4 : L;
+  // fused log rounds (round.hip): every round of both arguments is ONE launch — for the batches in which a round is a chain of latency-bound
+  // kernels (below the late rounds' threshold; the 16-bit table of multiples)
+  const size_t fused_max = n <= 256 ? (size_t)opt_.fused_rounds_max : (size_t)opt_.fused_rounds_max * 256 / n;
+  dp.fused = opt_.fused_rounds_max > 0 && B <= fused_max && !lt.on && fix_bits_ == 16 && !opt_.serial_streams;
+  // wave shapes of the fused rounds: as many waves per proof as find a SIMD of their own (1024 SIMDs; proofs of n > 256 take n / 256 times the work)
+  const size_t simd_share = 1024 * 256 / (B * std::max<size_t>(n, 256));   // SIMDs per proof
+  const int f_fix_ipa = opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : (simd_share >= 16 ? 4 : 8);
+  const bool f_combine = opt_.fused_combine >= 0 ? opt_.fused_combine != 0 : simd_share < 12;
+  const int f_fix_smsm = f_combine ? 4 : std::max(8, opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : 8), f_tbl_smsm = f_combine ? 16 : (int)opt_.fused_tbl_wpw;
+  dp.fused = dp.fused && round_fused_supported(f_fix_ipa, 0, true) && round_fused_supported(f_fix_smsm, f_tbl_smsm, false);
   // -- phase 1: everything that depends only on vec_a and the prover's randomness (curdleproofs.rs:93,110-116,
   //    same_multiscalar_argument.rs:80 (B_a; B_t and B_u are phase 1t), inner_product_argument.rs:126, same_scalar_argument.rs:60-61).
   for (size_t p = 0; p < B; p++) {
@@ -317,8 +336,13 @@ void Engine::prepare_device_prover() {
   reqs.clear();
   ci.clear();
   for (size_t p = 0; p < B; p++) {
-    TblReq rb = req(cseg(n + 3, 1), pseg(p, O_M, 1), sc(p, SC_BETA_SP), slot_index(p, SL_B));
-    rb.add[0] = slot_index(p, SL_A);
+    // B.  Large batches: A + alpha M + beta sum(G) — two points and an addend.  Fused / small batches: the commitment the reference computes,
+    // msm(G | Hvec, a_sigma + alpha sigma + beta | a_blinders + alpha m_blinders) (same_permutation_argument.rs:75-76; the scalars are the
+    // grand-product factors k_ps_sameperm leaves in V_FACT) — a 256-point task of the fixed-base kernel like C beside it, instead of a
+    // one-point task of the bucket-list kernel whose 32 bucket sets per proof cost the phase 0.5 ms of reductions at 128 proofs
+    TblReq rb = dp.fused ? req(cseg(0, (uint32_t)n), none, vec(p, V_FACT), slot_index(p, SL_B))
+                         : req(cseg(n + 3, 1), pseg(p, O_M, 1), sc(p, SC_BETA_SP), slot_index(p, SL_B));
+    if (!dp.fused) rb.add[0] = slot_index(p, SL_A);
     reqs.push_back(rb);
     ci.push_back(cidx(p, SL_B));
     TblReq ra = req(none, none, nullptr);
@@ -346,24 +370,6 @@ void Engine::prepare_device_prover() {
   // -- IPA rounds as MSMs over the original bases; scalars from k_ipa_round_scalars
   dp.ipa.clear();
   dp.smsm.clear();
-  const size_t hn = n / 2, per = 4 * hn + 2;
-  // the last four rounds of a large batch work on 16 materialised folded bases per family instead (late.hip)
-  DevProver::Late& lt = dp.late;
-  lt.m = 16;
-  // (late_min_batch is stated for n <= 256; larger proofs have larger grids per proof: the threshold shrinks with 256 / n)
-  const size_t late_min = n <= 256 ? (size_t)opt_.late_min_batch : std::max<size_t>(1, (size_t)opt_.late_min_batch * 256 / n);
-  lt.on = opt_.late_rounds == 4 && L >= 5 && B >= late_min && late_supported((int)n, lt.m) && 4 * lt.m <= 64;
-  lt.j0 = lt.on ? L - 4 : L;
-  // fused log rounds (round.hip): every round of both arguments is ONE launch — for the batches in which a round is a chain of latency-bound
-  // kernels (below the late rounds' threshold; the 16-bit table of multiples)
-  const size_t fused_max = n <= 256 ? (size_t)opt_.fused_rounds_max : (size_t)opt_.fused_rounds_max * 256 / n;
-  dp.fused = opt_.fused_rounds_max > 0 && B <= fused_max && !lt.on && fix_bits_ == 16 && !opt_.serial_streams;
-  // wave shapes of the fused rounds: as many waves per proof as find a SIMD of their own (1024 SIMDs; proofs of n > 256 take n / 256 times the work)
-  const size_t simd_share = 1024 * 256 / (B * std::max<size_t>(n, 256));   // SIMDs per proof
-  const int f_fix_ipa = opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : (simd_share >= 16 ? 4 : 8);
-  const bool f_combine = opt_.fused_combine >= 0 ? opt_.fused_combine != 0 : simd_share < 12;
-  const int f_fix_smsm = f_combine ? 4 : std::max(8, opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : 8), f_tbl_smsm = f_combine ? 16 : (int)opt_.fused_tbl_wpw;
-  dp.fused = dp.fused && round_fused_supported(f_fix_ipa, 0, true) && round_fused_supported(f_fix_smsm, f_tbl_smsm, false);
   for (size_t j = 0; j < L; j++) {
     if (j >= lt.j0) {   // placeholders: exec_late_round takes these rounds
       dp.ipa.emplace_back(nullptr);

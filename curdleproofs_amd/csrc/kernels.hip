@@ -1504,10 +1504,10 @@ void launch_reduce_sets(const Options& o, const uint32_t* d_raw, const uint32_t*
   // reduce_wave_max / finalize_wave_max move the switch-over between the latency (wave per item) and the
   // throughput instantiations, so that tests reach the throughput kernels with small batches.
   // The wave form spends ~4x the lane time of the work-efficient form: it pays while the GPU is not full — up to 16384 sets when
-  // at most 512 proofs are in flight (64 ... 512 proofs per pass: +5-9 %); a large batch (several contexts keep the GPU busy) keeps
+  // at most 1024 proofs are in flight (64 ... 512 proofs per pass: +5-9 %, 1024: +2 %); a large batch (several contexts keep the GPU busy) keeps
   // it for launches of at most 2048 sets (at 16384 for every batch size the bench lost 3 %)
   const long forced = o.reduce_wave_max;
-  const long wave_max = forced >= 0 ? forced : (nproofs > 0 && nproofs <= 512 ? 16384L : 2048L);
+  const long wave_max = forced >= 0 ? forced : (nproofs > 0 && nproofs <= 1024 ? 16384L : 2048L);   // (1024 proofs: 94.0 -> 92.0 ms per pass, 512: no difference)
   if (nsets <= wave_max) {   // a few proofs: wave per set, both kinds in one launch
     CPX_LAUNCH(k_reduce_sets_wave, dim3(nsets), dim3(64), QP_ENTRIES * sizeof(TAcc), s, d_raw, d_raw_slot, nplain, d_part);
     return;

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(64) void k_ps_sameperm(const ProveDev d) {
     fact[i] = f;
     buf[i] = f;
   }
+  // (entries ell .. ell + 3: the scalars of B = A + alpha M + beta sum(G) on the blinder bases Hvec, a_blinders | 0 0 + alpha vec_m_blinders —
+  // with them V_FACT is the scalar vector of B as ONE multi-scalar multiplication over G | Hvec, the form small batches take)
+  if (lane < 4) fact[ell + lane] = fe_add(ap[ell + lane], fe_mul(d.mbl[(size_t)v.p * 4 + lane], alpha));
   __syncthreads();
   scan_mul(buf, ell);
   Fr* c = v.vec(V_C);

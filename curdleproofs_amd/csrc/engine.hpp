@@ -252,7 +252,7 @@ class Engine {
     TblPlan p1, p1b, p1t, p2, p3;   // p1t: B_t, B_u — the two commitments of phase 1 over per-proof tables, on the table stream
     std::vector<std::unique_ptr<TblPlan>> ipa, smsm;
     // fused log rounds (round.hip; options fused_rounds_max, fused_fix_wpw, fused_tbl_wpw): the plans above in proof-major order, one launch per round
-    bool fused = false;
+    bool fused = false, fused_smsm = false;   // the IPA rounds / the SameMSM rounds (and the small-batch form of phase 2)
     DevBuf<TAcc> rpart;          // XYZZ partial sums of a round's MSM waves
     DevBuf<uint32_t> rcount;     // [B] arrival counters
     // the last log rounds on materialised folded bases (late.hip; options late_rounds, late_min_batch)

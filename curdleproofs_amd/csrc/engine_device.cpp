@@ -270,13 +270,17 @@ void Engine::prepare_device_prover() {
   // fused log rounds (round.hip): every round of both arguments is ONE launch — for the batches in which a round is a chain of latency-bound
   // kernels (below the late rounds' threshold; the 16-bit table of multiples)
   const size_t fused_max = n <= 256 ? (size_t)opt_.fused_rounds_max : (size_t)opt_.fused_rounds_max * 256 / n;
-  dp.fused = opt_.fused_rounds_max > 0 && B <= fused_max && !lt.on && fix_bits_ == 16 && !opt_.serial_streams;
+  const size_t fused_smsm_max = n <= 256 ? (size_t)opt_.fused_smsm_max : (size_t)opt_.fused_smsm_max * 256 / n;
+  const bool fused_ok = !lt.on && fix_bits_ == 16 && !opt_.serial_streams;
+  dp.fused = fused_ok && opt_.fused_rounds_max > 0 && B <= fused_max;
+  dp.fused_smsm = fused_ok && opt_.fused_smsm_max > 0 && B <= fused_smsm_max;
   // wave shapes of the fused rounds: as many waves per proof as find a SIMD of their own (1024 SIMDs; proofs of n > 256 take n / 256 times the work)
   const size_t simd_share = 1024 * 256 / (B * std::max<size_t>(n, 256));   // SIMDs per proof
-  const int f_fix_ipa = opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : (simd_share >= 16 ? 4 : 8);
+  const int f_fix_ipa = opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : (simd_share >= 16 ? 4 : simd_share >= 4 ? 8 : 16);
   const bool f_combine = opt_.fused_combine >= 0 ? opt_.fused_combine != 0 : simd_share < 12;
   const int f_fix_smsm = f_combine ? 4 : std::max(8, opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : 8), f_tbl_smsm = f_combine ? 16 : (int)opt_.fused_tbl_wpw;
-  dp.fused = dp.fused && round_fused_supported(f_fix_ipa, 0, true) && round_fused_supported(f_fix_smsm, f_tbl_smsm, false);
+  dp.fused = dp.fused && round_fused_supported(f_fix_ipa, 0, true);
+  dp.fused_smsm = dp.fused_smsm && round_fused_supported(f_fix_smsm, f_tbl_smsm, false);
   // -- phase 1: everything that depends only on vec_a and the prover's randomness (curdleproofs.rs:93,110-116,
   //    same_multiscalar_argument.rs:80 (B_a; B_t and B_u are phase 1t), inner_product_argument.rs:126, same_scalar_argument.rs:60-61).
   for (size_t p = 0; p < B; p++) {
@@ -340,9 +344,9 @@ void Engine::prepare_device_prover() {
     // msm(G | Hvec, a_sigma + alpha sigma + beta | a_blinders + alpha m_blinders) (same_permutation_argument.rs:75-76; the scalars are the
     // grand-product factors k_ps_sameperm leaves in V_FACT) — a 256-point task of the fixed-base kernel like C beside it, instead of a
     // one-point task of the bucket-list kernel whose 32 bucket sets per proof cost the phase 0.5 ms of reductions at 128 proofs
-    TblReq rb = dp.fused ? req(cseg(0, (uint32_t)n), none, vec(p, V_FACT), slot_index(p, SL_B))
+    TblReq rb = dp.fused_smsm ? req(cseg(0, (uint32_t)n), none, vec(p, V_FACT), slot_index(p, SL_B))
                          : req(cseg(n + 3, 1), pseg(p, O_M, 1), sc(p, SC_BETA_SP), slot_index(p, SL_B));
-    if (!dp.fused) rb.add[0] = slot_index(p, SL_A);
+    if (!dp.fused_smsm) rb.add[0] = slot_index(p, SL_A);
     reqs.push_back(rb);
     ci.push_back(cidx(p, SL_B));
     TblReq ra = req(none, none, nullptr);
@@ -433,7 +437,7 @@ void Engine::prepare_device_prover() {
       ci.push_back(cidx(p, sm.RU((int)j)));
     }
     dp.smsm.emplace_back(new TblPlan());
-    if (dp.fused) {
+    if (dp.fused_smsm) {
       dp.smsm.back()->keep_order = true;
       dp.smsm.back()->force_fix_wpw = f_fix_smsm;
       dp.smsm.back()->force_tbl_wpw = f_tbl_smsm;
@@ -551,7 +555,7 @@ void Engine::prepare_device_prover() {
     for (auto& pl : dp.smsm)
       if (pl) upd(*pl);
     if (lt.on) max_parts = std::max(max_parts, 6 * B);
-    if (dp.fused) {
+    if (dp.fused || dp.fused_smsm) {
       dp.rpart.ensure(max_parts);
       dp.rcount.ensure(B);
     }
@@ -674,6 +678,7 @@ void Engine::enqueue_prove_device() {
   const size_t BM = B * (size_t)lt.m;
   // fused rounds (round.hip): the descriptor of a round's launch from its plan (the scratch pointers are read at enqueue time: a later
   // batch of another shape may have regrown them)
+  if (dp.fused || dp.fused_smsm) CPX_HIP(hipMemsetAsync(dp.rcount.p, 0, B * sizeof(uint32_t), stream_));
   auto round_dev = [&](const TblPlan& pl, int nreq, bool last) {
     RoundDev rd{};
     rd.ftasks = pl.ftasks.p;
@@ -702,7 +707,6 @@ void Engine::enqueue_prove_device() {
     return rd;
   };
   if (dp.fused) {
-    CPX_HIP(hipMemsetAsync(dp.rcount.p, 0, B * sizeof(uint32_t), stream_));
     launch_ipa_round_scalars(d_rvec_.p, Bi, (int)n, (int)(n >> 1), d_rbeta_.p, d_rout_.p, stream_);   // round 0's scalars; every later round's come from the tail before it
     for (size_t j = 0; j < L; j++) {
       const TblPlan& pl = *dp.ipa[j];
@@ -739,7 +743,7 @@ void Engine::enqueue_prove_device() {
   CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_d, 0));
   if (tabs != stream_) CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_t2, 0));   // B_t, B_u in the slot registry
   launch_ps_smsm_setup(d, Bi, stream_);
-  if (dp.fused) {
+  if (dp.fused_smsm) {
     launch_smsm_round_scalars(dp.rvec2.p, Bi, (int)n, (int)(n >> 1), d_rout_.p, stream_);
     for (size_t j = 0; j < L; j++) {
       const TblPlan& pl = *dp.smsm[j];
@@ -748,7 +752,7 @@ void Engine::enqueue_prove_device() {
       tock();
     }
   }
-  for (size_t j = 0; j < L && !dp.fused; j++) {
+  for (size_t j = 0; j < L && !dp.fused_smsm; j++) {
     const int half = (int)(n >> (j + 1));
     if (lt.on && j == lt.j0) {   // T_b^(j0), U_b^(j0), G_b^(j0): one shared digit sequence per proof (fold coefficients S_M)
       // (T_b, U_b with two lanes per output fill a wave; G_b then comes from the table of multiples like G and G')

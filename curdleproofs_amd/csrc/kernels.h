@@ -51,6 +51,7 @@ struct Options {
   long fused_rounds_max = 160;     // batches of up to this many proofs (n <= 256; scaled by 256 / n above) run every log round as ONE launch (round.hip); 0: the chain of
                                    // separate kernels.  The in-wave reductions of a fused round pay while its waves have SIMDs of their own (128 proofs x 8 waves = the
                                    // GPU's 1024): 64 proofs 24.4 -> 22.4 ms per pass, 128: 29.0 -> 27.3, 192: 34.5 -> 34.8, 256: 38.0 -> 43.9
+  long fused_smsm_max = 160;       // ... and the SameMSM rounds up to this many (their in-wave bucket reductions — 2 x 19 quad rounds per wave — do not pay once waves share SIMDs)
   long fused_fix_wpw = 0;          // windows per fixed-base wave of a fused round: 4 | 8 | 16, 0 = by the batch (4 while 16 waves per proof fit the SIMDs, else 8)
   long fused_tbl_wpw = 16;         // windows per table wave of a fused SameMSM round (8 | 16 | 32)
   long fused_combine = -1;         // 1: a SameMSM wave of a fused round runs a fixed-base block (4 windows) and a table block (16 windows): 8 waves per proof instead of

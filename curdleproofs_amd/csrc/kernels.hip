@@ -1345,7 +1345,7 @@ const OptField kOptFields[] = {
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
     {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
     {"scale_any_point", &Options::scale_any_point, 0, 1},         {"strict_infinity", &Options::strict_infinity, 0, 1},
-    {"fused_rounds_max", &Options::fused_rounds_max, 0, 1L << 30}, {"fused_fix_wpw", &Options::fused_fix_wpw, 0, 16},
+    {"fused_rounds_max", &Options::fused_rounds_max, 0, 1L << 30}, {"fused_smsm_max", &Options::fused_smsm_max, 0, 1L << 30}, {"fused_fix_wpw", &Options::fused_fix_wpw, 0, 16},
     {"smul_quad_max", &Options::smul_quad_max, 0, 1L << 30},       {"fused_tbl_wpw", &Options::fused_tbl_wpw, 8, 32},             {"fused_combine", &Options::fused_combine, -1, 1},
 };
 bool option_value_ok(const OptField& f, long v) {

@@ -237,6 +237,7 @@ class Engine {
     double pts_fix = 0, pts_tbl = 0;
     bool any_add = false;
     bool table_stream = false;   // runs beside the main stream's plans (phase 1t): its own write-only dummy slot
+    bool combined = false;       // fused SameMSM rounds: wave w of a proof runs fixed-base block w and table block w (RoundDev::combine)
     bool keep_order = false;     // tasks stay in request (= proof-major) order: the fused round kernels address them by proof (round.hip)
     int force_fix_wpw = 0, force_tbl_wpw = 0;   // != 0: the windows per wave instead of the launch-size heuristics
     DevBuf<TblTask> ttasks;

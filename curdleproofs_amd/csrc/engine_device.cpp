@@ -276,9 +276,13 @@ void Engine::prepare_device_prover() {
   dp.fused_smsm = fused_ok && opt_.fused_smsm_max > 0 && B <= fused_smsm_max;
   // wave shapes of the fused rounds: as many waves per proof as find a SIMD of their own (1024 SIMDs; proofs of n > 256 take n / 256 times the work)
   const size_t simd_share = 1024 * 256 / (B * std::max<size_t>(n, 256));   // SIMDs per proof
-  const int f_fix_ipa = opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : (simd_share >= 16 ? 4 : simd_share >= 4 ? 8 : 16);
+  const int f_fix_ipa = opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : (simd_share >= 16 ? 4 : simd_share >= 8 ? 8 : 16);   // 16 / 8 / 4 waves per proof
+  // SameMSM: separate fixed-base and table waves (12 per proof) while they find SIMDs of their own; then combined waves — a fixed-base block
+  // and a table block per wave — 8 per proof (4 + 16 windows), and 4 per proof (8 + 32 windows) from 129 proofs on
   const bool f_combine = opt_.fused_combine >= 0 ? opt_.fused_combine != 0 : simd_share < 12;
-  const int f_fix_smsm = f_combine ? 4 : std::max(8, opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : 8), f_tbl_smsm = f_combine ? 16 : (int)opt_.fused_tbl_wpw;
+  const bool f_combine4 = f_combine && opt_.fused_combine < 0 && simd_share < 8;
+  const int f_fix_smsm = f_combine ? (f_combine4 ? 8 : 4) : std::max(8, opt_.fused_fix_wpw ? (int)opt_.fused_fix_wpw : 8);
+  const int f_tbl_smsm = f_combine ? (f_combine4 ? 32 : 16) : (int)opt_.fused_tbl_wpw;
   dp.fused = dp.fused && round_fused_supported(f_fix_ipa, 0, true);
   dp.fused_smsm = dp.fused_smsm && round_fused_supported(f_fix_smsm, f_tbl_smsm, false);
   // -- phase 1: everything that depends only on vec_a and the prover's randomness (curdleproofs.rs:93,110-116,
@@ -439,6 +443,7 @@ void Engine::prepare_device_prover() {
     dp.smsm.emplace_back(new TblPlan());
     if (dp.fused_smsm) {
       dp.smsm.back()->keep_order = true;
+      dp.smsm.back()->combined = f_combine;
       dp.smsm.back()->force_fix_wpw = f_fix_smsm;
       dp.smsm.back()->force_tbl_wpw = f_tbl_smsm;
     }
@@ -687,8 +692,8 @@ void Engine::enqueue_prove_device() {
     rd.nt = (int)(pl.ntt / B);
     rd.fix_wpw = pl.fix_wpw;
     rd.tbl_wpw = rd.nt ? pl.tbl_wpw : 0;
-    rd.combine = (rd.nt && pl.fix_wpw == 4 && pl.tbl_wpw == 16 && rd.nf * 4 == rd.nt * 2) ? 1 : 0;   // (4 / 16 windows per wave are only planned for combined waves)
-    rd.wpp = rd.combine ? (uint32_t)(rd.nt * 2) : (uint32_t)(rd.nf * (16 / pl.fix_wpw) + (rd.nt ? rd.nt * (32 / pl.tbl_wpw) : 0));
+    rd.combine = (rd.nt && pl.combined && rd.nf * (16 / pl.fix_wpw) == rd.nt * (32 / pl.tbl_wpw)) ? 1 : 0;
+    rd.wpp = rd.combine ? (uint32_t)(rd.nt * (32 / pl.tbl_wpw)) : (uint32_t)(rd.nf * (16 / pl.fix_wpw) + (rd.nt ? rd.nt * (32 / pl.tbl_wpw) : 0));
     rd.nreq = nreq;
     rd.nproofs = Bi;
     rd.max_count = (uint32_t)std::max(16 / pl.fix_wpw, rd.nt ? 64 / pl.tbl_wpw : 0);

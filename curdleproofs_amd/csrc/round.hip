@@ -271,7 +271,7 @@ template <int FW, int TW, bool IPA, bool COMBINE = false> __global__ __launch_bo
 
 bool round_fused_supported(int fix_wpw, int tbl_wpw, bool ipa) {
   if (ipa) return tbl_wpw == 0 && (fix_wpw == 4 || fix_wpw == 8 || fix_wpw == 16);
-  if (fix_wpw == 4 && tbl_wpw == 16) return true;   // combined waves (RoundDev::combine)
+  if ((fix_wpw == 4 && tbl_wpw == 16) || (fix_wpw == 8 && tbl_wpw == 32)) return true;   // (also the shapes of combined waves, RoundDev::combine)
   return (fix_wpw == 8 || fix_wpw == 16) && (tbl_wpw == 8 || tbl_wpw == 16 || tbl_wpw == 32);
 }
 size_t round_fused_lds(int tbl_wpw) {
@@ -293,9 +293,11 @@ void launch_round_fused(const RoundDev& rd, const ProveDev& d, int j, bool ipa, 
   }
 #define CASE(F, T) \
   if (rd.fix_wpw == F && rd.tbl_wpw == T) { ROUND_LAUNCH((k_round_fused<F, T, false>), grid, block, lds, s, rd, d, j); return; }
-  if (rd.combine) {   // wave w = fixed-base block w + table block w (4 windows of a CRS task, 16 windows of a table task)
-    if (rd.fix_wpw != 4 || rd.tbl_wpw != 16 || rd.nf * 4 != rd.nt * 2) throw std::invalid_argument("launch_round_fused: combined waves need 4 / 16 windows per wave");
-    ROUND_LAUNCH((k_round_fused<4, 16, false, true>), grid, block, lds, s, rd, d, j);
+  if (rd.combine) {   // wave w = fixed-base block w + table block w: 4 windows of a CRS task + 16 of a table task (8 waves per proof), or 8 + 32 (4 waves per proof)
+    if (rd.nf * (16 / rd.fix_wpw) != rd.nt * (32 / rd.tbl_wpw)) throw std::invalid_argument("launch_round_fused: combined waves need as many fixed-base blocks as table blocks");
+    if (rd.fix_wpw == 4 && rd.tbl_wpw == 16) ROUND_LAUNCH((k_round_fused<4, 16, false, true>), grid, block, lds, s, rd, d, j);
+    else if (rd.fix_wpw == 8 && rd.tbl_wpw == 32) ROUND_LAUNCH((k_round_fused<8, 32, false, true>), grid, block, lds, s, rd, d, j);
+    else throw std::invalid_argument("launch_round_fused: combined waves take 4 / 16 or 8 / 32 windows per wave");
     return;
   }
   CASE(8, 8) CASE(8, 16) CASE(8, 32) CASE(16, 8) CASE(16, 16) CASE(16, 32)

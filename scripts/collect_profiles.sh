@@ -4,7 +4,7 @@
 # PMC passes are separate runs (no traces together with --pmc).  The HBM counter pass runs first because bench.py reads
 # profiles/${RND}_hbm_counters.json for roofline.traffic.
 set -x
-RND=${RND:-r04}
+RND=${RND:-r05}
 R=$PWD
 O=$R/gpurun_out/prof
 mkdir -p $O
@@ -39,10 +39,26 @@ python scripts/single_proof_latency.py > $O/${RND}_single_proof_latency.txt 2>&1
 for m in ${MICRO:-}; do   # MICRO="quad_micro lat_micro place_micro keccak_micro" to rerun the micro-benchmarks (unchanged since r02)
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I curdleproofs_amd/csrc scripts/micro/$m.hip -o /tmp/$m > /dev/null 2>&1 && timeout 120 /tmp/$m > $O/${RND}_$m.txt 2>&1
 done
-python scripts/shape_sweep.py 128 2>&1 | tail -1 > $O/${RND}_shape_128.txt
-CPX_TRANSCRIPT_EXCL_MAX=0 python scripts/shape_sweep.py 128 2>&1 | tail -1 >> $O/${RND}_shape_128.txt   # A/B: the prefix sharing its SIMDs
-python scripts/shape_sweep.py 256 2>&1 | tail -1 >> $O/${RND}_shape_128.txt
-python scripts/shape_sweep.py 1024 2>&1 | tail -1 >> $O/${RND}_shape_128.txt
-# kernel timeline of one 128-proof pass (what the chain consists of, launch by launch)
-( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl128 -- python $R/scripts/batch_timeline.py run 128 > /dev/null 2>&1; python $R/scripts/batch_timeline.py report /tmp/tl128 > $O/${RND}_batch128_timeline.txt 2>&1 )
+# literal shapes, and the A/B of this round's small-batch path on the same box: fused log rounds (round.hip), the quad-per-element T_2 scalar
+# multiplications and B as one fixed-base MSM against the round-4 chain of separate kernels
+{
+  for b in 32 64 128 160 256 1024; do python scripts/shape_sweep.py $b 2>&1 | tail -1; done
+  echo "# A/B: the chain of separate kernels (round 4's path): fused rounds off, one-lane k_smul"
+  for b in 32 64 128 160; do CPX_FUSED_ROUNDS_MAX=0 CPX_FUSED_SMSM_MAX=0 CPX_SMUL_QUAD_MAX=0 python scripts/shape_sweep.py $b 2>&1 | tail -1; done
+  echo "# A/B at 128 proofs, one change at a time"
+  CPX_FUSED_SMSM_MAX=0 python scripts/shape_sweep.py 128 2>&1 | tail -1
+  CPX_FUSED_COMBINE=0 python scripts/shape_sweep.py 128 2>&1 | tail -1
+  CPX_SMUL_QUAD_MAX=0 python scripts/shape_sweep.py 128 2>&1 | tail -1
+  CPX_TRANSCRIPT_EXCL_MAX=0 python scripts/shape_sweep.py 128 2>&1 | tail -1
+  echo "# A/B at 1024 proofs: wave-per-set reductions (the default up to 1024 proofs since this round) against the work-efficient kernels"
+  CPX_REDUCE_WAVE_MAX=2048 python scripts/shape_sweep.py 1024 2>&1 | tail -1
+} > $O/${RND}_shape_128.txt
+# kernel timeline of one 128-proof pass, launch by launch: this round's path, then the round-4 chain on the same box
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl128 -- python $R/scripts/batch_timeline.py run 128 > /dev/null 2>&1
+  { echo "#### 128 proofs, default options: one launch per log round (k_round_fused), k_smul_quad, B as a fixed-base MSM"; python $R/scripts/batch_timeline.py report /tmp/tl128; } > $O/${RND}_batch128_timeline.txt 2>&1
+  export CPX_FUSED_ROUNDS_MAX=0 CPX_FUSED_SMSM_MAX=0 CPX_SMUL_QUAD_MAX=0
+  rocprofv3 --kernel-trace --output-format csv -d /tmp/tl128b -- python $R/scripts/batch_timeline.py run 128 > /dev/null 2>&1
+  { echo; echo "#### 128 proofs, fused_rounds_max = fused_smsm_max = smul_quad_max = 0: the chain of separate kernels (round 4's path), same box"; python $R/scripts/batch_timeline.py report /tmp/tl128b; } >> $O/${RND}_batch128_timeline.txt 2>&1 )
+bash scripts/host_budget.sh > /dev/null 2>&1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I curdleproofs_amd/csrc scripts/micro/affine_micro.hip -o /tmp/affine_micro > /dev/null 2>&1 && timeout 300 /tmp/affine_micro 16 > $O/${RND}_affine_micro_raw.txt 2>&1
 cut -c1-300 $O/${RND}_bench.json; head -3 $O/${RND}_gpu_busy.txt

@@ -23,7 +23,17 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <unistd.h>
 #include "cpx.h"
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/lsan_interface.h>
+#define ENGINE_SAN_LEAK_CHECK() __lsan_do_leak_check()
+#endif
+#endif
+#ifndef ENGINE_SAN_LEAK_CHECK
+#define ENGINE_SAN_LEAK_CHECK() ((void)0)
+#endif
 
 namespace {
 
@@ -205,7 +215,13 @@ int main(int argc, char** argv) {
   if (!g_fail) scenario_four_contexts(sets);
   if (!g_fail) scenario_small_beside_big(sets);
   if (g_fail) return 1;
+  // Every context is destroyed at this point: the leak check runs NOW, and the process then leaves without the static destructors of the
+  // (uninstrumented) ROCm runtime — under ROCm's ASan runtime their frees can trip its own "device runtime unloaded" CHECK during
+  // __cxa_finalize (seen once in three runs; no frame of this repository on that stack), which would turn a clean run into a failed one.
+  ENGINE_SAN_LEAK_CHECK();
   printf("engine_san ok: one context (host-driven, device-resident, fused and unfused rounds, option changes), four contexts switching CRS on four threads, "
          "a 128-proof batch beside 1536-proof batches — every proof bit-exact, every verdict as expected\n");
-  return 0;
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);
 }

@@ -68,6 +68,7 @@ int cpx_device_count(void) {
 void* cpx_host_alloc(size_t bytes) {
   void* p = nullptr;
   if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  CPX_NEW_HOST_MEMORY(p, bytes);
   return p;
 }
 void cpx_host_free(void* p) {

@@ -41,6 +41,22 @@ struct ArgError : std::runtime_error {
     if (_e != hipSuccess) throw ::cpx::HipError(_e, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
   } while (0)
 
+// Page-locked host memory comes from the (uninstrumented) HIP runtime, which hands a freed range out again: ThreadSanitizer cannot see the
+// free / allocate pair between two owners of the same addresses — one context's staging buffer released, another context's allocated — and
+// reports their accesses as a race (tests/test_sanitizers.py, engine under TSan on the GPU box).  Fresh pinned memory is therefore announced
+// to the tool as new memory; a no-op in every other build.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define CPX_TSAN 1
+#endif
+#endif
+#if defined(CPX_TSAN)
+extern "C" void AnnotateNewMemory(const char* file, int line, const volatile void* mem, unsigned long size);
+#define CPX_NEW_HOST_MEMORY(p, bytes) AnnotateNewMemory(__FILE__, __LINE__, (p), (unsigned long)(bytes))
+#else
+#define CPX_NEW_HOST_MEMORY(p, bytes) ((void)0)
+#endif
+
 template <class T> struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;
@@ -63,6 +79,7 @@ template <class T> struct PinBuf {
     if (p) CPX_HIP(hipHostFree(p));
     p = nullptr;
     CPX_HIP(hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault));
+    CPX_NEW_HOST_MEMORY(p, n * sizeof(T));
     cap = n;
   }
   ~PinBuf() {

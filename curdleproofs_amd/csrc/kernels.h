@@ -48,10 +48,10 @@ struct Options {
   long p1_split = 1;               // 1: phase 1 without A (it only needs the prover's randomness) runs before the main stream waits for the transcript prefix, A alone behind it: 128 proofs 41.7 -> 40.6 ms per pass, nothing at 8192
   long serial_streams = 0;         // 1 (measurement aid): the side stream's kernels run in line on the main stream — every kernel's duration is its own
   long bench_field = 12;           // cpx_bench_fpmul: 12 = 32-bit-limb standard form, 28 = 28-bit-limb table form
-  long fused_rounds_max = 160;     // batches of up to this many proofs (n <= 256; scaled by 256 / n above) run every log round as ONE launch (round.hip); 0: the chain of
+  long fused_rounds_max = 256;     // batches of up to this many proofs (n <= 256; scaled by 256 / n above) run every log round as ONE launch (round.hip); 0: the chain of
                                    // separate kernels.  The in-wave reductions of a fused round pay while its waves have SIMDs of their own (128 proofs x 8 waves = the
-                                   // GPU's 1024): 64 proofs 24.4 -> 22.4 ms per pass, 128: 29.0 -> 27.3, 192: 34.5 -> 34.8, 256: 38.0 -> 43.9
-  long fused_smsm_max = 160;       // ... and the SameMSM rounds up to this many (their in-wave bucket reductions — 2 x 19 quad rounds per wave — do not pay once waves share SIMDs)
+                                   // GPU's 1024 SIMDs; 256 proofs x 4): ms per pass with everything of this round, 64 proofs 24.4 -> 22.1, 128: 29.0 -> 26.7, 192: 34.9 -> 33.7, 256: 38.0 -> 36.0; 512 and above: slower (waves share SIMDs)
+  long fused_smsm_max = 256;       // ... and the SameMSM rounds up to this many (their in-wave bucket reductions — 2 x 19 quad rounds per wave — do not pay once waves share SIMDs)
   long fused_fix_wpw = 0;          // windows per fixed-base wave of a fused round: 4 | 8 | 16, 0 = by the batch (4 while 16 waves per proof fit the SIMDs, else 8)
   long fused_tbl_wpw = 16;         // windows per table wave of a fused SameMSM round (8 | 16 | 32)
   long fused_combine = -1;         // 1: a SameMSM wave of a fused round runs a fixed-base block (4 windows) and a table block (16 windows): 8 waves per proof instead of

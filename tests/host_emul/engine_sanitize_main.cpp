@@ -135,9 +135,11 @@ void scenario_one_context(const std::vector<Set>& sets) {
   prove_verify(ctx, s, make_batch(s, 1), true);          // host-driven
   prove_verify(ctx, s, make_batch(s, 5), false);         // host-driven with the spin team
   prove_verify(ctx, s, make_batch(s, 96), true);         // device-resident, fused rounds
-  CHECK(cpx_ctx_set_option(ctx, "fused_rounds_max", 0) == CPX_OK, "set_option");
+  CHECK(cpx_ctx_set_option(ctx, "fused_rounds_max", 0) == CPX_OK && cpx_ctx_set_option(ctx, "fused_smsm_max", 0) == CPX_OK, "set_option");
   prove_verify(ctx, s, make_batch(s, 96), false);        // plans rebuilt: the chain of separate kernels
-  CHECK(cpx_ctx_set_option(ctx, "fused_rounds_max", 160) == CPX_OK && cpx_ctx_set_option(ctx, "device_min_batch", 1) == CPX_OK, "set_option");
+  CHECK(cpx_ctx_set_option(ctx, "fused_rounds_max", 256) == CPX_OK && cpx_ctx_set_option(ctx, "fused_smsm_max", 256) == CPX_OK &&
+            cpx_ctx_set_option(ctx, "device_min_batch", 1) == CPX_OK,
+        "set_option");
   prove_verify(ctx, s, make_batch(s, 2), false);         // device-resident on two proofs
   CHECK(cpx_set_host_threads(ctx, 3) == CPX_OK && cpx_ctx_set_option(ctx, "device_min_batch", 1000000) == CPX_OK, "set_host_threads / set_option");
   prove_verify(ctx, s, make_batch(s, 40), false);        // host-driven on 40 proofs: the worker pool

@@ -68,10 +68,11 @@ int cpx_device_count(void) {
 void* cpx_host_alloc(size_t bytes) {
   void* p = nullptr;
   if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-  CPX_NEW_HOST_MEMORY(p, bytes);
+  CPX_HOST_MEMORY_ACQUIRE();
   return p;
 }
 void cpx_host_free(void* p) {
+  CPX_HOST_MEMORY_RELEASE();
   if (p) (void)hipHostFree(p);
 }
 

@@ -42,19 +42,24 @@ struct ArgError : std::runtime_error {
   } while (0)
 
 // Page-locked host memory comes from the (uninstrumented) HIP runtime, which hands a freed range out again: ThreadSanitizer cannot see the
-// free / allocate pair between two owners of the same addresses — one context's staging buffer released, another context's allocated — and
-// reports their accesses as a race (tests/test_sanitizers.py, engine under TSan on the GPU box).  Fresh pinned memory is therefore announced
-// to the tool as new memory; a no-op in every other build.
+// runtime's lock between one owner's hipHostFree and the next owner's hipHostMalloc of the same addresses — one context's staging buffer
+// released, another context's status buffer allocated there — and reports the two owners' accesses as a race (tests/test_sanitizers.py, the
+// engine under TSan on the GPU box).  The free / allocate pair is therefore announced to the tool as a release / acquire on one
+// process-wide object; a no-op in every other build.
 #if defined(__has_feature)
 #if __has_feature(thread_sanitizer)
 #define CPX_TSAN 1
 #endif
 #endif
 #if defined(CPX_TSAN)
-extern "C" void AnnotateNewMemory(const char* file, int line, const volatile void* mem, unsigned long size);
-#define CPX_NEW_HOST_MEMORY(p, bytes) AnnotateNewMemory(__FILE__, __LINE__, (p), (unsigned long)(bytes))
+extern "C" void AnnotateHappensBefore(const char* file, int line, const volatile void* addr);
+extern "C" void AnnotateHappensAfter(const char* file, int line, const volatile void* addr);
+inline char g_pinned_memory_sync = 0;
+#define CPX_HOST_MEMORY_RELEASE() AnnotateHappensBefore(__FILE__, __LINE__, &::cpx::g_pinned_memory_sync)
+#define CPX_HOST_MEMORY_ACQUIRE() AnnotateHappensAfter(__FILE__, __LINE__, &::cpx::g_pinned_memory_sync)
 #else
-#define CPX_NEW_HOST_MEMORY(p, bytes) ((void)0)
+#define CPX_HOST_MEMORY_RELEASE() ((void)0)
+#define CPX_HOST_MEMORY_ACQUIRE() ((void)0)
 #endif
 
 template <class T> struct DevBuf {
@@ -76,13 +81,15 @@ template <class T> struct PinBuf {
   size_t cap = 0;
   void ensure(size_t n) {
     if (n <= cap) return;
+    CPX_HOST_MEMORY_RELEASE();
     if (p) CPX_HIP(hipHostFree(p));
     p = nullptr;
     CPX_HIP(hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault));
-    CPX_NEW_HOST_MEMORY(p, n * sizeof(T));
+    CPX_HOST_MEMORY_ACQUIRE();
     cap = n;
   }
   ~PinBuf() {
+    CPX_HOST_MEMORY_RELEASE();
     if (p) (void)hipHostFree(p);
   }
 };

@@ -283,7 +283,7 @@ class Engine {
     // the last log rounds on materialised folded bases (late.hip; options late_rounds, late_min_batch)
     struct Late {
       bool on = false;
-      int m = 16;
+      int m = 16, nr = 4;               // materialised bases per family, late rounds = log2(m)
       size_t j0 = 0;                    // first late round
       DevBuf<TJac> jac;                 // [LATE_FAMILIES][B][m] materialised points
       DevBuf<TAff> tab;                 // [LATE_FAMILIES][B][m][late_tab_entries()] their small multiples

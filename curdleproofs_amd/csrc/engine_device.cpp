@@ -260,13 +260,20 @@ void Engine::prepare_device_prover() {
   }
   // (decided before the plans are laid out: the phases of a small batch differ, too)
   const size_t hn = n / 2, per = 4 * hn + 2;
-  // the last four rounds of a large batch work on 16 materialised folded bases per family instead (late.hip)
+  // the last log2(m) rounds of a large batch work on m materialised folded bases per family instead (late.hip): m = 16 (four rounds) up to
+  // n = 256; an all-MSM round of n = 512 / 1024 costs two / four times as much, while materialising costs the same whatever m (every base
+  // is visited once) and a late round 32 x (4 + m) operations per cross term: m = 32 (five rounds) pays there — measured per pass of 2048
+  // proofs of ell = 1020: m = 16 534.8 ms, m = 32 506.1 ms, m = 64 506.7 ms (six rounds, two k_late_uniform waves per proof: no further gain);
+  // 4096 proofs of ell = 508: 500.9 / 475.8 / 495.2 ms; 8192 proofs of ell = 252: 507.4 / 511.2 ms
   DevProver::Late& lt = dp.late;
-  lt.m = 16;
+  lt.m = opt_.late_m ? (int)opt_.late_m : n >= 512 ? 32 : 16;
+  while (lt.m > 16 && !late_supported((int)n, lt.m)) lt.m /= 2;
+  lt.nr = 0;
+  while ((1 << lt.nr) < lt.m) lt.nr++;
   // (late_min_batch is stated for n <= 256; larger proofs have larger grids per proof: the threshold shrinks with 256 / n)
   const size_t late_min = n <= 256 ? (size_t)opt_.late_min_batch : std::max<size_t>(1, (size_t)opt_.late_min_batch * 256 / n);
-  lt.on = opt_.late_rounds == 4 && L >= 5 && B >= late_min && late_supported((int)n, lt.m) && 4 * lt.m <= 64;
-  lt.j0 = lt.on ? L - 4 : L;
+  lt.on = opt_.late_rounds != 0 && L >= (size_t)lt.nr + 1 && B >= late_min && late_supported((int)n, lt.m);
+  lt.j0 = lt.on ? L - (size_t)lt.nr : L;
   // fused log rounds (round.hip): every round of both arguments is ONE launch — for the batches in which a round is a chain of latency-bound
   // kernels (below the late rounds' threshold; the 16-bit table of multiples)
   const size_t fused_max = n <= 256 ? (size_t)opt_.fused_rounds_max : (size_t)opt_.fused_rounds_max * 256 / n;
@@ -468,7 +475,7 @@ void Engine::prepare_device_prover() {
       meta[g] = (uint32_t)g;      // request g = partial sum g
       meta[6 * B + g] = 1;
     }
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < lt.nr; r++) {
       const int j = (int)lt.j0 + r;
       LateRound a{};
       a.m = m;
@@ -677,7 +684,7 @@ void Engine::enqueue_prove_device() {
   launch_ps_gprod(d, Bi, stream_);
   exec_plan(dp.p3, dp.slotcomp.p);
   launch_ps_ipa_setup(d, Bi, stream_);
-  // -- IPA rounds (inner_product_argument.rs:150-186 in all-MSM form; the last four of a large batch on materialised folded
+  // -- IPA rounds (inner_product_argument.rs:150-186 in all-MSM form; the last log2(m) of a large batch on materialised folded
   //    bases: late.hip)
   const DevProver::Late& lt = dp.late;
   const size_t BM = B * (size_t)lt.m;
@@ -760,10 +767,11 @@ void Engine::enqueue_prove_device() {
   for (size_t j = 0; j < L && !dp.fused_smsm; j++) {
     const int half = (int)(n >> (j + 1));
     if (lt.on && j == lt.j0) {   // T_b^(j0), U_b^(j0), G_b^(j0): one shared digit sequence per proof (fold coefficients S_M)
-      // (T_b, U_b with two lanes per output fill a wave; G_b then comes from the table of multiples like G and G')
+      // (T_b, U_b with two lanes per output fill a wave at m = 16, with one lane per output at m = 32; m = 64: two waves per proof; G_b comes
+      // from the table of multiples like G and G')
       tick("k_late_uniform", 128.0 * 2 * n * B, (double)(2 * n * B));
-      launch_late_uniform(dp.rvec2.p + n, 2 * n, d_ptab_.p, (size_t)copies_ * NP, (int)NP, ctab(), (int)nc(), lt.gb_cols, (int)n, lt.m, 2, 2, lt.jac.p + LATE_F_T * BM, BM,
-                          Bi, stream_);
+      launch_late_uniform(dp.rvec2.p + n, 2 * n, d_ptab_.p, (size_t)copies_ * NP, (int)NP, ctab(), (int)nc(), lt.gb_cols, (int)n, lt.m, 2, 4 * lt.m <= 64 ? 2 : 1,
+                          lt.jac.p + LATE_F_T * BM, BM, Bi, stream_);
       tock();
       launch_late_fix(dp.rvec2.p + n, 2 * n, lt.gb_cols, (int)n, lt.m, fixtab(), fix_bits_, (int)nc(), lt.jac.p + LATE_F_GB * BM, (size_t)lt.m, Bi, stream_);
       tick("k_late_tables", 0, (double)(3 * BM));

@@ -38,7 +38,8 @@ struct Options {
   long inline_below = 16;          // host loops shorter than this run inline
   long cu_mask = 1;                // 0: plain instead of CU-masked streams for the lone-proof prover
   long trace = 0;                  // 1: print the challenges of proof 0 to stderr (debugging aid)
-  long late_rounds = 4;            // 4: the last four log rounds of a large batch run on materialised folded bases (late.hip); 0: all-MSM everywhere
+  long late_rounds = 4;            // != 0: the last log2(m) log rounds of a large batch run on m materialised folded bases per family (late.hip); 0: all-MSM everywhere
+  long late_m = 0;                 // m = 16 | 32 | 64 (four / five / six late rounds); 0 = by the proof size: 16 up to n = 256, 32 from n = 512 on (ell = 1020: 3.83 -> 4.05 k proofs/s, ell = 508: 8.18 -> 8.61 k)
   long late_min_batch = 2048;      // ... for batches of at least this many proofs (n <= 256; scaled by 256 / n above: 512 at ell = 1020); the lane-per-output kernels need a full GPU to pay
   long late_slices = 8;            // lanes per cross term of a late round (1, 2, 4, 8): 15.3 k proofs/s at 8, 14.9 k at 4 and 2, 14.3 k at 1
   long rs_pairs = 1;               // 1: the prover's R and S MSMs of a proof share their waves (same scalars: one digit sort for both); 0: two separate tasks
@@ -243,7 +244,7 @@ void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, i
 // out[f * fstride + p * m + i] = sum_t sm[p * sstride + t m] * F_(t m + i) for the families f < nfam: T_b, U_b (per-proof 32-copy tables,
 // row M | T_b | U_b, NP columns) and G_b (CRS copies d_ctab, nc columns, column map d_gb_cols)
 void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, size_t ptab_proof_stride, int NP, const TAff* d_ctab, int nc, const uint32_t* d_gb_cols, int n,
-                         int m, int nfam, int split, TJac* d_out, size_t fstride, int nproofs, hipStream_t s);   // split: lanes per output (nfam * m * split <= 64)
+                         int m, int nfam, int split, TJac* d_out, size_t fstride, int nproofs, hipStream_t s);   // split: lanes per output (> 1 only while nfam * m * split <= 64); ceil(nfam * m * split / 64) waves per proof
 void launch_late_tables(const TJac* d_jac, TAff* d_tab, TblTmp* d_tmp, int npoints, hipStream_t s);
 void launch_late_msm(const LateRound& r, hipStream_t s);
 void launch_late_restart(Fr* d_vec, int n, int m, int nproofs, hipStream_t s);

@@ -1342,7 +1342,7 @@ const OptField kOptFields[] = {
     {"bench_field", &Options::bench_field, 12, 28},              {"serial_streams", &Options::serial_streams, 0, 1},
     {"p1_split", &Options::p1_split, 0, 1},                      {"transcript_lane_min_batch", &Options::transcript_lane_min_batch, 1, 1L << 30},
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
-    {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},
+    {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},                         {"late_m", &Options::late_m, 0, 64},
     {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
     {"scale_any_point", &Options::scale_any_point, 0, 1},         {"strict_infinity", &Options::strict_infinity, 0, 1},
     {"fused_rounds_max", &Options::fused_rounds_max, 0, 1L << 30}, {"fused_smsm_max", &Options::fused_smsm_max, 0, 1L << 30}, {"fused_fix_wpw", &Options::fused_fix_wpw, 0, 16},
@@ -1354,6 +1354,7 @@ bool option_value_ok(const OptField& f, long v) {
   if (!strcmp(f.key, "tbw_slices")) return v == 0 || v == 1 || v == 2 || v == 4;
   if (!strcmp(f.key, "fix_bits")) return v == 8 || v == 16 || v == 19;
   if (!strcmp(f.key, "late_rounds")) return v == 0 || v == 4;
+  if (!strcmp(f.key, "late_m")) return v == 0 || v == 16 || v == 32 || v == 64;
   if (!strcmp(f.key, "late_slices")) return v == 1 || v == 2 || v == 4 || v == 8;
   if (!strcmp(f.key, "fused_fix_wpw")) return v == 0 || v == 4 || v == 8 || v == 16;
   if (!strcmp(f.key, "fused_tbl_wpw")) return v == 8 || v == 16 || v == 32;

@@ -2,10 +2,11 @@
 //
 // The all-MSM prover pays n/2 (scalar, point) pairs per cross term in EVERY round of the inner-product and
 // same-multiscalar arguments (inner_product_argument.rs:150-186, same_multiscalar_argument.rs:99-136), although the
-// reference's folded bases shrink to n / 2^j points.  For the last LATE_ROUNDS = 4 rounds this file goes back to folded bases:
+// reference's folded bases shrink to n / 2^j points.  For the last log2(m) rounds this file goes back to folded bases (m = 16: four rounds,
+// the shape of n <= 256; m = 32 / 64: five / six rounds for n = 512 / n >= 1024, where an all-MSM round costs 2 - 4 times as much):
 //
-//   1. materialise   G^(j0)_i = sum_t S_t G_(t m + i),  i < m = 16,  for the five basis families G, G' = u o G, G_b (SameMSM CRS
-//      basis), T_b, U_b — the identity the all-MSM form rests on, evaluated once at round j0 = log2(n) - 4:
+//   1. materialise   G^(j0)_i = sum_t S_t G_(t m + i),  i < m,  for the five basis families G, G' = u o G, G_b (SameMSM CRS
+//      basis), T_b, U_b — the identity the all-MSM form rests on, evaluated once at round j0 = log2(n) - log2(m):
 //        k_late_fix      CRS families from the fixed-base table of multiples: one LANE per output walks its n/m points x 16
 //                        windows = exactly (n/m) * 16 mixed additions, no buckets, no raw sets, no reduction kernels;
 //        k_late_uniform  T_b, U_b (and G_b) from the 32-copy shifted tables: the fold coefficients S_t are the same for every
@@ -73,20 +74,21 @@ template <int CB> __global__ __launch_bounds__(64, 2) void k_late_fix(const Fr* 
 }
 
 // ------------------------------------------------------------------ 1b. T_b, U_b, G_b from the 32-copy shifted tables
-// One wave per proof.  lane = family * m + i (family 0: T_b, 1: U_b, 2: G_b via the CRS copies); the n/m fold coefficients
+// `waves` waves per proof (one while nfam * m * split <= 64: m = 16 with two lanes per output, m = 32 with one; m = 64: two waves, each
+// sorting the proof's digit list for itself).  lane = family * m + i (family 0: T_b, 1: U_b, 2: G_b via the CRS copies); the n/m fold coefficients
 // S_t = sm[t m] are split (glv.hpp) and recoded once, their 32 n/m (t, copy) entries sorted by |digit| into `list`
 // (descending), and every lane adds ITS point of each entry, folding the running sum into its total once per magnitude.
 constexpr int LU_MAX_T = 128;                       // n / m <= 128
 __global__ __launch_bounds__(64, 2) void k_late_uniform(const Fr* __restrict__ sm, size_t sstride, const TAff* __restrict__ ptab, size_t ptab_proof_stride, int NP,
                                                         const TAff* __restrict__ ctab, int nc, const uint32_t* __restrict__ gb_cols, int n, int m, int nfam,
-                                                        int split, TJac* __restrict__ out, size_t fstride) {
+                                                        int split, int waves, TJac* __restrict__ out, size_t fstride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int nt = n / m, nent = 32 * nt;
   TAcc* total = reinterpret_cast<TAcc*>(smem);                                    // [64]
   uint16_t* list = reinterpret_cast<uint16_t*>(smem + 64 * sizeof(TAcc));         // [nent] (t << 6) | (copy << 1) | neg
   uint32_t* cnt = reinterpret_cast<uint32_t*>(list + ((nent + 1) & ~1));          // [129] entries per magnitude
   uint32_t* cur = cnt + 132;                                                      // [129] scatter cursors
-  const int p = blockIdx.x, lane = threadIdx.x;
+  const int p = blockIdx.x / waves, lane = threadIdx.x, flat = (blockIdx.x % waves) * 64 + lane;   // flat: the lane's index among the proof's lanes
   for (int b = lane; b < 132; b += 64) cnt[b] = 0;
   __syncthreads();
   // digits of S_t (lane t; nt may exceed 64)
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(64, 2) void k_late_uniform(const Fr* __restrict__ s
   // with a running sum and a total of its own (sum_b b B_b is linear in the buckets); the totals are added at the end.  With two
   // families (T_b, U_b: G_b then comes from the table of multiples) and split = 2 all 64 lanes work: 256 + 128 additions deep
   // instead of 512 + 128 on 48 lanes.
-  const int fam = (lane / m) % nfam, sub = lane / (m * nfam), i = lane % m;
+  // (split > 1 only with one wave per proof: the lanes of an output then meet in this wave's LDS)
+  const int fam = (flat / m) % nfam, sub = flat / (m * nfam), i = flat % m;
   const bool live = sub < split;
   // where this lane's copy-0 points live and how far apart the copies are
   const TAff* base = nullptr;
@@ -236,12 +239,12 @@ __global__ __launch_bounds__(64, 2) void k_late_msm(const LateRound r) {
   const LateOut o = r.o[oi];
   const Fr* sc = r.scal + (size_t)p * r.scal_proof_stride + o.scal_off;
   const int w_lo = slice * ws;
-  uint32_t signs = 0;   // bit 2 s: sign of the |t| half of scalar s, bit 2 s + 1: of the q half
+  uint64_t signs = 0;   // bit 2 s: sign of the |t| half of scalar s, bit 2 s + 1: of the q half (s < m / 2 <= 32)
   for (int s = 0; s < hm; s++) {
     const Fr k = fe_from_mont(sc[s]);
     uint32_t h[2][4], nk, ntg;
     glv_split(k.v, h[0], h[1], nk, ntg);
-    signs |= ((nk ^ ntg) << (2 * s)) | (nk << (2 * s + 1));
+    signs |= ((uint64_t)(nk ^ ntg) << (2 * s)) | ((uint64_t)nk << (2 * s + 1));
     CPX_UNROLL for (int hf = 0; hf < 2; hf++) {
       uint32_t packed[4];
       recode_signed_nibbles_biased(h[hf], packed);   // recode.hpp: signed radix-16 digits in [-7, 8], biased by 7, eight per word
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(64, 2) void k_late_msm(const LateRound r) {
       const uint32_t word = dw[(size_t)(sh * wph + (rel >> 3)) * 64 + lane];
       const int d = (int)((word >> (4 * (rel & 7))) & 15u) - 7;
       if (d) {
-        const bool neg = (d < 0) != (((signs >> sh) & 1u) != 0);
+        const bool neg = (d < 0) != (((signs >> sh) & 1u) != 0u);
         acc = t_acc_add_mixed_inl(acc, t_cneg_lazy(ftab[(size_t)pt * (2 * LATE_MULT) + hf * LATE_MULT + (d < 0 ? -d : d) - 1], neg));
       }
     }
@@ -297,8 +300,8 @@ __global__ __launch_bounds__(64) void k_late_restart(Fr* __restrict__ vec, int n
 
 size_t late_tab_entries() { return 2 * LATE_MULT; }
 size_t late_tmp_per_lane() { return LATE_MULT; }
-// (2 families x m outputs x 2 lanes per output must fit the 64 lanes of k_late_uniform's wave: m <= 16)
-bool late_supported(int n, int m) { return m >= 2 && m <= 16 && n % m == 0 && n / m <= LU_MAX_T && n > m; }
+// (m a power of two up to 64: k_late_msm keeps one sign bit per endomorphism half of its m / 2 scalars in a 64-bit mask)
+bool late_supported(int n, int m) { return m >= 2 && m <= 64 && (m & (m - 1)) == 0 && n % m == 0 && n / m <= LU_MAX_T && n > m; }
 
 void launch_late_fix(const Fr* d_scal, size_t sstride, const uint32_t* d_cols, int n, int m, const TFix* d_fix_tab, int cbits, int nc, TJac* d_out, size_t ostride,
                      int nproofs, hipStream_t s) {
@@ -313,11 +316,13 @@ void launch_late_uniform(const Fr* d_sm, size_t sstride, const TAff* d_ptab, siz
   if (nproofs <= 0) return;
   // (late_supported() keeps the engine away from shapes this kernel cannot take; a caller that gets here anyway must not go on with
   // uninitialised folded bases)
-  if (nfam * m * split > 64 || m <= 0 || n % m || n / m > LU_MAX_T || (n / m) > (1 << 10))
-    throw std::invalid_argument("launch_late_uniform: nfam * m * split lanes must fit one wave and n / m the 16-bit list entries");
+  const int waves = (nfam * m * split + 63) / 64;
+  if ((split > 1 && waves > 1) || split < 1 || m <= 0 || n % m || n / m > LU_MAX_T || (n / m) > (1 << 10))
+    throw std::invalid_argument("launch_late_uniform: the lanes of a split output must fit one wave and n / m the 16-bit list entries");
   const int nent = 32 * (n / m);
   const size_t lds = 64 * sizeof(TAcc) + (size_t)((nent + 1) & ~1) * 2 + 2 * 132 * 4;
-  LATE_LAUNCH(k_late_uniform, dim3(nproofs), dim3(64), lds, s, d_sm, sstride, d_ptab, ptab_proof_stride, NP, d_ctab, nc, d_gb_cols, n, m, nfam, split, d_out, fstride);
+  LATE_LAUNCH(k_late_uniform, dim3(nproofs * waves), dim3(64), lds, s, d_sm, sstride, d_ptab, ptab_proof_stride, NP, d_ctab, nc, d_gb_cols, n, m, nfam, split, waves, d_out,
+              fstride);
 }
 void launch_late_tables(const TJac* d_jac, TAff* d_tab, TblTmp* d_tmp, int npoints, hipStream_t s) {
   if (npoints <= 0) return;

@@ -704,14 +704,23 @@ def test_engine_variants_stay_bit_exact(name, orc, whisk_kat, oracle_vectors):
         c.close()
 
 
-@pytest.mark.parametrize("ell,seeds", [(28, [0, 1, 2]), (60, [0, 1]), (1020, [0])])
-def test_late_rounds_on_materialised_bases_other_sizes(orc, oracle_vectors, ell, seeds):
+@pytest.mark.parametrize("ell,seeds,late_m", [(28, [0, 1, 2], 0), (60, [0, 1], 0), (1020, [0], 0), (1020, [0], 16), (1020, [0], 64), (508, [0], 0), (508, [0], 64),
+                                              (252, [0, 1], 32), (252, [0], 64), (124, [0], 64), (60, [0, 1], 32)])
+def test_late_rounds_on_materialised_bases_other_sizes(orc, oracle_vectors, ell, seeds, late_m):
     """late.hip at the sizes the variant checks do not reach: ell = 28 (n = 32: two points per materialised base, first late round
-    = round 1), ell = 60, ell = 1020 (64 points per materialised base, 2048-entry digit lists).  Bytes == oracle."""
+    = round 1), ell = 60, ell = 1020 (default there: m = 32 materialised bases per family, five late rounds, one lane per output; m = 16: 64
+    points per base, 2048-entry digit lists; m = 64: six late rounds, two k_late_uniform waves per proof), ell = 508 (default m = 32; m = 64), and the deeper shapes forced onto n = 256 / 128 / 64 (late_m; an m the proof is too short for falls back).  Bytes == oracle."""
     import curdleproofs_amd as cpx
-    c = cpx.Context(0, options={"late_min_batch": 1, "device_min_batch": 1})
+    c = cpx.Context(0, options={"late_min_batch": 1, "device_min_batch": 1, "late_m": late_m})
     try:
+        c.set_profiling(True)
         crs, insts, proofs = _prove_and_check(c, orc, ell, seeds)
+        n, L = ell + 4, (ell + 4).bit_length() - 1
+        m = late_m or (32 if n >= 512 else 16)
+        while m > 16 and m >= n:
+            m //= 2
+        # the late rounds ran, as many as the shape says: log2(m) rounds x 2 arguments
+        assert c.stat("k_late_uniform")["launches"] == 1 and c.stat("k_late_msm")["launches"] == 2 * min(m.bit_length() - 1, L - 1)
         if str(ell) in oracle_vectors:
             assert hashlib.sha256(proofs[0]).hexdigest() == oracle_vectors[str(ell)]["proof_sha256"]
     finally:

@@ -75,7 +75,9 @@ template <class JobFn> __device__ __forceinline__ void quad_exec(TAcc* buf, int 
 // into two partial sums, k_finalize_ranges adds the partials of a request).
 constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
 constexpr int TBW_CAP = 8704;         // list entries per round
-constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index
+constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index beside a 5-bit window and the sign ...
+constexpr int TBW_ROUND_PTS_PERWIN = 4096;   // ... or, with one window per scalar half (PERWIN), a 14-bit one: a round takes TBW_CAP / 2 points
+static_assert(2 * TBW_ROUND_PTS_PERWIN <= TBW_CAP, "two entries per point of a PERWIN round");
 constexpr int TBW_LDS = TBW_CAP * 2 + 3 * 128 * 4 + 128;
 constexpr int TBW_LDS_CACHE = TBW_LDS + TBW_ROUND_PTS * 4;   // k_msm_tblw<2, false> keeps a round's recoded digits (below)
 static_assert(TBW_CAP >= 64 * TBW_WINDOWS, "one slab always fits");
@@ -146,6 +148,12 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
   static_assert(!PAIR || PERWIN, "pairs only for the one-off MSMs");
   constexpr int NSETS = PAIR ? 4 : 2;
   constexpr int WV = PERWIN ? 16 : TBW_WINDOWS / WPW;   // waves per task
+  // list entry: (point index inside the round << ESH) | (window j << 1) | sign.  PERWIN has j < 2, so 14 bits of point index fit: the
+  // verifier's 1112 points per proof are ONE round instead of 1024 + 88 (the short second round cost a tenth of the kernel: its lists of
+  // 0 - 6 entries wait for the longest, and the histogram, ranking and parking are paid again)
+  constexpr int ESH = PERWIN ? 2 : 6;
+  constexpr uint32_t EJM = PERWIN ? 1u : 31u;
+  constexpr uint32_t ROUND_PTS = PERWIN ? (uint32_t)TBW_ROUND_PTS_PERWIN : (uint32_t)TBW_ROUND_PTS;
   constexpr int NW = (WPW + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* list = reinterpret_cast<uint16_t*>(smem);                 // [TBW_CAP]
@@ -182,7 +190,7 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
     __syncthreads();
     // histogram over as many 64-point slabs as fit the list
     uint32_t total = 0, end = next;
-    while (end < ntot && end - next + 64 <= (uint32_t)TBW_ROUND_PTS) {
+    while (end < ntot && end - next + 64 <= ROUND_PTS) {
       const uint32_t i = end + lane;
       uint32_t dg[NW], sg_lo, sg_hi;
       int mine = 0;
@@ -233,8 +241,26 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
       order[r1] = (uint8_t)(2 * lane + 1);
     }
     __syncthreads();
-    const uint32_t b0 = order[lane], b1 = order[127 - lane];
-    const uint32_t c0 = cnt[b0], c1 = cnt[b1], s0_ = start[b0], s1_ = start[b1];
+    uint32_t b0 = order[lane], b1 = order[127 - lane];
+    uint32_t c0 = cnt[b0], c1 = cnt[b1], s0_ = start[b0], s1_ = start[b1];
+    // PAIR: both tasks have the same lists, so a lane that walked its own bucket pair twice carried twice its imbalance (252 points: the
+    // longest pair 10.2 entries against a mean of 7.8).  The second task's walk takes the bucket pair of ANOTHER lane instead: the lanes are
+    // ranked by the size of their pair and lane of rank r takes the pair of rank 63 - r (the buckets are parked by bucket index, whoever adds
+    // them up): the two walks of a lane sum to about twice the mean
+    int partner = lane;
+    if (PAIR) {
+      const uint32_t mine = c0 + c1;
+      uint32_t rk = 0;
+      for (int q = 0; q < 64; q++) {
+        const uint32_t o = (uint32_t)__shfl((int)mine, q, 64);
+        rk += (o < mine || (o == mine && q < lane)) ? 1u : 0u;
+      }
+      // lane of rank 63 - rk: every lane publishes its rank, the partner is found by a second sweep
+      for (int q = 0; q < 64; q++) {
+        const uint32_t o = (uint32_t)__shfl((int)rk, q, 64);
+        if (o == 63u - rk) partner = q;
+      }
+    }
     for (uint32_t s0 = next; s0 < end; s0 += 64) {
       const uint32_t i = s0 + lane;
       if (i < end) {
@@ -251,14 +277,22 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
           uint32_t neg;
           const uint32_t b = tbw_bucket(dg[j >> 2], j, neg);
           neg ^= (PERWIN ? j == 0 : w0 + j < 16) ? sg_lo : sg_hi;
-          if (b < 128u) list[atomicAdd(&cur[b], 1u)] = (uint16_t)(((i - next) << 6) | ((uint32_t)j << 1) | neg);
+          if (b < 128u) list[atomicAdd(&cur[b], 1u)] = (uint16_t)(((i - next) << ESH) | ((uint32_t)j << 1) | neg);
         }
       }
     }
     __syncthreads();
 #pragma unroll 1
-    for (int pass = 0; pass < (PAIR ? 2 : 1); pass++) {   // (a pair walks the same lists once per task)
+    for (int pass = 0; pass < (PAIR ? 2 : 1); pass++) {   // (a pair walks the same lists once per task, the second time those of its partner lane)
       const TblTask& tk = pass ? task2 : task;
+      if (PAIR && pass) {   // (order / cnt / start are not written between the ranking and the end of the round)
+        b0 = order[partner];
+        b1 = order[127 - partner];
+        c0 = cnt[b0];
+        c1 = cnt[b1];
+        s0_ = start[b0];
+        s1_ = start[b1];
+      }
       uint32_t* const rb0 = raw0 + (2 * pass + (b0 >> 6)) * RAW_SET_WORDS;   // bucket b lives in set b / 64 at position b % 64
       uint32_t* const rb1 = raw0 + (2 * pass + (b1 >> 6)) * RAW_SET_WORDS;
       TAcc xacc = later ? raw_load(rb0, b0 & 63) : TAcc::identity();
@@ -269,7 +303,7 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
           xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
         }
         const uint32_t e = list[k < c0 ? s0_ + k : s1_ + (k - c0)];
-        const TAff q = *tbl_point(tk, next + (e >> 6), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & 31u));
+        const TAff q = *tbl_point(tk, next + (e >> ESH), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & EJM));
         xacc = t_acc_add_mixed_inl(xacc, t_cneg_lazy(q, (e & 1u) != 0));   // products inlined: no argument moves, 231 VGPRs, no scratch
       }
       if (c1 == 0) {

@@ -37,7 +37,9 @@ def test_quad_cooperative_formulas_match_one_lane_formulas():
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 31, 32, 33, 64, 128, 252, 256, 257, 300, 600])
+# (1112: the verifier's points per proof, one round of the bucket-list wave since round 5; 4096 / 4097 / 9000: the 14-bit point index of a
+# one-window-per-half round at its limit, one point beyond it, and a task of three rounds)
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 31, 32, 33, 64, 128, 252, 256, 257, 300, 600, 1112, 4096, 4097, 9000])
 def test_msm_matches_oracle(ctx, orc, n):
     rng = orc.rng(1000 + n)
     bases = rng.g1_affine(n)

@@ -73,6 +73,9 @@ template <class JobFn> __device__ __forceinline__ void quad_exec(TAcc* buf, int 
 // reload the parked accumulators (they are kept per bucket).  Waves never wait for each other and the CU scheduler
 // backfills a finished wave's slot.  Output: two raw sets per wave (buckets 1..64, 65..128; k_reduce_sets turns them
 // into two partial sums, k_finalize_ranges adds the partials of a request).
+#ifndef CPX_TBW_SEGMENTS_ALL
+#define CPX_TBW_SEGMENTS_ALL 0   // (A/B switch: the segment loop of the pair kernel for every bucket-list kernel)
+#endif
 constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
 constexpr int TBW_CAP = 8704;         // list entries per round
 constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index beside a 5-bit window and the sign ...
@@ -241,8 +244,8 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
       order[r1] = (uint8_t)(2 * lane + 1);
     }
     __syncthreads();
-    uint32_t b0 = order[lane], b1 = order[127 - lane];
-    uint32_t c0 = cnt[b0], c1 = cnt[b1], s0_ = start[b0], s1_ = start[b1];
+    const uint32_t b0 = order[lane];
+    const uint32_t c0 = cnt[b0], c1 = cnt[order[127 - lane]], s0_ = start[b0];
     // PAIR: both tasks have the same lists, so a lane that walked its own bucket pair twice carried twice its imbalance (252 points: the
     // longest pair 10.2 entries against a mean of 7.8).  The second task's walk takes the bucket pair of ANOTHER lane instead: the lanes are
     // ranked by the size of their pair and lane of rank r takes the pair of rank 63 - r (the buckets are parked by bucket index, whoever adds
@@ -282,19 +285,11 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
       }
     }
     __syncthreads();
-#pragma unroll 1
-    for (int pass = 0; pass < (PAIR ? 2 : 1); pass++) {   // (a pair walks the same lists once per task, the second time those of its partner lane)
-      const TblTask& tk = pass ? task2 : task;
-      if (PAIR && pass) {   // (order / cnt / start are not written between the ranking and the end of the round)
-        b0 = order[partner];
-        b1 = order[127 - partner];
-        c0 = cnt[b0];
-        c1 = cnt[b1];
-        s0_ = start[b0];
-        s1_ = start[b1];
-      }
-      uint32_t* const rb0 = raw0 + (2 * pass + (b0 >> 6)) * RAW_SET_WORDS;   // bucket b lives in set b / 64 at position b % 64
-      uint32_t* const rb1 = raw0 + (2 * pass + (b1 >> 6)) * RAW_SET_WORDS;
+    if constexpr (!PAIR && !CPX_TBW_SEGMENTS_ALL) {
+      // every lane walks its two lists in one loop; at the boundary it parks the first accumulator (by bucket index)
+      const uint32_t b1 = order[127 - lane], s1_ = start[b1];
+      uint32_t* const rb0 = raw0 + (b0 >> 6) * RAW_SET_WORDS;   // bucket b lives in set b / 64 at position b % 64
+      uint32_t* const rb1 = raw0 + (b1 >> 6) * RAW_SET_WORDS;
       TAcc xacc = later ? raw_load(rb0, b0 & 63) : TAcc::identity();
       const uint32_t cboth = c0 + c1;
       for (uint32_t k = 0; k < cboth; k++) {
@@ -303,7 +298,7 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
           xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
         }
         const uint32_t e = list[k < c0 ? s0_ + k : s1_ + (k - c0)];
-        const TAff q = *tbl_point(tk, next + (e >> ESH), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & EJM));
+        const TAff q = *tbl_point(task, next + (e >> ESH), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & EJM));
         xacc = t_acc_add_mixed_inl(xacc, t_cneg_lazy(q, (e & 1u) != 0));   // products inlined: no argument moves, 231 VGPRs, no scratch
       }
       if (c1 == 0) {
@@ -311,6 +306,44 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
         xacc = later ? raw_load(rb1, b1 & 63) : TAcc::identity();
       }
       raw_store(rb1, b1 & 63, xacc);
+    } else {
+    // ONE loop over the lane's four bucket lists — its own two for the first task, the two of its partner lane for the second: a wave runs a
+    // loop until its slowest lane is through, so only inside one loop do a lane's long and short lists add up (two loops, one per task,
+    // each waited for the longest pair of buckets of the wave, whoever walked it).  Segment sg: bucket, list, raw set and task; a segment
+    // that ends parks its accumulator by bucket index and loads (or zeroes) the next one.
+    {
+      constexpr int NSEG = PAIR ? 4 : 2;
+      auto seg_bucket = [&](int sg) { return (uint32_t)order[(sg & 1) ? 127 - ((PAIR && sg >= 2) ? partner : lane) : ((PAIR && sg >= 2) ? partner : lane)]; };
+      uint32_t total = c0 + c1;
+      if (PAIR) total += cnt[seg_bucket(2)] + cnt[seg_bucket(3)];
+      const ptrdiff_t base2 = PAIR ? task2.seg[0].base - task.seg[0].base : 0;   // (a pair's tasks differ in their bases only)
+      int sg = 0;
+      uint32_t bk = b0, cs = c0, st = s0_, kin = 0;
+      uint32_t* rb = raw0 + (bk >> 6) * RAW_SET_WORDS;   // bucket b lives in set b / 64 (+ 2 for the second task of a pair) at position b % 64
+      TAcc xacc = later ? raw_load(rb, bk & 63) : TAcc::identity();
+      auto next_segment = [&]() {
+        raw_store(rb, bk & 63, xacc);
+        sg++;
+        bk = seg_bucket(sg);
+        cs = cnt[bk];
+        st = start[bk];
+        kin = 0;
+        rb = raw0 + (2 * (sg >> 1) + (bk >> 6)) * RAW_SET_WORDS;
+        xacc = later ? raw_load(rb, bk & 63) : TAcc::identity();
+      };
+#pragma unroll 1
+      for (uint32_t k = 0; k < total; k++) {
+        while (kin == cs) next_segment();   // (sg stays below NSEG: entries remain)
+        const uint32_t e = list[st + kin];
+        const TAff* src = tbl_point(task, next + (e >> ESH), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & EJM));
+        if (PAIR && sg >= 2) src += base2;
+        const TAff q = *src;
+        xacc = t_acc_add_mixed_inl(xacc, t_cneg_lazy(q, (e & 1u) != 0));   // products inlined: no argument moves, no scratch
+        kin++;
+      }
+      while (sg + 1 < NSEG) next_segment();   // the lists that were empty or remain: every bucket of the round is written
+      raw_store(rb, bk & 63, xacc);
+    }
     }
     __syncthreads();
     next = end;

@@ -316,7 +316,7 @@ def fused_check(c0, proofs_raw, nb, ell, peak_mm, prod_per_add, brief=False):
     return d
 
 
-def other_ell(c0, e3, b3, seed, what):
+def other_ell(c0, e3, b3, seed, what, c1=None):
     """another proof size as throughput on one engine context (its own CRS, fixed-base table and synthetic batch): prove + verify passes,
     and the prover's and the verifier's rates apart."""
     import curdleproofs_amd as cpx
@@ -337,10 +337,38 @@ def other_ell(c0, e3, b3, seed, what):
             tp += t2 - t1
             reps += 1
         dt_ = time.perf_counter() - t0
-        return dict(value=b3 * reps / dt_, unit="proofs/s", batch=b3, ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall),
-                    prove_per_s=b3 * reps / tp, verify_per_s=b3 * reps / tv, prove_ms_per_pass=1e3 * tp / reps, verify_ms_per_pass=1e3 * tv / reps,
-                    note="%s: ell=%d, %d proofs per pass, one engine context; value = prove + verify, prove_per_s / verify_per_s = CurdleproofsProof::new / "
-                         "::verify alone (as criterion reports them)" % (what, e3, b3))
+        res = dict(value=b3 * reps / dt_, unit="proofs/s", batch=b3, ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall),
+                   prove_per_s=b3 * reps / tp, verify_per_s=b3 * reps / tv, prove_ms_per_pass=1e3 * tp / reps, verify_ms_per_pass=1e3 * tv / reps,
+                   note="%s: ell=%d, %d proofs per pass, one engine context; value = prove + verify, prove_per_s / verify_per_s = CurdleproofsProof::new / "
+                        "::verify alone (as criterion reports them)" % (what, e3, b3))
+        if c1 is not None:
+            # the same shape driven the way the headline is: a second engine context with a batch of its own (the same instances) on a second host
+            # thread — one context's latency-bound kernels beside the other's MSM waves
+            import threading
+            c1.set_crs(e3, d3["crs"])
+            c1.load_batch(d3["vec_R"], d3["vec_S"], d3["vec_T"], d3["vec_U"], d3["M"])
+            b1 = [c1.marshal(d3[k_]) for k_ in ("perms", "k", "mbl", "prand", "vrand")]
+            ok2 = [True, True]
+
+            def passes(c, a, slot, n):
+                for _ in range(n):
+                    pr = c.prove_batch(a[0], a[1], a[2], a[3], raw=True)
+                    ok2[slot] &= all(v == cpx.CPX_OK for v in c.verify_batch(pr, a[4]))
+
+            def both(n):
+                th = threading.Thread(target=passes, args=(c1, b1, 1, n))
+                th.start()
+                passes(c0, a3, 0, n)
+                th.join()
+
+            both(1)
+            n2 = max(2, min(8, int(round(1.5 / max(dt_ / reps, 1e-3)))))
+            t0 = time.perf_counter()
+            both(n2)
+            dt2 = time.perf_counter() - t0
+            res["two_contexts"] = dict(value=2 * b3 * n2 / dt2, unit="proofs/s", batch_per_context=b3, ms_per_pass_of_both=1e3 * dt2 / n2, passes=n2, all_verified=bool(all(ok2)),
+                                       note="two engine contexts x %d proofs, one host thread each, passes back to back (how the headline runs its 2 x 8192)" % b3)
+        return res
     except Exception as e:   # e.g. not enough free HBM for this ell's fixed-base table beside the bench's buffers
         return dict(value=None, error=repr(e))
 
@@ -680,8 +708,9 @@ def main():
             if ell == 252:
                 # the reference's own bench shape (benches/perf.rs:29: N = 512, ell = 508), prover and verifier rates apart as criterion prints
                 # them; and BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
-                out["ell_508"] = other_ell(c0, 508, 4096, 5081, "the reference's in-tree criterion bench shape (benches/perf.rs:29, N = 512)")
-                out["ell_1020"] = other_ell(c0, 1020, 2048, 4321, "BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput")
+                c1 = ctxs[1] if len(ctxs) > 1 else None
+                out["ell_508"] = other_ell(c0, 508, 4096, 5081, "the reference's in-tree criterion bench shape (benches/perf.rs:29, N = 512)", c1)
+                out["ell_1020"] = other_ell(c0, 1020, 2048, 4321, "BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput", c1)
         if not args.no_cpu_baseline:   # the CPU oracle beside the GPU number in the same run, on rank 0 at every N
             out["cpu_baseline"] = cpu_baseline(ell, data, proofs[0])   # (+ a sample of 8 proofs of context 0's last pass against the oracle's bytes)
             if "config5" in out:

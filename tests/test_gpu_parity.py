@@ -1454,6 +1454,7 @@ def test_bench_two_ranks_on_one_gpu(fused):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CPX_BENCH_BACKEND="gloo", CPX_BENCH_DEVICE="0")
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the ranks meet on the loopback interface whatever the box's hostname resolves to
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ell", "28", "--batch", "128", "--steps", "2", "--warmup", "1",

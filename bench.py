@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with `roofline
 import argparse
 import json
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before anything touches HIP: hardware queues for the engine contexts' streams (curdleproofs_amd/__init__.py)
 import random
 import sys
 import time
@@ -659,7 +660,7 @@ def main():
                                         "(CurdleproofsProof::new) then verified; BASELINE configs[1] instance shape, per-GPU share "
                                         "of configs[3]" % (ell, n, L, B),
                                ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads,
-                               fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), parallelism="proofs sharded over %d GPU(s), no collective" % world),
+                               fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"), parallelism="proofs sharded over %d GPU(s), no collective" % world),
                    all_verified=all_ok, algorithmic_bytes_per_proof=b_prove + b_verify,
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},

@@ -16,6 +16,11 @@ Byte layouts are arkworks' in-memory limbs (Fr 32 B, affine 96 B, Jacobian 144 B
 import ctypes
 import os
 
+# eight hardware queues for the HIP streams of this process (the runtime's default of four lets two streams of one engine context share a
+# queue in about half of the runs of a two-context process: capi.cpp); read by the runtime at its first call, so it is set
+# as early as this package is imported — libcpx.so sets it again when it is loaded — and a value the caller exported wins
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .build import LIB as _LIB_PATH
 
 FR = 32

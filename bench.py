@@ -352,9 +352,13 @@ def other_ell(c0, e3, b3, seed, what, c1=None):
             ok2 = [True, True]
 
             def passes(c, a, slot, n):
-                for _ in range(n):
-                    pr = c.prove_batch(a[0], a[1], a[2], a[3], raw=True)
-                    ok2[slot] &= all(v == cpx.CPX_OK for v in c.verify_batch(pr, a[4]))
+                try:
+                    for _ in range(n):
+                        pr = c.prove_batch(a[0], a[1], a[2], a[3], raw=True)
+                        ok2[slot] &= all(v == cpx.CPX_OK for v in c.verify_batch(pr, a[4]))
+                except Exception:   # (a failure on the helper thread must not read as a fast pass)
+                    ok2[slot] = False
+                    raise
 
             def both(n):
                 th = threading.Thread(target=passes, args=(c1, b1, 1, n))

@@ -391,8 +391,9 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per engine context (0 = cores / (ranks x contexts), clamped to [2, 24])")
     ap.add_argument("--synth-cache", default="", help="pickle file for the synthetic batch (created if missing): keeps profiled runs free of setup kernels")
     ap.add_argument("--ctxs", type=int, default=2, help="engine contexts (HIP streams, one host thread each) per GPU; the batch is split over them: the "
-                    "protocol is device-resident, two streams let one context's latency-bound kernels (reductions, finalisation, step "
-                    "kernels) run beside the other's MSM waves")
+                    "protocol is device-resident, several contexts let one context's latency-bound kernels (reductions, finalisation, step "
+                    "kernels) and the tails of its launches run beside the others' MSM waves (one box, eight hardware queues: 2 x 8192 17.29 k, "
+                    "3 x 8192 +0.4 %%, 4 x 8192 +2.7 %% with 230 of the 288 GB of HBM in use — not the default —, 2 x 16384 +1.0 %%; 6 x 8192 do not fit)")
     ap.add_argument("--no-extra-shapes", action="store_true", help="skip the extra keys: throughput at BASELINE's literal batch shapes (128 / 1024 proofs per "
                     "GPU), ell=1020 throughput and the all-cores CPU baseline")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option for every context (cpx_ctx_set_option), e.g. "
@@ -563,6 +564,13 @@ def main():
             for f in acc:
                 acc[f] += st[f]
         c.set_profiling(False)
+    hbm_used_gb = None
+    if torch.cuda.is_available():
+        free_b, total_b = torch.cuda.mem_get_info()
+        hbm_used_gb = round((total_b - free_b) / 1e9, 1)   # with every context's batch resident: the working set of the timed region
+    for c in ctxs[2:]:   # what follows (isolated pass, literal shapes, other proof sizes) runs on one or two contexts: the others give their HBM back
+        c.close()
+    ctxs = ctxs[:2]
     iso = None
     if rank == 0:   # one more pass of context 0 ALONE, outside the timed region, with its side stream's kernels in line on the main stream
         c = ctxs[0]  # (option serial_streams): every kernel then has the GPU to itself and its duration is its own — in the timed region a
@@ -664,7 +672,7 @@ def main():
                                         "(CurdleproofsProof::new) then verified; BASELINE configs[1] instance shape, per-GPU share "
                                         "of configs[3]" % (ell, n, L, B),
                                ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads,
-                               fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"), parallelism="proofs sharded over %d GPU(s), no collective" % world),
+                               fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"), hbm_used_gb=hbm_used_gb, parallelism="proofs sharded over %d GPU(s), no collective" % world),
                    all_verified=all_ok, algorithmic_bytes_per_proof=b_prove + b_verify,
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},

@@ -300,6 +300,8 @@ class Engine {
   DevProver dprove_;
   void enqueue_prove_device();
   void exec_late_round(const LateRound& r, size_t comp_off, const char* what);
+  // proofs per launch of the device prover's table build: about a million base points (2048 proofs of ell = 252)
+  size_t table_chunk_rows() const { return std::max<size_t>(1, ((size_t)1 << 20) / np()); }
   struct DevVerifier {
     std::vector<const void*> signature;
     VerifyDev dev;

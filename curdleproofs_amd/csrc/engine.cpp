@@ -814,7 +814,7 @@ void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S
     d_psrc_.ensure(batch * NP);
     // build scratch: the 15 doubled copies of every point — of one chunk of the device prover's table build (engine_device.cpp); the host-driven
     // prover, which builds all rows at once, makes sure of its own (batch_prove_tables)
-    d_tbltmp_.ensure(std::min(batch, table_chunk_rows()) * NP * (size_t)(copies_ / 2 - 1));
+    d_tbltmp_.ensure(table_chunk_rows(batch) * NP * (size_t)(copies_ / 2 - 1));
     tails.assign(batch * 8, Aff::identity());
     for (size_t p = 0; p < batch; p++) tails[8 * p + 2] = tails[8 * p + 7] = crs_single_[0];
     const size_t spitch = NP * sizeof(Aff);
@@ -965,7 +965,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
       CPX_HIP(hipEventCreateWithFlags(&tab_.ev_m, hipEventDisableTiming));
       CPX_HIP(hipEventCreateWithFlags(&tab_.ev_done, hipEventDisableTiming));
     }
-    d_tbltmp_.ensure(B * NP * (size_t)(copies_ / 2 - 1));   // (all rows in two launches; load_batch sized the scratch for the device prover's chunks: a no-op below 2048 proofs)
+    d_tbltmp_.ensure(B * NP * (size_t)(copies_ / 2 - 1));   // (all rows in two launches; load_batch sized the scratch for the device prover's chunks: a no-op below 3072 proofs)
     CPX_HIP(hipEventRecord(tab_.ev_start, stream_));
     CPX_HIP(hipStreamWaitEvent(tab_.stream, tab_.ev_start, 0));
     const size_t tmp_m = B * (size_t)(copies_ / 2 - 1);   // scratch entries of the M launch; the T | U launch takes the rest

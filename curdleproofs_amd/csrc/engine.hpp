@@ -300,8 +300,12 @@ class Engine {
   DevProver dprove_;
   void enqueue_prove_device();
   void exec_late_round(const LateRound& r, size_t comp_off, const char* what);
-  // proofs per launch of the device prover's table build: about a million base points (2048 proofs of ell = 252)
-  size_t table_chunk_rows() const { return std::max<size_t>(1, ((size_t)1 << 20) / np()); }
+  // proofs per launch of the device prover's table build: equal chunks of about two million base points (8192 proofs of ell = 252: two chunks
+  // of 4096; every chunk launch ends in a tail of long waves: five chunks cost the build 5 %)
+  size_t table_chunk_rows(size_t batch) const {
+    const size_t nch = std::max<size_t>(1, (batch * np() + ((size_t)1 << 20)) >> 21);
+    return (batch + nch - 1) / nch;
+  }
   struct DevVerifier {
     std::vector<const void*> signature;
     VerifyDev dev;

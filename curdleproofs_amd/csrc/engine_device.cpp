@@ -573,7 +573,7 @@ void Engine::prepare_device_prover() {
     }
     d_tpart_.ensure(max_parts);
     ensure_raw_sets(max_sets);
-    d_tbltmp_.ensure(std::max(std::min(B, table_chunk_rows()) * NP * (size_t)(copies_ / 2 - 1),   // one chunk of the table build ...
+    d_tbltmp_.ensure(std::max(table_chunk_rows(B) * NP * (size_t)(copies_ / 2 - 1),   // one chunk of the table build ...
                               (3 * B * (size_t)lt.m + 63) / 64 * 64 * late_tmp_per_lane()));               // ... or the multiples of the late rounds' materialised points
   }
   dp.signature = sig;
@@ -653,9 +653,9 @@ void Engine::enqueue_prove_device() {
   hipStream_t const tabs = table_stream_on() ? tab_.dstream : stream_;
   if (tabs != stream_) CPX_HIP(hipStreamWaitEvent(tabs, pre != side ? dp.ev_a2 : dp.ev_a, 0));
   if (pre != side) CPX_HIP(hipStreamWaitEvent(stream_, dp.ev_a2, 0));
-  // (in chunks of table_chunk_rows() proofs, one after the other on this stream, through ONE chunk's worth of scratch: 3.4 instead of 13.5 GB
-  // per context at 8192 proofs of ell = 252; a chunk of 2048 proofs is 1 M threads — the GPU is as full as with all rows at once)
-  for (size_t r0 = 0, ch = table_chunk_rows(); r0 < B; r0 += ch) {
+  // (in equal chunks of table_chunk_rows(B) proofs, one after the other on this stream, through ONE chunk's worth of scratch: 6.7 instead of
+  // 13.5 GB per context at 8192 proofs of ell = 252; a chunk of 4096 proofs is 2 M threads — the GPU is as full as with all rows at once)
+  for (size_t r0 = 0, ch = table_chunk_rows(B); r0 < B; r0 += ch) {
     const size_t rows = std::min(ch, B - r0);
     tick("k_table_build", 0, (double)(rows * NP));
     launch_table_build(opt_, d_psrc_.p + r0 * NP, NP, d_ptab_.p + r0 * (size_t)copies_ * NP, (int)rows, (size_t)copies_ * NP, (int)NP, (int)NP, copies_, true, d_tbltmp_.p, tabs);

@@ -73,9 +73,6 @@ template <class JobFn> __device__ __forceinline__ void quad_exec(TAcc* buf, int 
 // reload the parked accumulators (they are kept per bucket).  Waves never wait for each other and the CU scheduler
 // backfills a finished wave's slot.  Output: two raw sets per wave (buckets 1..64, 65..128; k_reduce_sets turns them
 // into two partial sums, k_finalize_ranges adds the partials of a request).
-#ifndef CPX_TBW_SEGMENTS_ALL
-#define CPX_TBW_SEGMENTS_ALL 0   // (A/B switch: the segment loop of the pair kernel for every bucket-list kernel)
-#endif
 constexpr int TBW_WINDOWS = 32;       // radix-256 windows of a scalar < 2^255
 constexpr int TBW_CAP = 8704;         // list entries per round
 constexpr int TBW_ROUND_PTS = 1024;   // a list entry holds a 10-bit point index beside a 5-bit window and the sign ...
@@ -285,7 +282,7 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
       }
     }
     __syncthreads();
-    if constexpr (!PAIR && !CPX_TBW_SEGMENTS_ALL) {
+    if constexpr (!PAIR) {
       // every lane walks its two lists in one loop; at the boundary it parks the first accumulator (by bucket index)
       const uint32_t b1 = order[127 - lane], s1_ = start[b1];
       uint32_t* const rb0 = raw0 + (b0 >> 6) * RAW_SET_WORDS;   // bucket b lives in set b / 64 at position b % 64
@@ -307,15 +304,15 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
       }
       raw_store(rb1, b1 & 63, xacc);
     } else {
-    // ONE loop over the lane's four bucket lists — its own two for the first task, the two of its partner lane for the second: a wave runs a
-    // loop until its slowest lane is through, so only inside one loop do a lane's long and short lists add up (two loops, one per task,
-    // each waited for the longest pair of buckets of the wave, whoever walked it).  Segment sg: bucket, list, raw set and task; a segment
-    // that ends parks its accumulator by bucket index and loads (or zeroes) the next one.
-    {
+      // ONE loop over the lane's four bucket lists — its own two for the first task, the two of its partner lane for the second: a wave runs a
+      // loop until its slowest lane is through, so only inside one loop do a lane's long and short lists add up (two loops, one per task,
+      // each waited for the longest pair of buckets of the wave, whoever walked it; the same loop in the one-task kernels measured 0.4 % slower
+      // than the two-list loop above).  Segment sg: bucket, list, raw set and task; a segment that ends parks its accumulator by bucket index
+      // and loads (or zeroes) the next one.
       constexpr int NSEG = PAIR ? 4 : 2;
       auto seg_bucket = [&](int sg) { return (uint32_t)order[(sg & 1) ? 127 - ((PAIR && sg >= 2) ? partner : lane) : ((PAIR && sg >= 2) ? partner : lane)]; };
-      uint32_t total = c0 + c1;
-      if (PAIR) total += cnt[seg_bucket(2)] + cnt[seg_bucket(3)];
+      uint32_t nwalk = c0 + c1;   // entries of all the lane's lists
+      if (PAIR) nwalk += cnt[seg_bucket(2)] + cnt[seg_bucket(3)];
       const ptrdiff_t base2 = PAIR ? task2.seg[0].base - task.seg[0].base : 0;   // (a pair's tasks differ in their bases only)
       int sg = 0;
       uint32_t bk = b0, cs = c0, st = s0_, kin = 0;
@@ -332,7 +329,7 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
         xacc = later ? raw_load(rb, bk & 63) : TAcc::identity();
       };
 #pragma unroll 1
-      for (uint32_t k = 0; k < total; k++) {
+      for (uint32_t k = 0; k < nwalk; k++) {
         while (kin == cs) next_segment();   // (sg stays below NSEG: entries remain)
         const uint32_t e = list[st + kin];
         const TAff* src = tbl_point(task, next + (e >> ESH), (PERWIN ? 0u : (uint32_t)w0) + ((e >> 1) & EJM));
@@ -343,7 +340,6 @@ template <int WPW, bool PERWIN, bool PAIR = false> __device__ __forceinline__ vo
       }
       while (sg + 1 < NSEG) next_segment();   // the lists that were empty or remain: every bucket of the round is written
       raw_store(rb, bk & 63, xacc);
-    }
     }
     __syncthreads();
     next = end;

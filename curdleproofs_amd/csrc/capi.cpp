@@ -32,7 +32,7 @@ namespace {
 // HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says otherwise), and kernels of two
 // streams that share a queue do not overlap.  An engine context owns four streams whose kernels are MEANT to overlap (main, side, table,
 // transcript prefix); with two contexts in the process half of the runs put two of one context's streams on one queue: a 128-proof pass
-// then took 28.7 instead of 26.5 ms (six runs each way on one box: 3 of 6 against 0 of 6; the saturated rate does not care).  Eight queues
+// then took 28.7 instead of 26.5 ms (3 of 6 runs on one box against 0 of 11 with eight queues; the saturated rate does not care).  Eight queues
 // keep the streams of two contexts apart.  Set when the library is loaded, before the process's first HIP call reads it; a value the
 // caller exported wins.
 struct HwQueueDefault {

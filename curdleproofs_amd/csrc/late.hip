@@ -3,7 +3,8 @@
 // The all-MSM prover pays n/2 (scalar, point) pairs per cross term in EVERY round of the inner-product and
 // same-multiscalar arguments (inner_product_argument.rs:150-186, same_multiscalar_argument.rs:99-136), although the
 // reference's folded bases shrink to n / 2^j points.  For the last log2(m) rounds this file goes back to folded bases (m = 16: four rounds,
-// the shape of n <= 256; m = 32 / 64: five / six rounds for n = 512 / n >= 1024, where an all-MSM round costs 2 - 4 times as much):
+// the shape of n <= 256; m = 32: five rounds, the default from n = 512 on, where an all-MSM round costs 2 - 4 times as much; m = 64: six
+// rounds, option late_m — measured no better than 32):
 //
 //   1. materialise   G^(j0)_i = sum_t S_t G_(t m + i),  i < m,  for the five basis families G, G' = u o G, G_b (SameMSM CRS
 //      basis), T_b, U_b — the identity the all-MSM form rests on, evaluated once at round j0 = log2(n) - log2(m):

@@ -24,24 +24,39 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 README_I7_PROOFS_PER_S = 1.0 / (0.560 + 0.035)   # reference README.md:49, i7-8550U (context only)
 
 
+def synth_scalars(seed, n):
+    """n synthetic scalars in wire form (arkworks' in-memory Fr, 4 x u64 LE), seeded: 32 random bytes with the top two bits cleared,
+    i.e. uniform below 2^254 < r.  The wire form is the Montgomery image of the scalar and the map is a bijection, so the scalars themselves are
+    spread over all of Fr; numpy draws them 200x faster than `params.random_fr_wire`'s Python integers (12.7 M draws per 16384-proof batch: half
+    a minute of every rank's set-up until round 5).  Benchmark inputs only — never verification factors."""
+    import numpy as np
+    a = np.frombuffer(np.random.default_rng(seed).bytes(32 * n), dtype=np.uint8).reshape(n, 32).copy()
+    a[:, 31] &= 0x3F   # little-endian: the top byte keeps 6 bits
+    return a.tobytes()
+
+
 def synth_batch(ctx, ell, B, seed):
     """Synthetic CRS + B shuffle instances built through the product API only (GPU scale / msm)."""
     import curdleproofs_amd as cpx
     from curdleproofs_amd import params as pr
+    t_start = time.perf_counter()
     rng = random.Random(seed)
     n = ell + 4
     gen = pr.g1_generator_wire()
-    crs = ctx.scale(gen * (ell + 7), pr.random_fr_wire(rng, ell + 7))
+    crs = ctx.scale(gen * (ell + 7), synth_scalars(seed * 16 + 1, ell + 7))
     ctx.set_crs(ell, crs)
-    vec_R = ctx.scale(gen * (B * ell), pr.random_fr_wire(rng, B * ell))
-    vec_S = ctx.scale(vec_R, pr.random_fr_wire(rng, B * ell))
-    ks = [rng.randrange(1, pr.R) for _ in range(B)]
-    k_wire = b"".join(pr.fr_to_wire(k) for k in ks)
-    perms, vec_T, vec_U, Ms, mbl = [], [], [], [], []
-    AFF = cpx.AFF
+    vec_R = ctx.scale(gen * (B * ell), synth_scalars(seed * 16 + 2, B * ell))
+    vec_S = ctx.scale(vec_R, synth_scalars(seed * 16 + 3, B * ell))
+    k_wire = synth_scalars(seed * 16 + 4, B)
+    mbl_all = synth_scalars(seed * 16 + 5, 4 * B)
+    perms, vec_T, vec_U, Ms = [], [], [], []
+    AFF, FR = cpx.AFF, cpx.FR
     k_rep = b"".join(k_wire[32 * p:32 * p + 32] * ell for p in range(B))
     kR_all = ctx.scale(vec_R, k_rep)                        # util.rs:94-95, all proofs in one launch
     kS_all = ctx.scale(vec_S, k_rep)
+    t_points = time.perf_counter()
+    idx_wire = [pr.fr_to_wire(i) for i in range(ell)]
+    crs_G = crs[:n * AFF]
     for p in range(B):
         perm = list(range(ell))
         rng.shuffle(perm)
@@ -49,12 +64,12 @@ def synth_batch(ctx, ell, B, seed):
         kR, kS = kR_all[p * ell * AFF:(p + 1) * ell * AFF], kS_all[p * ell * AFF:(p + 1) * ell * AFF]
         vec_T.append(b"".join(kR[i * AFF:(i + 1) * AFF] for i in perm))
         vec_U.append(b"".join(kS[i * AFF:(i + 1) * AFF] for i in perm))
-        mb = pr.random_fr_wire(rng, 4)
-        mbl.append(mb)
-        sigma = b"".join(pr.fr_to_wire(i) for i in perm)   # util.rs:99-103
-        Ms.append(ctx.msm(crs[:n * AFF], sigma + mb))
+        sigma = b"".join(idx_wire[i] for i in perm)   # util.rs:99-103
+        Ms.append(ctx.msm(crs_G, sigma + mbl_all[p * 4 * FR:(p + 1) * 4 * FR]))
+    t_end = time.perf_counter()
     return dict(crs=crs, vec_R=vec_R, vec_S=vec_S, vec_T=b"".join(vec_T), vec_U=b"".join(vec_U), M=b"".join(Ms), perms=perms,
-                k=k_wire, mbl=b"".join(mbl), prand=pr.random_fr_wire(rng, B * (3 * n + 9)), vrand=pr.random_fr_wire(rng, B * 8))
+                k=k_wire, mbl=mbl_all, prand=synth_scalars(seed * 16 + 6, B * (3 * n + 9)), vrand=synth_scalars(seed * 16 + 7, B * 8),
+                setup_s=dict(total=time.perf_counter() - t_start, crs_and_scalar_multiplications=t_points - t_start, per_proof_permute_and_commit=t_end - t_points))
 
 
 def _instance(data, ell, i):
@@ -279,6 +294,44 @@ def shape_passes(c0, data, ell, nb, min_s=1.0):
     return dict(value=nb * reps / dt_, unit="proofs/s", ms_per_pass=1e3 * dt_ / reps, passes=reps, all_verified=bool(okall))
 
 
+def shape_passes_two(c0, c1, data, ell, nb, min_s=1.0):
+    """the same, driven the way the headline is: two engine contexts with nb proofs each (instances 0..nb-1 and nb..2nb-1 of the bench batch), one host
+    thread each, passes back to back"""
+    import threading
+    import curdleproofs_amd as cpx
+    AFF, FR, JAC, n_ = cpx.AFF, cpx.FR, cpx.JAC, ell + 4
+    arg = []
+    for j, c in enumerate((c0, c1)):
+        cut = lambda key, unit: data[key][j * nb * unit:(j + 1) * nb * unit]
+        c.load_batch(cut("vec_R", ell * AFF), cut("vec_S", ell * AFF), cut("vec_T", ell * AFF), cut("vec_U", ell * AFF), cut("M", JAC))
+        arg.append([c.marshal(x) for x in (data["perms"][j * nb * ell:(j + 1) * nb * ell], cut("k", FR), cut("mbl", 4 * FR), cut("prand", (3 * n_ + 9) * FR), cut("vrand", 8 * FR))])
+    ok = [True, True]
+
+    def passes(j, n):
+        c, a = (c0, c1)[j], arg[j]
+        try:
+            for _ in range(n):
+                pr_ = c.prove_batch(a[0], a[1], a[2], a[3], raw=True)
+                ok[j] &= all(v == cpx.CPX_OK for v in c.verify_batch(pr_, a[4]))
+        except Exception:
+            ok[j] = False
+            raise
+
+    def both(n):
+        th = threading.Thread(target=passes, args=(1, n))
+        th.start()
+        passes(0, n)
+        th.join()
+    both(2)
+    t0 = time.perf_counter()
+    both(1)
+    n2 = max(3, min(50, int(round(min_s / max(time.perf_counter() - t0, 1e-3)))))
+    t0 = time.perf_counter()
+    both(n2)
+    dt = time.perf_counter() - t0
+    return dict(value=2 * nb * n2 / dt, unit="proofs/s", batch_per_context=nb, ms_per_pass_of_both=1e3 * dt / n2, passes=n2, all_verified=bool(all(ok)))
+
+
 def fused_check(c0, proofs_raw, nb, ell, peak_mm, prod_per_add, brief=False):
     """BASELINE configs[4] on ONE engine context: the nb proofs loaded into c0 (bytes in proofs_raw) go through ONE accumulated check
     (cpx_batch_verify_fused + cpx_g1_sum_jac), verdict included; a batch with one wrong proof must be refused."""
@@ -378,6 +431,141 @@ def other_ell(c0, e3, b3, seed, what, c1=None):
         return dict(value=None, error=repr(e))
 
 
+def _parse_opts(kvs):
+    return {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in kvs}
+
+
+def traffic_child(args):
+    """What `rocprofv3 --pmc` wraps when bench.py measures roofline.traffic (measure_traffic below): ONE engine context, --batch proofs, one
+    prove + verify pass — the launches of the timed region's context 0 (same plans, same pairs per launch).  64 distinct synthetic instances
+    tiled over the batch with prover randomness of its own for every proof: from the first challenge on every proof's scalars, hence its table
+    gathers, differ like those of the timed batch."""
+    import curdleproofs_amd as cpx
+    ell, Bk, n = args.ell, args.batch, args.ell + 4
+    c = cpx.Context(int(args.traffic_child), options=_parse_opts(args.opt))
+    c.set_host_threads(2)
+    base = min(64, Bk)
+    assert Bk % base == 0
+    d, rep = synth_batch(c, ell, base, seed=4242), Bk // base
+    c.load_batch(d["vec_R"] * rep, d["vec_S"] * rep, d["vec_T"] * rep, d["vec_U"] * rep, d["M"] * rep)
+    proofs = c.prove_batch(d["perms"] * rep, d["k"] * rep, d["mbl"] * rep, synth_scalars(77, Bk * (3 * n + 9)), raw=True)
+    ok = all(v == cpx.CPX_OK for v in c.verify_batch(proofs, synth_scalars(78, Bk * 8)))
+    print(json.dumps(dict(traffic_child_ok=bool(ok))))
+    sys.exit(0 if ok else 3)
+
+
+def measure_traffic(kernel, ell, Bk, device, opts, timeout_s=240):
+    """HBM bytes per launch of `kernel` from rocprofv3 PMC passes taken NOW, on this box, by this command (MI355X_MICROARCH.md, HBM section: FETCH_SIZE and
+    WRITE_SIZE do not fit one pass — two child processes, counters only, no trace domain beside them; KiB units; FETCH_SIZE doubled: gfx950
+    tallies the 128-byte requests of wide reads at 64 bytes).  Returns (bytes per launch or None, a dict that says how it was taken or why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, dict(skipped="this process already runs under rocprofv3")
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, dict(skipped="rocprofv3 not found")
+    res, info = {}, dict(method="two rocprofv3 --pmc child passes of this run (FETCH_SIZE, WRITE_SIZE), one engine context x %d proofs, one prove + verify pass each; "
+                                "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / dispatches" % Bk, kernel=kernel)
+    work = tempfile.mkdtemp(prefix="cpx_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--traffic-child", str(device),
+                   "--ell", str(ell), "--batch", str(Bk)] + [a for kv in opts.items() for a in ("--opt", "%s=%d" % kv)]
+            t0 = time.perf_counter()
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                log, _ = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)   # (our own process group: start_new_session)
+                p.wait()
+                return None, dict(info, failed="%s pass exceeded %d s" % (counter, timeout_s))
+            if p.returncode != 0 or b"traffic_child_ok\": true" not in log:
+                return None, dict(info, failed="%s pass: exit code %d" % (counter, p.returncode), log_tail=log[-400:].decode(errors="replace"))
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, dict(info, failed="%s pass left no counter_collection.csv" % counter)
+            tot, disp = 0.0, set()
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] == counter and r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cpx::", "") == kernel:
+                        tot += float(r["Counter_Value"])
+                        disp.add(r["Dispatch_Id"])
+            if not disp:
+                return None, dict(info, failed="%s pass saw no dispatch of %s" % (counter, kernel))
+            res[counter] = dict(total_kib=tot, dispatches=len(disp), seconds=round(time.perf_counter() - t0, 1))
+        info.update(res)
+        return (2.0 * res["FETCH_SIZE"]["total_kib"] / res["FETCH_SIZE"]["dispatches"] + res["WRITE_SIZE"]["total_kib"] / res["WRITE_SIZE"]["dispatches"]) * 1024.0, info
+    except Exception as e:   # a measurement aid must not take the bench line down
+        return None, dict(info, failed=repr(e))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def run_ab(args, variants, B, barrier, world):
+    """--ab / --ab-lib: blocks of prove + verify passes alternate between the variants in ONE process on ONE box (order reversed every round: A B, B A, ...).
+    variants: [(label, contexts, shares, options)].  Before a block the variant's options are set on its contexts (only when they differ from what the
+    context holds: an option change drops the plans) and one pass runs untimed; then `passes` timed passes, all contexts of the variant side by
+    side as in the headline.  The ratio of the means decides; the per-round ratios show the noise it has to beat."""
+    import threading
+    import curdleproofs_amd as cpx
+    held = {}
+
+    def apply(ctxs, opts):
+        for c in ctxs:
+            for k, v in opts.items():
+                if held.get((id(c), k)) != v:
+                    c.set_option(k, v)
+                    held[(id(c), k)] = v
+
+    def passes(ctxs, shares, n):
+        bad = [0] * len(ctxs)
+
+        def run(i):
+            c, sh = ctxs[i], shares[i]
+            for _ in range(n):
+                proofs = c.prove_batch(sh["perms"], sh["k"], sh["mbl"], sh["prand"], raw=True)
+                bad[i] += sum(1 for v in c.verify_batch(proofs, sh["vrand"]) if v != cpx.CPX_OK)
+        th = [threading.Thread(target=run, args=(i,)) for i in range(1, len(ctxs))]
+        for t in th:
+            t.start()
+        run(0)
+        for t in th:
+            t.join()
+        return sum(bad)
+
+    nbad = 0
+    for label, ctxs, shares, opts in variants:   # buffers and plans of every variant exist before anything is timed
+        apply(ctxs, opts)
+        nbad += passes(ctxs, shares, 1)
+    t0 = time.perf_counter()
+    nbad += passes(variants[0][1], variants[0][2], 1)
+    n = args.ab_passes or max(2, int(round(2.0 / max(time.perf_counter() - t0, 1e-3))))
+    rates = [[] for _ in variants]
+    for r in range(args.ab_rounds):
+        order = list(range(len(variants)))
+        if r % 2:
+            order.reverse()
+        for vi in order:
+            label, ctxs, shares, opts = variants[vi]
+            apply(ctxs, opts)
+            nbad += passes(ctxs, shares, 1)
+            barrier()
+            t0 = time.perf_counter()
+            nbad += passes(ctxs, shares, n)
+            barrier()
+            rates[vi].append(world * B * n / (time.perf_counter() - t0))
+    mean = [sum(x) / len(x) for x in rates]
+    per_round = [[rates[vi][r] / rates[0][r] for r in range(args.ab_rounds)] for vi in range(len(variants))]
+    return dict(variants=[dict(label=variants[vi][0], options=variants[vi][3], proofs_per_s_by_round=rates[vi], mean=mean[vi], ratio_to_first=mean[vi] / mean[0],
+                               ratio_by_round=per_round[vi], ratio_min=min(per_round[vi]), ratio_max=max(per_round[vi])) for vi in range(len(variants))],
+                rounds=args.ab_rounds, passes_per_block=n, order="A B, B A, ... (one untimed pass before every block)", all_verified=nbad == 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,18 +586,27 @@ def main():
                     "GPU), ell=1020 throughput and the all-cores CPU baseline")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option for every context (cpx_ctx_set_option), e.g. "
                     "--opt late_rounds=0 for an A/B run")
+    ap.add_argument("--ab", default="", metavar="KEY=V0,V1[,V2...]", help="in-process interleaved A/B of an engine option on the SAME contexts, batches and box: blocks of "
+                    "passes alternate between the values (order reversed every round), every block after one untimed pass under the new value (plans are rebuilt "
+                    "after an option change); prints the rate of every block, the means and their ratio instead of the bench line.  Honours --batch / --ctxs / --ell / --opt")
+    ap.add_argument("--ab-lib", default="", metavar="PATH", help="the same A/B between two BUILDS of the library (variant 0 = the default libcpx.so, variant 1 = PATH, e.g. "
+                    "curdleproofs_amd.build.build_variant): a second set of contexts with the same instances lives beside the first, blocks of passes alternate")
+    ap.add_argument("--ab-rounds", type=int, default=6, help="rounds of the A/B (each round = one block per variant)")
+    ap.add_argument("--ab-passes", type=int, default=0, help="timed passes per block (0 = about 2 s worth)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes that measure roofline.traffic (then null)")
+    ap.add_argument("--traffic-child", default="", help=argparse.SUPPRESS)   # internal: the process rocprofv3 wraps (one pass of one context under counters)
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child(args)
 
     # --gpus N without a launcher around us: start the N ranks ourselves (one process per GPU, the same command line the
     # driver uses for N > 1) and hand over; under torch.distributed.run WORLD_SIZE is set and must agree with --gpus.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: the launcher's own c10d rendezvous on a port IT binds (localhost:0) — no port is picked here and handed over (the
+        # bind-close-reuse of rounds 1-5 left a window for another process to take it); --local-addr: the container hostname may not resolve
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     import torch
@@ -429,10 +626,12 @@ def main():
         import torch.distributed as dist
         if not os.environ.get("CPX_BENCH_DRYRUN"):
             torch.cuda.set_device(local_rank)
+        import datetime
+        # (rank 0 runs the extra shapes and the CPU baseline while the other ranks wait at the final barrier: minutes, not seconds)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=60))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=60))
         assert dist.get_world_size() == args.gpus, "process group size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
         world = dist.get_world_size()   # n_gpus in the output line is what the process group (RCCL) reports
     if os.environ.get("CPX_BENCH_DRYRUN"):
@@ -456,7 +655,7 @@ def main():
     import threading
     ell, B, K = args.ell, args.batch, max(1, args.ctxs)
     assert B % K == 0, "--batch must be a multiple of --ctxs"
-    engine_opts = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.opt}
+    engine_opts = _parse_opts(args.opt)
     ctxs = [cpx.Context(local_rank, options=engine_opts) for _ in range(K)]          # raises without a GPU: no CPU fallback
     # host worker threads per context: the cores of the node divided over ranks x contexts (all ranks share one node)
     host_threads = args.host_threads or max(2, min(24, effective_cores() // (world * K)))
@@ -469,10 +668,11 @@ def main():
         import pickle
         with open(cache, "rb") as f:
             data = pickle.load(f)
-        if data.get("ell") != ell or data.get("B") != B:
+        if data.get("ell") != ell or data.get("B") != B or "setup_s" not in data:
             data = None
         else:
             ctx.set_crs(ell, data["crs"])
+            data["setup_s"] = dict(data["setup_s"], from_cache=True)
     if data is None:
         data = synth_batch(ctx, ell, B, seed=1234 + rank)
         data["ell"], data["B"] = ell, B
@@ -485,18 +685,54 @@ def main():
     n_ = ell + 4
     def part(buf, unit, k):
         return buf[k * Bk * unit:(k + 1) * Bk * unit]
-    shares = []
-    for k, c in enumerate(ctxs):
-        if k:
-            c.set_crs(ell, data["crs"])
-        sh = dict(vec_R=part(data["vec_R"], ell * cpx.AFF, k), vec_S=part(data["vec_S"], ell * cpx.AFF, k),
-                  vec_T=part(data["vec_T"], ell * cpx.AFF, k), vec_U=part(data["vec_U"], ell * cpx.AFF, k), M=part(data["M"], cpx.JAC, k),
-                  perms=data["perms"][k * Bk * ell:(k + 1) * Bk * ell], k=part(data["k"], cpx.FR, k), mbl=part(data["mbl"], 4 * cpx.FR, k),
-                  prand=part(data["prand"], (3 * n_ + 9) * cpx.FR, k), vrand=part(data["vrand"], 8 * cpx.FR, k))
-        c.load_batch(sh["vec_R"], sh["vec_S"], sh["vec_T"], sh["vec_U"], sh["M"])   # inputs now resident in HBM
-        for key in ("perms", "k", "mbl", "prand", "vrand"):                          # host-side witness buffers, marshalled once
-            sh[key] = c.marshal(sh[key])
-        shares.append(sh)
+
+    def make_shares(cs):
+        shs = []
+        for k, c in enumerate(cs):
+            if c is not ctx:
+                c.set_crs(ell, data["crs"])
+            sh = dict(vec_R=part(data["vec_R"], ell * cpx.AFF, k), vec_S=part(data["vec_S"], ell * cpx.AFF, k),
+                      vec_T=part(data["vec_T"], ell * cpx.AFF, k), vec_U=part(data["vec_U"], ell * cpx.AFF, k), M=part(data["M"], cpx.JAC, k),
+                      perms=data["perms"][k * Bk * ell:(k + 1) * Bk * ell], k=part(data["k"], cpx.FR, k), mbl=part(data["mbl"], 4 * cpx.FR, k),
+                      prand=part(data["prand"], (3 * n_ + 9) * cpx.FR, k), vrand=part(data["vrand"], 8 * cpx.FR, k))
+            # host-side buffers, marshalled once into page-locked memory: the witnesses of every prove, and the public instance (R, S, T, U, M)
+            # that cpx_batch_load moves — once before the timed region, and once per pass in the value_incl_instance_upload leg
+            for key in sh:
+                sh[key] = c.marshal(sh[key])
+            c.load_batch(sh["vec_R"], sh["vec_S"], sh["vec_T"], sh["vec_U"], sh["M"])   # inputs now resident in HBM
+            shs.append(sh)
+        return shs
+    shares = make_shares(ctxs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.ab or args.ab_lib:
+        variants = []
+        if args.ab:
+            key, vals = args.ab.split("=", 1)
+            variants = [("%s=%s" % (key, v), ctxs, shares, {key: int(v)}) for v in vals.split(",")]
+        if args.ab_lib:
+            ctxs_b = [cpx.Context(local_rank, options=engine_opts, lib=args.ab_lib) for _ in range(K)]
+            for c in ctxs_b:
+                c.set_host_threads(host_threads)
+            shares_b = make_shares(ctxs_b)
+            base = variants or [("", ctxs, shares, {})]
+            variants = [((lbl + " " if lbl else "") + "libcpx.so", c_, s_, o_) for lbl, c_, s_, o_ in base] + \
+                       [((lbl + " " if lbl else "") + os.path.basename(args.ab_lib), ctxs_b, shares_b, o_) for lbl, _, _, o_ in base]
+        res = run_ab(args, variants, B, barrier, world)
+        if rank == 0:
+            free_b, total_b = torch.cuda.mem_get_info()
+            print(json.dumps(dict(ab=res, metric="shuffle proofs/sec (prove+verify) at ell=%d, BLS12-381" % ell, unit="proofs/s", n_gpus=world,
+                                  config=dict(ell=ell, batch_per_gpu=B, engine_contexts_per_gpu=K, host_threads_per_context=host_threads, options=engine_opts,
+                                              hbm_used_gb=round((total_b - free_b) / 1e9, 1)))))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0 if res["all_verified"] else 3)
 
     if args.fused_verify:
         return run_config5(args, ctxs, shares, data, ell, B, K, world, rank, dist, torch, red_dev)
@@ -526,12 +762,6 @@ def main():
             for t in th:
                 t.join()
         return [o[0] for o in out], sum(bad)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     warm = {}   # kernel statistics of the warm-up launches (only used for the all-launches average rocprofv3 reports)
     if args.warmup:
@@ -564,6 +794,36 @@ def main():
             for f in acc:
                 acc[f] += st[f]
         c.set_profiling(False)
+    # The same passes with the public instance crossing PCIe inside the timed region (CurdleproofsProof::new / verify take vec_R, vec_S, vec_T,
+    # vec_U, M as arguments, curdleproofs.rs:59-70,197-207; `value` has them resident): every pass of every context starts with cpx_batch_load
+    # of its share (97 KB per proof from page-locked memory on the context's stream, beside the other context's kernels).
+    up_steps = max(2, min(args.steps, 5))
+
+    def steps_with_upload(nsteps):
+        bad = [0] * K
+
+        def run(k):
+            c, sh = ctxs[k], shares[k]
+            for _ in range(nsteps):
+                c.load_batch(sh["vec_R"], sh["vec_S"], sh["vec_T"], sh["vec_U"], sh["M"])
+                proofs_k = c.prove_batch(sh["perms"], sh["k"], sh["mbl"], sh["prand"], raw=True)
+                bad[k] += sum(1 for v in c.verify_batch(proofs_k, sh["vrand"]) if v != cpx.CPX_OK)
+        th = [threading.Thread(target=run, args=(k,)) for k in range(1, K)]
+        for t in th:
+            t.start()
+        run(0)
+        for t in th:
+            t.join()
+        return sum(bad)
+    barrier()
+    t0 = time.perf_counter()
+    nbad_up = steps_with_upload(up_steps)
+    barrier()
+    dt_up = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt_up], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_up = float(t.item())
     hbm_used_gb = None
     if torch.cuda.is_available():
         free_b, total_b = torch.cuda.mem_get_info()
@@ -606,20 +866,7 @@ def main():
         avg_ms = st["ms"] / max(st["launches"], 1)
         bytes_per_launch = st["alg_bytes"] / max(st["launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs)
-            import glob
-            with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.json")))[-1]) as f:   # the newest round's PMC passes
-                hc = json.load(f).get("cpx::" + dom)   # per instantiation, as rocprofv3 names it
-            traffic_src = ("not measured in this run: HBM bytes per launch from the committed rocprofv3 PMC passes %s (separate FETCH_SIZE / WRITE_SIZE runs of "
-                           "scripts/collect_profiles.sh at commit %s)" % (os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_counters.json")))[-1]),
-                                                                           hc.get("commit", "?") if hc else "?"))
-            if hc and hc["batch_per_gpu"] == B and hc.get("engine_contexts_per_gpu", 1) == K:
-                # counters are in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)
-                traffic = (2.0 * hc["FETCH_SIZE"]["total"] / hc["FETCH_SIZE"]["dispatches"]
-                           + hc["WRITE_SIZE"]["total"] / hc["WRITE_SIZE"]["dispatches"]) * 1024.0
-        except Exception:
-            traffic = None
+        traffic, traffic_src = None, dict(skipped="--no-traffic")   # measured at the end of this run (measure_traffic), or null
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, traffic_source=traffic_src, avg_launch_ms=avg_ms, launches=st["launches"], alg_bytes_per_launch=bytes_per_launch,
                         units_per_launch=st["units"] / max(st["launches"], 1),
@@ -646,10 +893,17 @@ def main():
                                 note="kernel time is measured with all engine contexts sharing the GPU, so it includes the other contexts' kernels; "
                                      "'isolated' repeats the measurement after the timed region with one context alone and its side stream's kernels in line "
                                      "(option serial_streams): the kernel has the GPU to itself")
+        per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_tblw_pair": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11,
+                    "k_msm_fix": 16 * PROD_PER_ADD}
+        pair_cost = lambda k: (14 * PROD_PER_ADD if k.startswith("k_msm_fix<19") else per_pair[k.split("<")[0]])
+        # The whole pass against the same peak: the products of the MSM additions of a prove + verify (every point-scalar pair of every MSM kernel of
+        # the timed region x the additions a pair costs x 9.04 products) x the measured rate.  Everything else a pass executes — per-proof table
+        # build, late-round materialisation, bucket reductions, decompression, transcripts — is overhead by this count, and so is idle issue time.
+        useful = sum(v["units"] * pair_cost(k) for k, v in stats.items() if k.split("<")[0] in per_pair and v["launches"]) / max(1.0, float(B * args.steps))
+        roofline["valu"]["whole_pass"] = dict(frac=useful * (value / world) / peak_mm if peak_mm else None, useful_products_per_proof=useful,
+                                              useful_products_per_s_per_gpu=useful * value / world,
+                                              note="useful = modular products of the MSM additions only; per GPU against the product peak measured in this run")
         if iso:   # every MSM kernel, one context alone: point-scalar pairs, additions x their product equivalents against the measured peak
-            per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_tblw_pair": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11,
-                        "k_msm_fix": 16 * PROD_PER_ADD}
-            pair_cost = lambda k: (14 * PROD_PER_ADD if k.startswith("k_msm_fix<19") else per_pair[k.split("<")[0]])
             roofline["valu"]["isolated_by_kernel"] = {
                 k: dict(pairs_per_proof=v["units"] / (B // K), ms_per_proof_batch=v["ms"],
                         frac=(v["units"] * pair_cost(k) / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None,
@@ -673,7 +927,15 @@ def main():
                                         "of configs[3]" % (ell, n, L, B),
                                ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads,
                                fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"), hbm_used_gb=hbm_used_gb, parallelism="proofs sharded over %d GPU(s), no collective" % world),
-                   all_verified=all_ok, algorithmic_bytes_per_proof=b_prove + b_verify,
+                   all_verified=all_ok and nbad_up == 0,
+                   # the same metric with the 97 KB public instance of every proof uploaded (cpx_batch_load) inside the timed region on every pass
+                   value_incl_instance_upload=world * B * up_steps / dt_up,
+                   instance_upload=dict(steps=up_steps, ms_per_step=1e3 * dt_up / up_steps, ratio_to_value=(world * B * up_steps / dt_up) / value,
+                                        bytes_per_proof=4 * ell * cpx.AFF + cpx.JAC,
+                                        note="value: instances resident in HBM before the clock starts (the contract's 'inputs already resident'); here every pass of "
+                                             "every context begins with cpx_batch_load of its share from page-locked host memory, measured right after the timed region"),
+                   setup_s=data.get("setup_s"),
+                   algorithmic_bytes_per_proof=b_prove + b_verify,
                    algorithmic_GBps=value * (b_prove + b_verify) / 1e9,
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
                    vs_readme_i7_8550u=value / README_I7_PROOFS_PER_S, roofline=roofline)
@@ -706,6 +968,12 @@ def main():
             for nb in (128, 1024):
                 if nb <= B:
                     shapes["batch_%d_per_gpu" % nb] = shape_passes(c0, data, ell, nb)
+            if len(ctxs) > 1 and 2048 <= B:
+                # the 1024 proofs of configs[3] on one GPU driven like the headline — two engine contexts: the literal batch split 2 x 512, and two batches
+                # of 1024 in flight (what a service that always has a next batch sees)
+                ctxs[1].set_crs(ell, data["crs"])
+                shapes["batch_1024_per_gpu"]["split_over_two_contexts"] = shape_passes_two(c0, ctxs[1], data, ell, 512)
+                shapes["batch_1024_per_gpu"]["two_contexts"] = shape_passes_two(c0, ctxs[1], data, ell, 1024)
             out["baseline_shapes"] = dict(note="BASELINE configs[3] (1024 independent ell=%d proofs) at its literal shapes, one engine context: 128 proofs per GPU "
                                                "(the per-GPU share on 8 GPUs) and 1024 proofs on one GPU" % ell, **shapes)
             # BASELINE configs[4] at its literal shapes: 4096 proofs in one accumulated check = 512 per GPU on 8 GPUs; and all 4096 on one GPU
@@ -734,6 +1002,13 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ell, data)
         else:
             out["cpu_baseline"] = None
+        if not args.no_traffic and os.environ.get("CPX_BENCH_TRAFFIC", "1") != "0":
+            for c in ctxs:   # the counter passes run in child processes with a context of their own: give the HBM back first
+                c.close()
+            tr, how = measure_traffic(dom, ell, B // K, local_rank, engine_opts)
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, how
+            if tr:
+                out["roofline"]["traffic_over_algorithmic"] = tr / bytes_per_launch if bytes_per_launch else None
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

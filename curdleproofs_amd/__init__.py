@@ -53,6 +53,7 @@ class ProofError(CpxError):
 
 
 _lib = None
+_libs = {}   # realpath -> loaded library (the default one and build variants for A/B runs)
 
 EXPORTS = [
     "cpx_host_alloc", "cpx_host_free", "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_option", "cpx_ctx_get_option", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size", "cpx_batch_size",
@@ -64,12 +65,17 @@ EXPORTS = [
 ]
 
 
-def load_library():
-    """Loads libcpx.so; raises if it has not been built (python -m curdleproofs_amd.build)."""
+def load_library(path=None):
+    """Loads libcpx.so; raises if it has not been built (python -m curdleproofs_amd.build).  `path`: another build of the
+    library (curdleproofs_amd.build.build_variant) beside the default one in the same process — bench.py --ab-lib runs contexts of
+    both on the same GPU, pass by pass; every library is loaded once and keeps its own CRS tables."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    path = os.environ.get("CPX_LIB", _LIB_PATH)   # CPX_LIB: experimental build variant for A/B runs
+    if path is not None and os.path.realpath(path) in _libs:
+        return _libs[os.path.realpath(path)]
+    default = path is None
+    path = path or os.environ.get("CPX_LIB", _LIB_PATH)   # CPX_LIB: experimental build variant as THE library of the process
     if not os.path.exists(path):
         raise ImportError("curdleproofs_amd: %s is missing — build it with `python -m curdleproofs_amd.build` "
                           "(hipcc, gfx950). There is no CPU fallback." % _LIB_PATH)
@@ -120,7 +126,9 @@ def load_library():
     L.cpx_whisk_generate_tracker_proof.argtypes = [vp, vp, vp, vp, vp]
     L.cpx_whisk_is_valid_tracker_proof.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ci)]
     L.cpx_bench_fpmul.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
-    _lib = L
+    _libs[os.path.realpath(path)] = L
+    if default:
+        _lib = L
     return L
 
 
@@ -168,8 +176,8 @@ def _pinned_array(ctype, n):
 class Context:
     """One HIP device + stream + device-resident CRS (cpx_ctx)."""
 
-    def __init__(self, device=0, options=None):
-        self._L = load_library()
+    def __init__(self, device=0, options=None, lib=None):
+        self._L = load_library(lib)
         h = ctypes.c_void_p()
         rc = self._L.cpx_ctx_create(device, ctypes.byref(h))
         if rc != CPX_OK:

@@ -29,15 +29,21 @@ struct cpx_accum {
 };
 
 namespace {
-// HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says otherwise), and kernels of two
-// streams that share a queue do not overlap.  An engine context owns four streams whose kernels are MEANT to overlap (main, side, table,
-// transcript prefix); with two contexts in the process half of the runs put two of one context's streams on one queue: a 128-proof pass
-// then took 28.7 instead of 26.5 ms (3 of 6 runs on one box against 0 of 11 with eight queues; the saturated rate does not care).  Eight queues
-// keep the streams of two contexts apart.  Set when the library is loaded, before the process's first HIP call reads it; a value the
-// caller exported wins.
-struct HwQueueDefault {
-  HwQueueDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} g_hw_queue_default;
+// The host side of this library is compiled for x86-64-v3 + ADX (build.py: the Keccak permutation of the host transcripts and the 64-bit-limb Fr
+// products use BMI2 / ADX forms).  A host without them would die of SIGILL somewhere inside a prove; cpx_ctx_create refuses it instead.
+const char* missing_cpu_feature() {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)   // (this file is compiled as HIP: the device pass has no CPU to ask)
+  __builtin_cpu_init();
+  if (!__builtin_cpu_supports("avx2")) return "AVX2";
+  if (!__builtin_cpu_supports("bmi2")) return "BMI2";
+  if (!__builtin_cpu_supports("fma")) return "FMA";
+  unsigned a = 0, b = 0, c = 0, d = 0;
+  __asm__ volatile("cpuid" : "=a"(a), "=b"(b), "=c"(c), "=d"(d) : "a"(7u), "c"(0u));
+  if (!(b & (1u << 19))) return "ADX";   // CPUID.(EAX=7, ECX=0):EBX bit 19
+#endif
+  return nullptr;
+}
+thread_local std::string g_create_error;   // why the calling thread's last cpx_ctx_create failed (there is no context to ask)
 }  // namespace
 
 namespace {
@@ -92,12 +98,24 @@ void cpx_host_free(void* p) {
 int cpx_ctx_create(int device_id, cpx_ctx** out) {
   if (!out) return CPX_ERR_ARG;
   *out = nullptr;
+  g_create_error.clear();
+  if (const char* f = missing_cpu_feature()) {
+    g_create_error = std::string("cpx_ctx_create: this host CPU lacks ") + f + " (libcpx.so's host code is built for x86-64-v3 + ADX)";
+    return CPX_ERR_STATE;
+  }
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return CPX_ERR_HIP;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) {
+    g_create_error = "cpx_ctx_create: no HIP device with this index";
+    return CPX_ERR_HIP;
+  }
   cpx_ctx* c = new (std::nothrow) cpx_ctx();
   if (!c) return CPX_ERR_INTERNAL;
   try {
     c->eng = new Engine(device_id);
+  } catch (const std::exception& e) {
+    g_create_error = std::string("cpx_ctx_create: ") + e.what();
+    delete c;
+    return CPX_ERR_HIP;
   } catch (...) {
     delete c;
     return CPX_ERR_HIP;
@@ -125,7 +143,7 @@ int cpx_ctx_get_option(const cpx_ctx* ctx, const char* key, long long* value) {
   *value = v;
   return CPX_OK;
 }
-const char* cpx_last_error(const cpx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+const char* cpx_last_error(const cpx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }   // NULL: why this thread's last cpx_ctx_create failed
 
 int cpx_ctx_set_crs(cpx_ctx* ctx, size_t ell, const uint8_t* points, size_t n_points) {
   if (!points) return CPX_ERR_ARG;

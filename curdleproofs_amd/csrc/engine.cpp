@@ -916,7 +916,7 @@ void Engine::batch_prove_tables(const uint32_t* permutation, const uint8_t* k_in
     CPX_HIP(hipEventCreateWithFlags(&side_.lat_ev, hipEventDisableTiming));
   }
   const hipStream_t sside = side_.lat_stream;
-  TeamScope team(this, B);   // 2 ... device_min_batch - 1 (95) proofs: the host loops between the phases on spinning helper threads
+  TeamScope team(this, B);   // 2 ... device_min_batch - 1 (55) proofs: the host loops between the phases on spinning helper threads
   StreamSwap lat_main(stream_, B <= 8 ? side_.lat_main : nullptr, side_.lat_ev);   // a few proofs: the phases on the lower half of the CUs
   const SlotMap sm(L);
   const size_t nrand = 3 * n + 9;
@@ -1531,7 +1531,7 @@ void Engine::verify_core(const uint8_t* proofs, const uint8_t* rand, size_t rand
     return;
   }
 
-  TeamScope team(this, B);   // 2 ... device_min_batch - 1 (95) proofs: the host loops on spinning helper threads
+  TeamScope team(this, B);   // 2 ... device_min_batch - 1 (55) proofs: the host loops on spinning helper threads
   struct VState {
     Transcript tr{"curdleproofs"};
     bool bad = false;           // deserialisation failure

@@ -303,7 +303,8 @@ class Engine {
   // proofs per launch of the device prover's table build: equal chunks of about two million base points (8192 proofs of ell = 252: two chunks
   // of 4096; every chunk launch ends in a tail of long waves: five chunks cost the build 5 %)
   size_t table_chunk_rows(size_t batch) const {
-    const size_t nch = std::max<size_t>(1, (batch * np() + ((size_t)1 << 20)) >> 21);
+    const size_t nch = opt_.table_chunks > 0 ? std::min<size_t>((size_t)opt_.table_chunks, std::max<size_t>(1, batch))
+                                             : std::max<size_t>(1, (batch * np() + ((size_t)1 << 20)) >> 21);
     return (batch + nch - 1) / nch;
   }
   struct DevVerifier {

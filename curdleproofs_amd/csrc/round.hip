@@ -302,6 +302,8 @@ void launch_round_fused(const RoundDev& rd, const ProveDev& d, int j, bool ipa, 
   }
   CASE(8, 8) CASE(8, 16) CASE(8, 32) CASE(16, 8) CASE(16, 16) CASE(16, 32)
 #undef CASE
+  // (4 / 16 exists as combined waves only: a round that reaches this line would add no cross terms, draw no challenge and fold nothing)
+  throw std::invalid_argument("launch_round_fused: no kernel for this wave shape without combined waves");
 }
 
 }  // namespace cpx

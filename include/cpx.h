@@ -41,6 +41,12 @@ extern "C" {
 typedef struct cpx_ctx cpx_ctx;
 
 /* ---- context ------------------------------------------------------------------------------- */
+/* cpx_ctx_create fails with CPX_ERR_HIP when there is no such HIP device (there is no CPU fallback) and with CPX_ERR_STATE when the host
+ * CPU lacks AVX2 / BMI2 / FMA / ADX (the library's host code is built for x86-64-v3 + ADX; every EPYC that hosts an MI355X has them) —
+ * instead of dying of SIGILL later.  cpx_last_error(NULL) then says why the calling thread's last cpx_ctx_create failed.
+ * The library does not touch the process environment.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and a context
+ * owns four streams that are meant to overlap: export GPU_MAX_HW_QUEUES=8 before the process's first HIP call when two or more contexts
+ * share a process (the Python package and bench.py do). */
 int cpx_ctx_create(int device_id, cpx_ctx** out);
 void cpx_ctx_destroy(cpx_ctx* ctx);
 const char* cpx_last_error(const cpx_ctx* ctx); /* message of the last failing call on this ctx    */

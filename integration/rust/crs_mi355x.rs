@@ -23,8 +23,17 @@ pub fn generate_random_points(num_points: usize, seed: &str) -> (Vec<G1Affine>, 
     let cofactor = [Fr::from(COFACTOR)]; // < r
     // The candidates are points of E(Fp), not of the order-r subgroup: cpx_g1_scale's default form splits the scalar by the G1
     // endomorphism (an identity of the subgroup only); option scale_any_point selects the plain double-and-add for this context.
+    // The context is the thread's shared one (ffi.rs `ctx()`): the option goes back to 0 when this function returns or unwinds, so that
+    // later cpx_g1_fold / cpx_g1_scale calls of util_mi355x.rs on this thread keep the 129-step endomorphism form (crs.py: try / finally).
+    struct AnyPoint(*mut cpx_ctx, std::ffi::CString);
+    impl Drop for AnyPoint {
+        fn drop(&mut self) {
+            unsafe { cpx_ctx_set_option(self.0, self.1.as_ptr(), 0) };
+        }
+    }
     let key = std::ffi::CString::new("scale_any_point").unwrap();
     assert_eq!(unsafe { cpx_ctx_set_option(h, key.as_ptr(), 1) }, CPX_OK);
+    let _restore = AnyPoint(h, key);
     let mut points: Vec<G1Affine> = vec![];
     let mut increment = 0u64;
     while points.len() != num_points {

@@ -60,6 +60,50 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["max_over_ranks_dt"] == 2.0 and d["steps"] == 2 and d["warmup"] == 1
 
 
+def test_bench_gpus_8_dry_run():
+    """The driver's one-shot scaling run ends at N = 8: the same rehearsal with eight ranks (gloo, no GPU) — the launcher's own rendezvous
+    (--standalone: it binds the port itself), eight process-group members, the max over ranks, one line from rank 0, two host threads per
+    engine context under the 16-core quota."""
+    env = dict(os.environ, CPX_BENCH_DRYRUN="1", CPX_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["max_over_ranks_dt"] == 8.0 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["host_threads_per_context"] >= 2
+
+
+def test_bench_under_the_drivers_launcher_command_line():
+    """The driver does not use bench.py's own launcher for N > 1: it runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`.  The same command line, dry, with N = 2."""
+    import socket
+    env = dict(os.environ, CPX_BENCH_DRYRUN="1", CPX_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    with socket.socket() as sk:   # (the driver picks its port; any free one will do for the rehearsal)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_synthetic_scalars_are_seeded_and_below_the_group_order():
+    sys.path.insert(0, ROOT)
+    import bench
+    from curdleproofs_amd import params as pr
+    a, b = bench.synth_scalars(7, 1000), bench.synth_scalars(7, 1000)
+    assert a == b and a != bench.synth_scalars(8, 1000) and len(a) == 32000
+    vals = [int.from_bytes(a[32 * i:32 * i + 32], "little") for i in range(1000)]
+    assert all(0 < v < pr.R for v in vals) and len(set(vals)) == 1000 and max(vals).bit_length() == 254
+
+
 def test_bench_refuses_a_world_that_disagrees_with_gpus():
     env = dict(os.environ, CPX_BENCH_DRYRUN="1", CPX_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)

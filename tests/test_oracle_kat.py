@@ -224,3 +224,16 @@ def test_infinity_flag_encodings_in_both_reading_modes(orc):
                 orc.g1_decompress(bytes([0x40]) + bytes(47))   # no compression flag: an error in both modes
     finally:
         orc.set_strict_infinity(False)
+
+
+def test_committed_mont_asm_header_is_the_generators_output():
+    """oracle/mont_asm.h (the mulx / adcx / adox product of the fast CPU-baseline build) is generated by oracle/gen_mont_asm.py and
+    committed; the Makefile no longer regenerates it by mtime, so the two are held together here."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    out = subprocess.run([sys.executable, os.path.join(here, "gen_mont_asm.py")], capture_output=True, text=True, timeout=120, cwd=here)
+    assert out.returncode == 0, out.stderr[-500:]
+    with open(os.path.join(here, "mont_asm.h")) as f:
+        assert f.read() == out.stdout

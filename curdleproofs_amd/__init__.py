@@ -59,7 +59,7 @@ EXPORTS = [
     "cpx_host_alloc", "cpx_host_free", "cpx_ctx_create", "cpx_ctx_destroy", "cpx_last_error", "cpx_device_count", "cpx_ctx_set_option", "cpx_ctx_get_option", "cpx_ctx_set_crs", "cpx_crs_sums", "cpx_proof_size", "cpx_batch_size",
     "cpx_g1_msm", "cpx_g1_msm_jac", "cpx_g1_fold", "cpx_g1_scale", "cpx_g1_normalize", "cpx_g1_decompress", "cpx_g1_decompress_status",
     "cpx_accum_new", "cpx_accum_free", "cpx_accum_check", "cpx_accum_verify",
-    "cpx_batch_load", "cpx_batch_prove", "cpx_batch_verify", "cpx_batch_verify_fused", "cpx_g1_sum_jac",
+    "cpx_batch_load", "cpx_batch_load_begin", "cpx_batch_load_end", "cpx_batch_prove", "cpx_batch_verify", "cpx_batch_verify_fused", "cpx_g1_sum_jac",
     "cpx_whisk_generate_shuffle_proof", "cpx_whisk_is_valid_shuffle_proof", "cpx_whisk_generate_tracker_proof", "cpx_whisk_is_valid_tracker_proof",
     "cpx_set_profiling", "cpx_reset_stats", "cpx_get_stat", "cpx_set_host_threads", "cpx_bench_fpmul",
 ]
@@ -112,6 +112,8 @@ def load_library(path=None):
     L.cpx_accum_check.argtypes = [vp, vp, vp, vp, sz, vp]
     L.cpx_accum_verify.argtypes = [vp]
     L.cpx_batch_load.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+    L.cpx_batch_load_begin.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+    L.cpx_batch_load_end.argtypes = [vp]
     L.cpx_batch_prove.argtypes = [vp, vp, vp, vp, vp, vp]
     L.cpx_batch_verify.argtypes = [vp, vp, vp, vp]
     L.cpx_set_profiling.argtypes = [vp, ci]
@@ -308,6 +310,26 @@ class Context:
             if len(v) != batch * self.ell * AFF:
                 raise ValueError("every instance vector must hold batch * ell affine points (%d bytes), got %d" % (batch * self.ell * AFF, len(v)))
         self._check(self._L.cpx_batch_load(self._h, batch, _in(vec_R), _in(vec_S), _in(vec_T), _in(vec_U), _in(M)))
+
+    def load_batch_begin(self, vec_R, vec_S, vec_T, vec_U, M):
+        """Starts uploading the NEXT batch beside the kernels of the loaded one (cpx_batch_load_begin); the buffers — best page-locked ones from
+        `marshal` — must stay untouched until load_batch_end() returns, which makes the staged batch the loaded one."""
+        if self.ell is None:
+            raise CpxError(CPX_ERR_STATE, "set_crs first")
+        batch = len(M) // JAC
+        if batch == 0 or len(M) % JAC:
+            raise ValueError("M: one Jacobian point (144 bytes) per instance")
+        for v in (vec_R, vec_S, vec_T, vec_U):
+            if len(v) != batch * self.ell * AFF:
+                raise ValueError("every instance vector must hold batch * ell affine points (%d bytes), got %d" % (batch * self.ell * AFF, len(v)))
+        self._staged = tuple(_in(v) for v in (vec_R, vec_S, vec_T, vec_U, M))   # kept alive until load_batch_end
+        self._check(self._L.cpx_batch_load_begin(self._h, batch, *self._staged))
+
+    def load_batch_end(self):
+        try:
+            self._check(self._L.cpx_batch_load_end(self._h))
+        finally:
+            self._staged = None
 
     @staticmethod
     def marshal(data):

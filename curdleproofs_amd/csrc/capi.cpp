@@ -270,6 +270,19 @@ int cpx_batch_load(cpx_ctx* ctx, size_t batch, const uint8_t* vec_R, const uint8
     return CPX_OK;
   });
 }
+int cpx_batch_load_begin(cpx_ctx* ctx, size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M) {
+  if (!batch || !vec_R || !vec_S || !vec_T || !vec_U || !M) return CPX_ERR_ARG;
+  return guarded(ctx, [&] {
+    ctx->eng->batch_load_begin(batch, vec_R, vec_S, vec_T, vec_U, M);
+    return CPX_OK;
+  });
+}
+int cpx_batch_load_end(cpx_ctx* ctx) {
+  return guarded(ctx, [&] {
+    ctx->eng->batch_load_end();
+    return CPX_OK;
+  });
+}
 int cpx_batch_prove(cpx_ctx* ctx, const uint32_t* permutation, const uint8_t* k, const uint8_t* vec_m_blinders, const uint8_t* rand, uint8_t* proofs_out) {
   if (!permutation || !k || !vec_m_blinders || !rand || !proofs_out) return CPX_ERR_ARG;
   return guarded(ctx, [&] {

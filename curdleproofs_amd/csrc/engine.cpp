@@ -61,6 +61,9 @@ Engine::~Engine() {
   if (tab_.dstream) (void)hipStreamDestroy(tab_.dstream);
   for (hipEvent_t e : {dprove_.ev_a, dprove_.ev_b, dprove_.ev_c, dprove_.ev_d, dprove_.ev_t1, dprove_.ev_t2, dprove_.ev_a2, dverify_.ev_a, dverify_.ev_b})
     if (e) (void)hipEventDestroy(e);
+  if (stage_.uploaded) (void)hipEventDestroy(stage_.uploaded);
+  if (stage_.consumed) (void)hipEventDestroy(stage_.consumed);
+  if (stage_.stream) (void)hipStreamDestroy(stage_.stream);
   if (side_.stream) (void)hipStreamDestroy(side_.stream);
   if (side_.hi_stream) (void)hipStreamDestroy(side_.hi_stream);
   if (side_.lat_stream) (void)hipStreamDestroy(side_.lat_stream);
@@ -448,6 +451,7 @@ void Engine::set_crs(size_t ell, const uint8_t* points) {
   } catch (...) {   // e.g. out of device memory while building the tables: the context is left without a CRS, not half-initialised
     ell_ = n_ = L_ = 0;
     B_ = 0;
+    consts_rows_ = 0;
     crs_tab_.reset();
     throw;
   }
@@ -476,6 +480,7 @@ void Engine::set_crs_impl(size_t ell, const uint8_t* points) {
   crs_single_[2] = pts[n + 2];
   // G_sum, H_sum (crs.rs:46-47) as unit-scalar MSMs on the device
   B_ = 0;
+  consts_rows_ = 0;
   pp_stride_ = 4 * ell_ + SlotMap(L_).count();
   d_pp_.ensure(pp_stride_);
   SVec ones(ell, S::one());
@@ -572,11 +577,20 @@ void Engine::crs_sums(uint8_t* g_sum, uint8_t* h_sum) const {
 // ---------------------------------------------------------------- tier 0
 void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out_jac) {
   CPX_HIP(hipSetDevice(device_));
-  DevBuf<Aff> db;
-  DevBuf<Fr> ds;
-  DevBuf<MsmTask> dt;
-  DevBuf<TJac> w, pt;
-  DevBuf<Jac> res;
+  DevBuf<Aff>& db = t0_.a0;   // (tier-0 scratch of the engine, engine.hpp: no allocation on the call path once warm)
+  DevBuf<Fr>& ds = t0_.fr;
+  DevBuf<MsmTask>& dt = t0_.mtask;
+  DevBuf<TJac>&w = t0_.w, &pt = t0_.pt;
+  DevBuf<Jac>& res = t0_.res;
+  struct Trim {
+    Engine* e;
+    ~Trim() {
+      tier0_trim(e->t0_.a0);
+      tier0_trim(e->t0_.fr);
+      tier0_trim(e->t0_.conv);
+      tier0_trim(e->t0_.dig);
+    }
+  } trim{this};
   db.ensure(std::max<size_t>(n, 1));
   ds.ensure(std::max<size_t>(n, 1));
   dt.ensure(1);
@@ -589,12 +603,12 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   }
   MsmTask t{db.p, nullptr, ds.p, (uint32_t)n, 0, 0};
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
-  DevBuf<TAff> conv;
+  DevBuf<TAff>& conv = t0_.conv;
   conv.ensure(2 * std::max<size_t>(n, 1));
   if (n >= 64) {   // endomorphism split + radix-256 bucket lists (the verifier's kernel): 32 additions per point
-    DevBuf<TblTask> tt;
-    DevBuf<TJac> part;
-    DevBuf<uint32_t> dig;
+    DevBuf<TblTask>& tt = t0_.ttask;
+    DevBuf<TJac>& part = t0_.part;
+    DevBuf<uint32_t>& dig = t0_.dig;
     const int slices = msm_tblw_slices(opt_, 1, 2, (int)n);
     tt.ensure(1);
     part.ensure(32 * (size_t)slices);
@@ -606,7 +620,7 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
     reduce_sets(0, 32 * (size_t)slices, part.p);
     launch_msm_tail(opt_, part.p, nullptr, res.p, 1, 16, 8, stream_, nullptr, 0, 2 * slices);
     CPX_HIP(hipMemcpyAsync(out_jac, res.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
-    CPX_HIP(hipStreamSynchronize(stream_));   // before the scratch buffers above go out of scope
+    CPX_HIP(hipStreamSynchronize(stream_));   // the result is in out_jac; the scratch may be reused by the next call
     flush_timers();
     return;
   }
@@ -622,9 +636,9 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
 void Engine::normalize(const uint8_t* jac, size_t n, uint8_t* out_aff, uint8_t* out_comp) {
   CPX_HIP(hipSetDevice(device_));
   if (!n) return;
-  DevBuf<Jac> dj;
-  DevBuf<Aff> da;
-  DevBuf<uint8_t> dc;
+  DevBuf<Jac>& dj = t0_.jin;
+  DevBuf<Aff>& da = t0_.a0;
+  DevBuf<uint8_t>& dc = t0_.bytes;
   dj.ensure(n);
   da.ensure(n);
   dc.ensure(n * 48);
@@ -633,11 +647,14 @@ void Engine::normalize(const uint8_t* jac, size_t n, uint8_t* out_aff, uint8_t* 
   if (out_aff) CPX_HIP(hipMemcpyAsync(out_aff, da.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
   if (out_comp) CPX_HIP(hipMemcpyAsync(out_comp, dc.p, n * 48, hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
+  tier0_trim(dj);
+  tier0_trim(da);
+  tier0_trim(dc);
 }
 bool Engine::sum_jac(const uint8_t* points_jac, size_t n, uint8_t* out_jac) {
   CPX_HIP(hipSetDevice(device_));
-  DevBuf<Jac> din, dout;
-  DevBuf<int> dflag;
+  DevBuf<Jac>&din = t0_.jin, &dout = t0_.res;
+  DevBuf<int>& dflag = t0_.flag;
   din.ensure(std::max<size_t>(n, 1));
   dout.ensure(1);
   dflag.ensure(1);
@@ -647,6 +664,7 @@ bool Engine::sum_jac(const uint8_t* points_jac, size_t n, uint8_t* out_jac) {
   CPX_HIP(hipMemcpyAsync(out_jac, dout.p, sizeof(Jac), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipMemcpyAsync(&flag, dflag.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
+  tier0_trim(din);
   return flag != 0;
 }
 void Engine::msm_jac(const uint8_t* bases_jac, const uint8_t* scalars, size_t n, uint8_t* out_jac) {
@@ -657,9 +675,9 @@ void Engine::msm_jac(const uint8_t* bases_jac, const uint8_t* scalars, size_t n,
 void Engine::fold(uint8_t* PL, const uint8_t* PR, const uint8_t* gamma, size_t half) {
   CPX_HIP(hipSetDevice(device_));
   if (!half) return;
-  DevBuf<Aff> dl, dr;
-  DevBuf<Fr> dg;
-  DevBuf<SmulTask> dt;
+  DevBuf<Aff>&dl = t0_.a0, &dr = t0_.a1;
+  DevBuf<Fr>& dg = t0_.fr;
+  DevBuf<SmulTask>& dt = t0_.stask;
   dl.ensure(half);
   dr.ensure(half);
   dg.ensure(1);
@@ -675,13 +693,15 @@ void Engine::fold(uint8_t* PL, const uint8_t* PR, const uint8_t* gamma, size_t h
   CPX_HIP(hipMemcpyAsync(PL, dl.p, half * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
   flush_timers();
+  tier0_trim(dl);
+  tier0_trim(dr);
 }
 void Engine::scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_stride, size_t n, uint8_t* out) {
   CPX_HIP(hipSetDevice(device_));
   if (!n) return;
-  DevBuf<Aff> dp, dout;
-  DevBuf<Fr> dsc;
-  DevBuf<SmulTask> dt;
+  DevBuf<Aff>&dp = t0_.a0, &dout = t0_.a1;
+  DevBuf<Fr>& dsc = t0_.fr;
+  DevBuf<SmulTask>& dt = t0_.stask;
   const size_t ns = scalar_stride ? n : 1;
   dp.ensure(n);
   dout.ensure(n);
@@ -697,6 +717,9 @@ void Engine::scale(const uint8_t* P, const uint8_t* scalars, size_t scalar_strid
   CPX_HIP(hipMemcpyAsync(out, dout.p, n * sizeof(Aff), hipMemcpyDeviceToHost, stream_));
   CPX_HIP(hipStreamSynchronize(stream_));
   flush_timers();
+  tier0_trim(dp);
+  tier0_trim(dout);
+  tier0_trim(dsc);
 }
 // Encodings with the infinity flag set (include/cpx.h, option strict_infinity).  ark-bls12-381 ^0.4's `read_g1_compressed` — the
 // deserialiser behind `G1Affine::deserialize_compressed`, whisk.rs:313-320 — returns the identity as soon as the compression and the
@@ -734,8 +757,8 @@ int Engine::decompress(const uint8_t* comp, size_t n, uint8_t* out_aff, int chec
   CPX_HIP(hipSetDevice(device_));
   if (!n) return CPX_OK;
   comp = canonical_infinities(comp, n * 48, n, 48, {0});
-  DevBuf<uint8_t> dc, dst;
-  DevBuf<Aff> da;
+  DevBuf<uint8_t>&dc = t0_.bytes, &dst = t0_.status;
+  DevBuf<Aff>& da = t0_.a0;
   dc.ensure(n * 48);
   dst.ensure(n);
   da.ensure(n);
@@ -784,47 +807,96 @@ double Engine::bench_fpmul(int blocks, int iters, int reps) {
 }
 
 // ---------------------------------------------------------------- batch load
-void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M) {
+// The public instance of `batch` proofs -> the engine's instance buffers, from host memory (batch_load) or from the device staging area of
+// batch_load_begin (batch_load_end: device-to-device, a few hundred microseconds per GB).  Everything is enqueued on the main stream.
+void Engine::load_rows(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M, bool from_device) {
   if (!ell_) throw std::logic_error("set_crs first");
   CPX_HIP(hipSetDevice(device_));
+  const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   const SlotMap sm(L_);
   pp_stride_ = 4 * ell_ + sm.count();
+  const Aff* pp_before = d_pp_.p;
+  const Aff* psrc_before = d_psrc_.p;
   d_pp_.ensure(batch * pp_stride_);
   d_Mjac_.ensure(batch);
   B_ = batch;
   const size_t vb = ell_ * sizeof(Aff);
   // strided 2-D copies: one per instance vector instead of one per proof
   const size_t pitch = pp_stride_ * sizeof(Aff);
-  auto rows = [&](Aff* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width) {
-    CPX_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, batch, hipMemcpyHostToDevice, stream_));
+  auto rows = [&](Aff* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, hipMemcpyKind k) {
+    CPX_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, batch, k, stream_));
   };
-  rows(pp(0), pitch, vec_R, vb, vb);
-  rows(pp(0) + ell_, pitch, vec_S, vb, vb);
-  rows(pp(0) + 2 * ell_, pitch, vec_T, vb, vb);
-  rows(pp(0) + 3 * ell_, pitch, vec_U, vb, vb);
-  std::vector<Aff> rep(batch * 5);   // the same constants for every proof (a pitch of 0 is not a valid 2-D copy)
-  for (size_t p = 0; p < batch; p++) memcpy(&rep[5 * p], crs_single_, 5 * sizeof(Aff));
-  rows(slot(0, SL_H), pitch, reinterpret_cast<const uint8_t*>(rep.data()), 5 * sizeof(Aff), 5 * sizeof(Aff));
-  CPX_HIP(hipMemcpyAsync(d_Mjac_.p, M, batch * sizeof(Jac), hipMemcpyHostToDevice, stream_));
-  std::vector<Aff> tails;   // outlives the asynchronous copies below (synchronised at the end of this function)
-  {
-    // copy 0 of the per-proof tables: M (filled at prove time) | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
-    const size_t NP = np();
-    d_ptab_.ensure(batch * (size_t)copies_ * NP);
-    d_psrc_.ensure(batch * NP);
-    // build scratch: the 15 doubled copies of every point — of one chunk of the device prover's table build (engine_device.cpp); the host-driven
-    // prover, which builds all rows at once, makes sure of its own (batch_prove_tables)
-    d_tbltmp_.ensure(table_chunk_rows(batch) * NP * (size_t)(copies_ / 2 - 1));
-    tails.assign(batch * 8, Aff::identity());
+  rows(pp(0), pitch, vec_R, vb, vb, kind);
+  rows(pp(0) + ell_, pitch, vec_S, vb, vb, kind);
+  rows(pp(0) + 2 * ell_, pitch, vec_T, vb, vb, kind);
+  rows(pp(0) + 3 * ell_, pitch, vec_U, vb, vb, kind);
+  CPX_HIP(hipMemcpyAsync(d_Mjac_.p, M, batch * sizeof(Jac), kind, stream_));
+  // copy 0 of the per-proof tables: M (filled at prove time) | T || O O H O | U || O O O H  (curdleproofs.rs:141-155)
+  const size_t NP = np();
+  d_ptab_.ensure(batch * (size_t)copies_ * NP);
+  d_psrc_.ensure(batch * NP);
+  // build scratch: the 15 doubled copies of every point — of one chunk of the device prover's table build (engine_device.cpp); the host-driven
+  // prover, which builds all rows at once, makes sure of its own (batch_prove_tables)
+  d_tbltmp_.ensure(table_chunk_rows(batch) * NP * (size_t)(copies_ / 2 - 1));
+  const size_t spitch = NP * sizeof(Aff);
+  Aff* t = d_psrc_.p;
+  rows(t + 1, spitch, vec_T, vb, vb, kind);
+  rows(t + 1 + n_, spitch, vec_U, vb, vb, kind);
+  // The constants every proof's row carries (the CRS's single points in five slots; the blinder tails O O H O / O O O H behind T and U) are the
+  // same for every batch of this CRS: written when the buffers are new, have grown, or the CRS has changed — not on every load
+  if (consts_rows_ < batch || pp_before != d_pp_.p || psrc_before != d_psrc_.p) {
+    std::vector<Aff> rep(batch * 5);   // (a pitch of 0 is not a valid 2-D copy)
+    for (size_t p = 0; p < batch; p++) memcpy(&rep[5 * p], crs_single_, 5 * sizeof(Aff));
+    rows(slot(0, SL_H), pitch, reinterpret_cast<const uint8_t*>(rep.data()), 5 * sizeof(Aff), 5 * sizeof(Aff), hipMemcpyHostToDevice);
+    std::vector<Aff> tails(batch * 8, Aff::identity());
     for (size_t p = 0; p < batch; p++) tails[8 * p + 2] = tails[8 * p + 7] = crs_single_[0];
-    const size_t spitch = NP * sizeof(Aff);
-    Aff* t = d_psrc_.p;
-    rows(t + 1, spitch, vec_T, vb, vb);
-    rows(t + 1 + ell_, spitch, reinterpret_cast<const uint8_t*>(tails.data()), 8 * sizeof(Aff), 4 * sizeof(Aff));
-    rows(t + 1 + n_, spitch, vec_U, vb, vb);
-    rows(t + 1 + n_ + ell_, spitch, reinterpret_cast<const uint8_t*>(tails.data() + 4), 8 * sizeof(Aff), 4 * sizeof(Aff));
+    rows(t + 1 + ell_, spitch, reinterpret_cast<const uint8_t*>(tails.data()), 8 * sizeof(Aff), 4 * sizeof(Aff), hipMemcpyHostToDevice);
+    rows(t + 1 + n_ + ell_, spitch, reinterpret_cast<const uint8_t*>(tails.data() + 4), 8 * sizeof(Aff), 4 * sizeof(Aff), hipMemcpyHostToDevice);
+    CPX_HIP(hipStreamSynchronize(stream_));   // rep / tails leave scope
+    consts_rows_ = batch;
   }
-  CPX_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M) {
+  load_rows(batch, vec_R, vec_S, vec_T, vec_U, M, false);
+  CPX_HIP(hipStreamSynchronize(stream_));   // the caller's buffers are free again
+}
+// cpx_batch_load_begin / _end (include/cpx.h): the NEXT batch's instance crosses PCIe on an upload stream of its own while the loaded batch is
+// being proven and verified; _end makes it the loaded batch with device-to-device copies behind the main stream's last kernel.
+void Engine::batch_load_begin(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M) {
+  if (!ell_) throw std::logic_error("set_crs first");
+  CPX_HIP(hipSetDevice(device_));
+  if (!stage_.stream) {
+    CPX_HIP(hipStreamCreateWithFlags(&stage_.stream, hipStreamNonBlocking));
+    CPX_HIP(hipEventCreateWithFlags(&stage_.uploaded, hipEventDisableTiming));
+    CPX_HIP(hipEventCreateWithFlags(&stage_.consumed, hipEventDisableTiming));
+  }
+  const size_t pts = batch * ell_;
+  for (auto* b : {&stage_.R, &stage_.S, &stage_.T, &stage_.U}) b->ensure(pts);
+  stage_.M.ensure(batch);
+  if (stage_.have_consumed) CPX_HIP(hipStreamWaitEvent(stage_.stream, stage_.consumed, 0));   // the previous staged batch has been copied out
+  CPX_HIP(hipMemcpyAsync(stage_.R.p, vec_R, pts * sizeof(Aff), hipMemcpyHostToDevice, stage_.stream));
+  CPX_HIP(hipMemcpyAsync(stage_.S.p, vec_S, pts * sizeof(Aff), hipMemcpyHostToDevice, stage_.stream));
+  CPX_HIP(hipMemcpyAsync(stage_.T.p, vec_T, pts * sizeof(Aff), hipMemcpyHostToDevice, stage_.stream));
+  CPX_HIP(hipMemcpyAsync(stage_.U.p, vec_U, pts * sizeof(Aff), hipMemcpyHostToDevice, stage_.stream));
+  CPX_HIP(hipMemcpyAsync(stage_.M.p, M, batch * sizeof(Jac), hipMemcpyHostToDevice, stage_.stream));
+  CPX_HIP(hipEventRecord(stage_.uploaded, stage_.stream));
+  stage_.batch = batch;
+  stage_.ell = ell_;
+}
+void Engine::batch_load_end() {
+  if (!stage_.batch) throw std::logic_error("batch_load_begin first");
+  if (stage_.ell != ell_) {
+    stage_.batch = 0;
+    throw std::logic_error("the CRS changed between batch_load_begin and batch_load_end");
+  }
+  CPX_HIP(hipSetDevice(device_));
+  CPX_HIP(hipEventSynchronize(stage_.uploaded));   // the caller's host buffers are free again when this call returns
+  const size_t batch = stage_.batch;
+  stage_.batch = 0;
+  load_rows(batch, reinterpret_cast<const uint8_t*>(stage_.R.p), reinterpret_cast<const uint8_t*>(stage_.S.p), reinterpret_cast<const uint8_t*>(stage_.T.p),
+            reinterpret_cast<const uint8_t*>(stage_.U.p), reinterpret_cast<const uint8_t*>(stage_.M.p), true);
+  CPX_HIP(hipEventRecord(stage_.consumed, stream_));
+  stage_.have_consumed = true;
 }
 
 // ---------------------------------------------------------------- prover

@@ -72,6 +72,11 @@ template <class T> struct DevBuf {
     CPX_HIP(hipMalloc(&p, n * sizeof(T)));
     cap = n;
   }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
   ~DevBuf() {
     if (p) (void)hipFree(p);
   }
@@ -144,6 +149,9 @@ class Engine {
 
   // ---- tier 2: batches of whole proofs, instance data resident in HBM ----
   void batch_load(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M);
+  // the next batch's instance uploaded beside the running batch (include/cpx.h cpx_batch_load_begin / _end)
+  void batch_load_begin(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M);
+  void batch_load_end();
   // witnesses + the 3n+9 Fr draws per proof (SURVEY §8b RNG contract); writes batch * proof_size() bytes
   void batch_prove(const uint32_t* permutation, const uint8_t* k, const uint8_t* m_blinders, const uint8_t* rand, uint8_t* proofs_out);
   // proofs: batch * proof_size() bytes; rand: batch * 8 Fr; verdict[i] = CPX_OK / CPX_ERR_VERIFY / CPX_ERR_DESERIALIZE
@@ -298,13 +306,36 @@ class Engine {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_t1 = nullptr, ev_t2 = nullptr, ev_a2 = nullptr;   // t1: tables built, t2: B_t, B_u in the registry, a2: the prefix stream is about to launch
   };
   DevProver dprove_;
+  // Scratch of the tier-0 calls (msm, fold, scale, normalize, decompress, sum_jac): kept between calls — a call used to allocate and free up to ten
+  // device buffers of its own (hipMalloc + hipFree: 1.9 ms per 256-point cpx_g1_msm, most of it the allocator); a buffer that has grown beyond
+  // kTier0Keep bytes for one large call is given back at the end of that call.
+  struct Tier0 {
+    DevBuf<Aff> a0, a1;
+    DevBuf<Fr> fr;
+    DevBuf<MsmTask> mtask;
+    DevBuf<SmulTask> stask;
+    DevBuf<TJac> w, pt, part;
+    DevBuf<Jac> res, jin;
+    DevBuf<TAff> conv;
+    DevBuf<TblTask> ttask;
+    DevBuf<uint32_t> dig;
+    DevBuf<uint8_t> bytes, status;
+    DevBuf<int> flag;
+  } t0_;
+  static constexpr size_t kTier0Keep = (size_t)64 << 20;
+  template <class T> static void tier0_trim(DevBuf<T>& b) {
+    if (b.cap * sizeof(T) > kTier0Keep) b.release();
+  }
   void enqueue_prove_device();
   void exec_late_round(const LateRound& r, size_t comp_off, const char* what);
-  // proofs per launch of the device prover's table build: equal chunks of about two million base points (8192 proofs of ell = 252: two chunks
-  // of 4096; every chunk launch ends in a tail of long waves: five chunks cost the build 5 %)
+  // proofs per launch of the device prover's table build (option table_chunks).  Default: ALL rows in one launch while its scratch (15 doubled
+  // copies of every base: 13.5 GB at 8192 proofs of ell = 252) stays below 16 GiB, equal chunks of that size above.  Round 5 shipped two chunks of
+  // 4096 (6.7 GB of scratch) on a cross-box comparison; the in-process A/B of round 6 (bench.py --ab table_chunks=0,1, profiles/r06_ab_table_chunks.json)
+  // has all rows 0.53 % faster in six of six rounds (every chunk launch ends in a tail of long waves) — and HBM footprint is not the metric.
   size_t table_chunk_rows(size_t batch) const {
+    const size_t bytes = batch * np() * (size_t)(copies_ / 2 - 1) * sizeof(TblTmp);
     const size_t nch = opt_.table_chunks > 0 ? std::min<size_t>((size_t)opt_.table_chunks, std::max<size_t>(1, batch))
-                                             : std::max<size_t>(1, (batch * np() + ((size_t)1 << 20)) >> 21);
+                                             : std::max<size_t>(1, (bytes + ((size_t)16 << 30) - 1) >> 34);
     return (batch + nch - 1) / nch;
   }
   struct DevVerifier {
@@ -421,6 +452,16 @@ class Engine {
 
   // batch
   size_t B_ = 0;
+  size_t consts_rows_ = 0;   // rows of d_pp_ / d_psrc_ whose per-CRS constants are in place (load_rows)
+  void load_rows(size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U, const uint8_t* M, bool from_device);
+  struct Stage {   // device staging area of batch_load_begin
+    DevBuf<Aff> R, S, T, U;
+    DevBuf<Jac> M;
+    hipStream_t stream = nullptr;
+    hipEvent_t uploaded = nullptr, consumed = nullptr;
+    bool have_consumed = false;
+    size_t batch = 0, ell = 0;
+  } stage_;
   size_t pp_stride_ = 0;     // 4*ell + NSLOT
   DevBuf<Aff> d_pp_;         // per proof: R|S|T|U | slots
   DevBuf<Jac> d_Mjac_;

@@ -43,7 +43,7 @@ struct Options {
   long late_min_batch = 2048;      // ... for batches of at least this many proofs (n <= 256; scaled by 256 / n above: 512 at ell = 1020); the lane-per-output kernels need a full GPU to pay
   long late_slices = 8;            // lanes per cross term of a late round (1, 2, 4, 8): 15.3 k proofs/s at 8, 14.9 k at 4 and 2, 14.3 k at 1
   long rs_pairs = 1;               // 1: the prover's R and S MSMs of a proof share their waves (same scalars: one digit sort for both); 0: two separate tasks
-  long table_chunks = 0;           // launches of the device prover's per-proof table build: 0 = chunks of about two million base points (8192 proofs of ell = 252: two), k = exactly k equal chunks (1 = all rows at once: 13.5 instead of 6.7 GB of scratch per context at 8192 proofs)
+  long table_chunks = 0;           // launches of the device prover's per-proof table build: 0 = all rows at once while the scratch stays below 16 GiB (8192 proofs of ell = 252: 13.5 GB), k = exactly k equal chunks (2: round 5's default, 6.7 GB, 0.5 % slower in the round-6 A/B)
   long table_stream_max = 4096;            // up to this many proofs (n <= 256; scaled by 256 / n above) the prover's per-proof tables and B_t, B_u run on a table stream beside phase 1 (engine_device.cpp); larger batches fill the GPU with either and keep them in line
   long transcript_excl_max = 256;          // up to this many proofs a wave of k_transcript_step1 claims the whole register file of its SIMD: no wave of a concurrent kernel is placed beside it (a shared SIMD costs a lone dependent chain 1.7x)
   long transcript_lane_min_batch = 8192;   // batches of at least this many proofs (n <= 256; scaled by n / 256 above) hash the transcript prefix with one LANE per proof (k_transcript_step1_lane): a fifth of the wave instructions but a chain of 19 ms at ell = 252 — only where the table build (prover) and the decompression (verifier: 18.7 ms per 8192 proofs) hide it; +2.2 % at 2 x 8192 proofs

@@ -119,6 +119,17 @@ int cpx_accum_verify(cpx_accum* acc);
  * the public inputs of curdleproofs.rs:59-70 / :197-207. */
 int cpx_batch_load(cpx_ctx* ctx, size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U,
                    const uint8_t* M);
+/* The same upload in two halves, for a caller that always has a next batch (a service draining a queue of shuffles): _begin starts moving the
+ * NEXT batch's instance to a staging area in HBM on an upload stream of its own and returns at once — the batch loaded before stays loaded, and
+ * cpx_batch_prove / cpx_batch_verify on it run beside the transfer; _end waits for the transfer (the host buffers, which must stay untouched
+ * from _begin to _end, are free again when it returns) and makes the staged batch the loaded one (device-to-device, behind the context's last
+ * kernel).  97 KB per proof at ell = 252 cross PCIe per instance: with cpx_batch_load in every pass the bench rate is 5 % lower, with
+ * _begin before the prove and _end after the verify it is within 1 % (bench.py `value_incl_instance_upload`).  Page-locked buffers
+ * (cpx_host_alloc) make the transfer asynchronous; pageable ones work, the copy then happens inside _begin.
+ * _end without _begin, or a cpx_ctx_set_crs in between -> CPX_ERR_STATE. */
+int cpx_batch_load_begin(cpx_ctx* ctx, size_t batch, const uint8_t* vec_R, const uint8_t* vec_S, const uint8_t* vec_T, const uint8_t* vec_U,
+                         const uint8_t* M);
+int cpx_batch_load_end(cpx_ctx* ctx);
 /* curdleproofs.rs:59 `CurdleproofsProof::new` for every loaded instance.
  *   permutation  batch*ell u32          k  batch*32          vec_m_blinders  batch*4*32
  *   rand         batch*(3n+9)*32, n = ell+4: the `Fr::rand(rng)` draws in the reference's order —

@@ -61,6 +61,8 @@ extern "C" {
     pub fn cpx_accum_verify(acc: *mut cpx_accum) -> c_int;
     // tier 2: curdleproofs.rs:59, :197 for batches of instances resident in HBM
     pub fn cpx_batch_load(ctx: *mut cpx_ctx, batch: usize, vec_r: *const u8, vec_s: *const u8, vec_t: *const u8, vec_u: *const u8, m: *const u8) -> c_int;
+    pub fn cpx_batch_load_begin(ctx: *mut cpx_ctx, batch: usize, vec_r: *const u8, vec_s: *const u8, vec_t: *const u8, vec_u: *const u8, m: *const u8) -> c_int;
+    pub fn cpx_batch_load_end(ctx: *mut cpx_ctx) -> c_int;
     pub fn cpx_batch_prove(ctx: *mut cpx_ctx, permutation: *const u32, k: *const u8, vec_m_blinders: *const u8, rand: *const u8, proofs_out: *mut u8) -> c_int;
     pub fn cpx_batch_verify(ctx: *mut cpx_ctx, proofs: *const u8, rand: *const u8, verdict: *mut c_int) -> c_int;
     pub fn cpx_batch_verify_fused(ctx: *mut cpx_ctx, proofs: *const u8, rand: *const u8, partial_jac: *mut u8, n_invalid: *mut c_int) -> c_int;

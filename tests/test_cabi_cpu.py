@@ -58,7 +58,10 @@ def test_null_arguments_are_rejected_not_dereferenced(lib):
     assert lib.cpx_batch_prove(None, None, None, None, None, None) == cpx.CPX_ERR_ARG
     assert lib.cpx_whisk_generate_shuffle_proof(None, None, None, None, None, None, None, None) == cpx.CPX_ERR_ARG
     assert lib.cpx_whisk_is_valid_tracker_proof(None, None, None, None, None) == cpx.CPX_ERR_ARG
+    assert lib.cpx_batch_load_begin(None, 1, None, None, None, None, None) == cpx.CPX_ERR_ARG
+    assert lib.cpx_batch_load_end(None) == cpx.CPX_ERR_ARG
     assert lib.cpx_proof_size(None) == 0
+    assert isinstance(lib.cpx_last_error(None), bytes)   # NULL context: the calling thread's last cpx_ctx_create failure (or nothing)
     lib.cpx_ctx_destroy(None)
 
 

@@ -1559,3 +1559,50 @@ def test_bench_measures_hbm_traffic_in_the_run_and_reports_the_upload_inclusive_
     assert 0 < r["valu"]["whole_pass"]["frac"] < 1
     assert d["all_verified"] is True and 0.3 < d["instance_upload"]["ratio_to_value"] < 1.5 and d["value_incl_instance_upload"] > 0
     assert d["setup_s"]["total"] > 0
+
+
+def test_staged_instance_upload_keeps_the_loaded_batch_and_then_replaces_it(orc):
+    """cpx_batch_load_begin / _end: the NEXT batch's instance is uploaded beside the loaded batch's prove + verify and becomes the loaded batch at
+    _end.  Between the two calls the loaded batch still proves to ITS oracle bytes; after _end the staged instances prove to theirs — on the
+    host-driven path (3 proofs) and on the device-resident path (64 proofs).  _end without _begin, and a CRS change in between, are state errors."""
+    import curdleproofs_amd as cpx
+    ell = 28
+    crs = orc.generate_crs_points(ell)
+    base = [orc.make_instance(ell, 900 + i, crs) for i in range(4)]
+    for nb in (3, 64):
+        c = cpx.Context(0)
+        c.set_crs(ell, crs)
+        first = [base[i % 2] for i in range(nb)]            # instances 0 / 1
+        second = [base[2 + i % 2] for i in range(nb)]       # instances 2 / 3
+        cat = lambda insts, k_: b"".join(i[k_] for i in insts)
+        inst = lambda insts: tuple(c.marshal(cat(insts, k_)) for k_ in ("vec_R", "vec_S", "vec_T", "vec_U", "M"))
+        wit = lambda insts: ([x for i in insts for x in i["permutation"]], cat(insts, "k"), cat(insts, "vec_m_blinders"), cat(insts, "prover_rand"))
+        with pytest.raises(cpx.CpxError) as e:
+            c.load_batch_end()
+        assert e.value.code == cpx.CPX_ERR_STATE
+        c.load_batch(*inst(first))
+        staged = inst(second)
+        c.load_batch_begin(*staged)
+        proofs = c.prove_batch(*wit(first))
+        assert [p == i["proof"] for p, i in zip(proofs, first)] == [True] * nb
+        assert c.verify_batch(proofs, cat(first, "verifier_rand")) == [cpx.CPX_OK] * nb
+        c.load_batch_end()
+        assert c.batch == nb
+        assert c.verify_batch(proofs, cat(first, "verifier_rand")) == [cpx.CPX_ERR_VERIFY] * nb   # the old proofs do not fit the new instances
+        proofs2 = c.prove_batch(*wit(second))
+        assert [p == i["proof"] for p, i in zip(proofs2, second)] == [True] * nb
+        assert c.verify_batch(proofs2, cat(second, "verifier_rand")) == [cpx.CPX_OK] * nb
+        # twice in a row (the staging area is reused once the first staged batch has been copied out), with a smaller batch
+        c.load_batch_begin(*inst(first[:2]))
+        c.load_batch_end()
+        c.load_batch_begin(*inst(second[:2]))
+        c.load_batch_end()
+        assert c.batch == 2
+        assert c.prove_batch(*wit(second[:2])) == [i["proof"] for i in second[:2]]
+        # a CRS of another size between _begin and _end: the staged rows no longer fit
+        c.load_batch_begin(*inst(first[:2]))
+        c.set_crs(60, orc.generate_crs_points(60))
+        with pytest.raises(cpx.CpxError) as e:
+            c.load_batch_end()
+        assert e.value.code == cpx.CPX_ERR_STATE
+        c.close()

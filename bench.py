@@ -431,6 +431,24 @@ def other_ell(c0, e3, b3, seed, what, c1=None):
         return dict(value=None, error=repr(e))
 
 
+PROD_PER_ADD = 3542.0 / 392.0   # modular products of one XYZZ mixed addition of the bucket loops (8M + 2S, two products of Y3 under one reduction: 3542 multiply-adds of 392)
+
+
+def msm_pair_cost(kernel):
+    """modular products one (scalar, point) pair costs in MSM kernel `kernel` (a name as Context.KERNELS / rocprofv3 spell it), 0.0 for a kernel that
+    moves no MSM pairs.  ONE table for every place that prices a kernel: until round 5 the dominant-kernel lookup had its own, without
+    k_msm_tblw_pair — whenever that kernel happened to be the longest MSM kernel of a small two-rank run, rank 0 died of a KeyError after the timed
+    region (the 'launcher failure' of tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu, VERDICT r05)."""
+    base = kernel.split("<")[0]
+    if base in ("k_msm_tblw", "k_msm_tblw_pair"):
+        return 32 * 255.0 / 256 * PROD_PER_ADD            # 32 radix-256 windows, a zero digit once in 256
+    if base == "k_msm_fix":
+        return (14 if kernel.startswith("k_msm_fix<19") else 16) * PROD_PER_ADD
+    if base == "k_msm_accw":
+        return 64 * 15.0 / 16 * 11                         # radix-16 windows, Jacobian additions (11 products)
+    return 0.0
+
+
 def _parse_opts(kvs):
     return {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in kvs}
 
@@ -875,7 +893,7 @@ def main():
         # (the dominant kernel is an MSM kernel: on a small batch the lone k_smul chain of the side stream can be the longest launch, but it
         # moves no MSM points and says nothing about the path's roofline)
         msm_kernels = [k for k in stats if k.startswith(("k_msm_fix", "k_msm_tblw", "k_msm_accw")) and stats[k]["ms"] > 0]
-        dom = max(msm_kernels or [k for k in stats if k.startswith("k_smul")], key=lambda k: stats[k]["ms"])
+        dom = max(msm_kernels or [k for k in stats if k.startswith("k_smul")] or list(stats), key=lambda k: stats[k]["ms"])
         st = stats[dom]
         avg_ms = st["ms"] / max(st["launches"], 1)
         bytes_per_launch = st["alg_bytes"] / max(st["launches"], 1)
@@ -896,9 +914,7 @@ def main():
         # of one mixed addition.  The extended-Jacobian mixed addition of the bucket loops is 8M + 2S with the two products of Y3
         # under one reduction: 3542 multiply-adds = 9.04 products of 392 (rounds 1-2 of this build counted 11, the Jacobian 7M + 4S,
         # for an addition that cost 9.5: their fractions read 16 % too high).
-        PROD_PER_ADD = 3542.0 / 392.0
-        mulmods_per_point = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11, "k_msm_fix": (14 if dom.startswith("k_msm_fix<19") else 16) * PROD_PER_ADD,
-                             "k_smul": 0.0}[dom.split("<")[0]]
+        mulmods_per_point = msm_pair_cost(dom)
         ctxs[0].set_option("bench_field", 28)
         peak_mm = ctxs[0].bench_fpmul(2048, 1000, 2)
         ach_mm = st["units"] * mulmods_per_point / (st["ms"] * 1e-3) if st["ms"] else 0.0
@@ -907,13 +923,11 @@ def main():
                                 note="kernel time is measured with all engine contexts sharing the GPU, so it includes the other contexts' kernels; "
                                      "'isolated' repeats the measurement after the timed region with one context alone and its side stream's kernels in line "
                                      "(option serial_streams): the kernel has the GPU to itself")
-        per_pair = {"k_msm_tblw": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_tblw_pair": 32 * 255.0 / 256 * PROD_PER_ADD, "k_msm_accw": 64 * 15.0 / 16 * 11,
-                    "k_msm_fix": 16 * PROD_PER_ADD}
-        pair_cost = lambda k: (14 * PROD_PER_ADD if k.startswith("k_msm_fix<19") else per_pair[k.split("<")[0]])
+        pair_cost = msm_pair_cost
         # The whole pass against the same peak: the products of the MSM additions of a prove + verify (every point-scalar pair of every MSM kernel of
         # the timed region x the additions a pair costs x 9.04 products) x the measured rate.  Everything else a pass executes — per-proof table
         # build, late-round materialisation, bucket reductions, decompression, transcripts — is overhead by this count, and so is idle issue time.
-        useful = sum(v["units"] * pair_cost(k) for k, v in stats.items() if k.split("<")[0] in per_pair and v["launches"]) / max(1.0, float(B * args.steps))
+        useful = sum(v["units"] * pair_cost(k) for k, v in stats.items() if msm_pair_cost(k) and v["launches"]) / max(1.0, float(B * args.steps))
         roofline["valu"]["whole_pass"] = dict(frac=useful * (value / world) / peak_mm if peak_mm else None, useful_products_per_proof=useful,
                                               useful_products_per_s_per_gpu=useful * value / world,
                                               note="useful = modular products of the MSM additions only; per GPU against the product peak measured in this run")
@@ -924,7 +938,7 @@ def main():
                         # the same measurement in the accounting of rounds 1-2a (11 products per addition), for comparison with their numbers
                         frac_at_11_products_per_addition=(v["units"] * pair_cost(k) * (11.0 / PROD_PER_ADD if k.split("<")[0] != "k_msm_accw" else 1.0)
                                                           / (v["ms"] * 1e-3) / peak_mm) if v["ms"] and peak_mm else None)
-                for k, v in iso.items() if k.split("<")[0] in per_pair and v["ms"] and v["launches"] > 0}
+                for k, v in iso.items() if msm_pair_cost(k) and v["ms"] and v["launches"] > 0}
         if iso and dom in iso and iso[dom]["ms"]:
             ist = iso[dom]
             iso_mm = ist["units"] * mulmods_per_point / (ist["ms"] * 1e-3)
@@ -957,28 +971,42 @@ def main():
                    kernel_ms_per_step={k: v["ms"] / args.steps for k, v in stats.items() if v["launches"]},
                    vs_readme_i7_8550u=value / README_I7_PROOFS_PER_S, roofline=roofline)
         # Everything below runs on rank 0 only, outside the timed region, at ANY N (the other ranks wait at the final barrier): the
-        # literal BASELINE shapes, the batched verifier, the other proof sizes and the CPU baseline belong to every line.
+        # literal BASELINE shapes, the batched verifier, the other proof sizes and the CPU baseline belong to every line.  Every stage is guarded: a
+        # failure in an extra (round 5: a KeyError after the timed region took rank 0 down, and the line with it) is recorded under `errors` and the
+        # contract line is still printed.
         AFF, FR, JAC = cpx.AFF, cpx.FR, cpx.JAC
         c0, n_ = ctxs[0], ell + 4
-        if not args.no_extra_shapes:
+        errors = {}
+
+        def stage(name, fn):
+            try:
+                fn()
+            except Exception as e:
+                import traceback
+                errors[name] = "%r | %s" % (e, traceback.format_exc(limit=4).replace("\n", " / "))
+
+        def st_config5():
             # BASELINE configs[4] (the batched verifier), driver-visible: context 0 still holds its share of the timed batch and the proofs
             # of the last pass; ONE accumulated check over all of them, verdict included (cpx_batch_verify_fused + cpx_g1_sum_jac; with
             # N GPUs the 144-byte partial sums are all-gathered first: --fused-verify)
             out["config5"] = fused_check(c0, proofs[0], B // K, ell, peak_mm, PROD_PER_ADD)
-        # BASELINE configs[1]: the same instance shape as ONE proof (latency, not throughput): instance 0 alone on context 0
-        c0.load_batch(data["vec_R"][:ell * AFF], data["vec_S"][:ell * AFF], data["vec_T"][:ell * AFF], data["vec_U"][:ell * AFF], data["M"][:JAC])
-        tp, tv = [], []
-        for _ in range(4):
-            t0 = time.perf_counter()
-            one = c0.prove_batch(data["perms"][:ell], data["k"][:FR], data["mbl"][:4 * FR], data["prand"][:(3 * n_ + 9) * FR])
-            t1 = time.perf_counter()
-            v1 = c0.verify_batch(one, data["vrand"][:8 * FR])
-            t2 = time.perf_counter()
-            tp.append(t1 - t0)
-            tv.append(t2 - t1)
-        out["single_proof"] = dict(prove_ms=1e3 * min(tp), verify_ms=1e3 * min(tv), accepted=v1 == [cpx.CPX_OK],
-                                   note="BASELINE configs[1] as a latency figure: one ell=%d proof alone on the GPU (best of 4)" % ell)
-        if not args.no_extra_shapes:
+
+        def st_single():
+            # BASELINE configs[1]: the same instance shape as ONE proof (latency, not throughput): instance 0 alone on context 0
+            c0.load_batch(data["vec_R"][:ell * AFF], data["vec_S"][:ell * AFF], data["vec_T"][:ell * AFF], data["vec_U"][:ell * AFF], data["M"][:JAC])
+            tp, tv = [], []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                one = c0.prove_batch(data["perms"][:ell], data["k"][:FR], data["mbl"][:4 * FR], data["prand"][:(3 * n_ + 9) * FR])
+                t1 = time.perf_counter()
+                v1 = c0.verify_batch(one, data["vrand"][:8 * FR])
+                t2 = time.perf_counter()
+                tp.append(t1 - t0)
+                tv.append(t2 - t1)
+            out["single_proof"] = dict(prove_ms=1e3 * min(tp), verify_ms=1e3 * min(tv), accepted=v1 == [cpx.CPX_OK],
+                                       note="BASELINE configs[1] as a latency figure: one ell=%d proof alone on the GPU (best of 4)" % ell)
+
+        def st_shapes():
             # BASELINE configs[3] at its literal shapes: 1024 proofs total = 128 per GPU on 8 GPUs; and 1024 on one GPU.  One context, proofs of the
             # bench batch; steady-state prove + verify passes (not the headline: smaller batches fill the GPU less)
             shapes = {}
@@ -993,6 +1021,8 @@ def main():
                 shapes["batch_1024_per_gpu"]["two_contexts"] = shape_passes_two(c0, ctxs[1], data, ell, 1024)
             out["baseline_shapes"] = dict(note="BASELINE configs[3] (1024 independent ell=%d proofs) at its literal shapes, one engine context: 128 proofs per GPU "
                                                "(the per-GPU share on 8 GPUs) and 1024 proofs on one GPU" % ell, **shapes)
+
+        def st_config5_literal():
             # BASELINE configs[4] at its literal shapes: 4096 proofs in one accumulated check = 512 per GPU on 8 GPUs; and all 4096 on one GPU
             lit = {}
             for nb in (512, 4096):
@@ -1003,29 +1033,49 @@ def main():
             if "config5" in out:
                 out["config5"]["literal_shapes"] = dict(note="BASELINE configs[4] is 4096 proofs in ONE accumulated check: 512 per GPU on 8 GPUs (then one all-gather of "
                                                              "148 bytes per rank), or all 4096 on one GPU; one engine context each", **lit)
-            if ell == 252:
-                # the reference's own bench shape (benches/perf.rs:29: N = 512, ell = 508), prover and verifier rates apart as criterion prints
-                # them; and BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
-                c1 = ctxs[1] if len(ctxs) > 1 else None
-                out["ell_508"] = other_ell(c0, 508, 4096, 5081, "the reference's in-tree criterion bench shape (benches/perf.rs:29, N = 512)", c1)
-                out["ell_1020"] = other_ell(c0, 1020, 2048, 4321, "BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput", c1)
-        if not args.no_cpu_baseline:   # the CPU oracle beside the GPU number in the same run, on rank 0 at every N
+
+        def st_other_ells():
+            # the reference's own bench shape (benches/perf.rs:29: N = 512, ell = 508), prover and verifier rates apart as criterion prints
+            # them; and BASELINE configs[2] as throughput: ell = 1020 (n = 1024, 10 rounds)
+            c1 = ctxs[1] if len(ctxs) > 1 else None
+            out["ell_508"] = other_ell(c0, 508, 4096, 5081, "the reference's in-tree criterion bench shape (benches/perf.rs:29, N = 512)", c1)
+            out["ell_1020"] = other_ell(c0, 1020, 2048, 4321, "BASELINE configs[2] shape (ell=1020, n=1024, 10 rounds) as throughput", c1)
+
+        def st_cpu():
             out["cpu_baseline"] = cpu_baseline(ell, data, proofs[0])   # (+ a sample of 8 proofs of context 0's last pass against the oracle's bytes)
             if "config5" in out:
                 vs = out["cpu_baseline"]["verify_s"]
                 out["config5"]["cpu_verify_per_proof"] = dict(value=1.0 / vs, unit="proofs/s", cores=1, kind="port",
                                                               sample="CurdleproofsProof::verify of instance 0, oracle/ single thread, %.4f s each" % vs)
-            if not args.no_extra_shapes:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ell, data)
-        else:
-            out["cpu_baseline"] = None
-        if not args.no_traffic and os.environ.get("CPX_BENCH_TRAFFIC", "1") != "0":
+
+        def st_cpu_all():
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ell, data)
+
+        def st_traffic():
             for c in ctxs:   # the counter passes run in child processes with a context of their own: give the HBM back first
                 c.close()
             tr, how = measure_traffic(dom, ell, B // K, local_rank, engine_opts)
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr, how
             if tr:
                 out["roofline"]["traffic_over_algorithmic"] = tr / bytes_per_launch if bytes_per_launch else None
+
+        out["cpu_baseline"] = None
+        if not args.no_extra_shapes:
+            stage("config5", st_config5)
+        stage("single_proof", st_single)
+        if not args.no_extra_shapes:
+            stage("baseline_shapes", st_shapes)
+            stage("config5_literal_shapes", st_config5_literal)
+            if ell == 252:
+                stage("other_proof_sizes", st_other_ells)
+        if not args.no_cpu_baseline:   # the CPU oracle beside the GPU number in the same run, on rank 0 at every N
+            stage("cpu_baseline", st_cpu)
+            if not args.no_extra_shapes:
+                stage("cpu_baseline_all_cores", st_cpu_all)
+        if not args.no_traffic and os.environ.get("CPX_BENCH_TRAFFIC", "1") != "0":
+            stage("traffic", st_traffic)
+        if errors:
+            out["errors"] = errors
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -9,12 +9,13 @@ ok=0; bad=0
 {
   echo "# two_rank_soak: $N x python bench.py --gpus 2 --ell 28 --batch 128 --steps 2 --warmup 1 --no-extra-shapes --no-traffic $* (commit ${COMMIT:-unknown})"
   for i in $(seq 1 $N); do
-    t0=$(date +%s.%N)
+    t0=$(date +%s%N)
     python bench.py --gpus 2 --ell 28 --batch 128 --steps 2 --warmup 1 --no-extra-shapes --no-traffic "$@" > /tmp/soak_$i.out 2> /tmp/soak_$i.err
     rc=$?
-    t1=$(date +%s.%N)
+    t1=$(date +%s%N)
     v=$(grep -o '"value": [0-9.]*' /tmp/soak_$i.out | head -1)
-    printf "run %2d rc=%d %.1f s %s\n" $i $rc $(echo "$t1 - $t0" | bc) "$v"
+    v="$v dominant $(grep -o '"roofline": {"bound": "hbm", "kernel": "[^"]*"' /tmp/soak_$i.out | head -1 | sed 's/.*"kernel": //') $(grep -o '"errors": {[^}]*}' /tmp/soak_$i.out | head -1)"
+    printf "run %2d rc=%d %d.%d s %s\n" $i $rc $(( (t1 - t0) / 1000000000 )) $(( (t1 - t0) / 100000000 % 10 )) "$v"
     if [ $rc -ne 0 ]; then bad=$((bad+1)); { echo "==== run $i rc=$rc stdout"; cat /tmp/soak_$i.out; echo "==== stderr"; cat /tmp/soak_$i.err; } > $O/two_rank_soak_failure_$i.log; else ok=$((ok+1)); fi
   done
   echo "# green $ok / $N, failed $bad"

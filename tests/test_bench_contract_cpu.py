@@ -108,3 +108,20 @@ def test_bench_refuses_a_world_that_disagrees_with_gpus():
     env = dict(os.environ, CPX_BENCH_DRYRUN="1", CPX_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_every_msm_kernel_the_engine_reports_has_a_price():
+    """bench.py prices the dominant MSM kernel of the timed region through ONE table (msm_pair_cost).  Until round 5 the dominant-kernel lookup had a
+    table of its own that lacked k_msm_tblw_pair: when that kernel happened to be the longest MSM kernel of a small two-rank run, rank 0 died of a
+    KeyError after the timed region — the unexplained 'launcher failure' the two-rank GPU test retried."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import curdleproofs_amd as cpx
+    msm = [k for k in cpx.Context.KERNELS if k.startswith(("k_msm_fix", "k_msm_tblw", "k_msm_accw"))]
+    assert "k_msm_tblw_pair" in msm and len(msm) >= 10
+    for k in msm:
+        assert bench.msm_pair_cost(k) > 0, k
+    assert bench.msm_pair_cost("k_msm_fix<19, 7>") == 14 * bench.PROD_PER_ADD and bench.msm_pair_cost("k_msm_fix<16, 16>") == 16 * bench.PROD_PER_ADD
+    for k in cpx.Context.KERNELS:
+        if not k.startswith(("k_msm_fix", "k_msm_tblw", "k_msm_accw")):
+            assert bench.msm_pair_cost(k) == 0.0, k   # (k_msm_tail, k_smul, k_reduce_sets ...: no pairs)

@@ -1469,6 +1469,7 @@ def test_bench_two_ranks_on_one_gpu(fused):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["all_verified"] is True and d["scaling"] == "weak"
+    assert "errors" not in d, d["errors"]   # (a failing extra stage is recorded there instead of taking rank 0 — and the line — down)
     assert d["config"]["global_batch"] == 256 and d["config"]["batch_per_gpu"] == 128
     assert abs(d["value"] - 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     assert ("batched verifier" in d["metric"]) == fused
@@ -1528,7 +1529,9 @@ def _run_bench(extra, timeout=900):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-6000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    assert "errors" not in d, d["errors"]
+    return d
 
 
 def test_bench_interleaved_ab_of_an_option_and_of_two_library_builds(tmp_path):

@@ -35,12 +35,14 @@ def synth_scalars(seed, n):
     return a.tobytes()
 
 
-def synth_batch(ctx, ell, B, seed):
-    """Synthetic CRS + B shuffle instances built through the product API only (GPU scale / msm)."""
+def synth_batch(ctx, ell, B, seed, helpers=()):
+    """Synthetic CRS + B shuffle instances built through the product API only (GPU scale / msm).  `helpers`: further contexts whose host threads share
+    the per-proof util::msm calls (M of every instance: 0.8 ms per call, one call at a time per context)."""
+    import threading
+    import numpy as np
     import curdleproofs_amd as cpx
     from curdleproofs_amd import params as pr
     t_start = time.perf_counter()
-    rng = random.Random(seed)
     n = ell + 4
     gen = pr.g1_generator_wire()
     crs = ctx.scale(gen * (ell + 7), synth_scalars(seed * 16 + 1, ell + 7))
@@ -49,27 +51,39 @@ def synth_batch(ctx, ell, B, seed):
     vec_S = ctx.scale(vec_R, synth_scalars(seed * 16 + 3, B * ell))
     k_wire = synth_scalars(seed * 16 + 4, B)
     mbl_all = synth_scalars(seed * 16 + 5, 4 * B)
-    perms, vec_T, vec_U, Ms = [], [], [], []
     AFF, FR = cpx.AFF, cpx.FR
-    k_rep = b"".join(k_wire[32 * p:32 * p + 32] * ell for p in range(B))
-    kR_all = ctx.scale(vec_R, k_rep)                        # util.rs:94-95, all proofs in one launch
-    kS_all = ctx.scale(vec_S, k_rep)
+    k_rep = np.repeat(np.frombuffer(k_wire, dtype=np.uint8).reshape(B, FR), ell, axis=0).tobytes()
+    kR_all = np.frombuffer(ctx.scale(vec_R, k_rep), dtype=np.uint8).reshape(B, ell, AFF)   # util.rs:94-95, all proofs in one launch
+    kS_all = np.frombuffer(ctx.scale(vec_S, k_rep), dtype=np.uint8).reshape(B, ell, AFF)
+    del k_rep
     t_points = time.perf_counter()
-    idx_wire = [pr.fr_to_wire(i) for i in range(ell)]
-    crs_G = crs[:n * AFF]
-    for p in range(B):
-        perm = list(range(ell))
-        rng.shuffle(perm)
-        perms += perm
-        kR, kS = kR_all[p * ell * AFF:(p + 1) * ell * AFF], kS_all[p * ell * AFF:(p + 1) * ell * AFF]
-        vec_T.append(b"".join(kR[i * AFF:(i + 1) * AFF] for i in perm))
-        vec_U.append(b"".join(kS[i * AFF:(i + 1) * AFF] for i in perm))
-        sigma = b"".join(idx_wire[i] for i in perm)   # util.rs:99-103
-        Ms.append(ctx.msm(crs_G, sigma + mbl_all[p * 4 * FR:(p + 1) * 4 * FR]))
+    rng = np.random.default_rng(seed)
+    perm_all = np.stack([rng.permutation(ell) for _ in range(B)]).astype(np.uint32)      # [B][ell]
+    rows = np.arange(B)[:, None]
+    vec_T = kR_all[rows, perm_all].tobytes()                                               # T_i = k R_sigma(i)
+    vec_U = kS_all[rows, perm_all].tobytes()
+    del kR_all, kS_all
+    idx_wire = np.frombuffer(b"".join(pr.fr_to_wire(i) for i in range(ell)), dtype=np.uint8).reshape(ell, FR)
+    sigma_all = idx_wire[perm_all]                                                         # [B][ell][32]: util.rs:99-103
+    crs_G = ctx.marshal(crs[:n * AFF])
+    Ms = [None] * B
+    workers = [ctx] + list(helpers)
+
+    def commit(w):
+        c = workers[w]
+        for p in range(w, B, len(workers)):
+            Ms[p] = c.msm(crs_G, sigma_all[p].tobytes() + mbl_all[p * 4 * FR:(p + 1) * 4 * FR])
+    th = [threading.Thread(target=commit, args=(w,)) for w in range(1, len(workers))]
+    for t in th:
+        t.start()
+    commit(0)
+    for t in th:
+        t.join()
     t_end = time.perf_counter()
-    return dict(crs=crs, vec_R=vec_R, vec_S=vec_S, vec_T=b"".join(vec_T), vec_U=b"".join(vec_U), M=b"".join(Ms), perms=perms,
+    return dict(crs=crs, vec_R=vec_R, vec_S=vec_S, vec_T=vec_T, vec_U=vec_U, M=b"".join(Ms), perms=perm_all.reshape(-1).tolist(),
                 k=k_wire, mbl=mbl_all, prand=synth_scalars(seed * 16 + 6, B * (3 * n + 9)), vrand=synth_scalars(seed * 16 + 7, B * 8),
-                setup_s=dict(total=time.perf_counter() - t_start, crs_and_scalar_multiplications=t_points - t_start, per_proof_permute_and_commit=t_end - t_points))
+                setup_s=dict(total=time.perf_counter() - t_start, crs_and_scalar_multiplications=t_points - t_start, per_proof_permute_and_commit=t_end - t_points,
+                             commit_threads=len(workers)))
 
 
 def _instance(data, ell, i):
@@ -589,17 +603,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16384, help="instances per GPU per step (16 x the BASELINE configs[3] batch, split over the engine contexts: 8192 per context; 8192 per step measured 3 %% lower: the latency-bound kernels of a pass amortise over fewer proofs)")
+    ap.add_argument("--batch", type=int, default=32768, help="instances per GPU per step (32 x the BASELINE configs[3] batch, split over the engine contexts: 8192 per context; "
+                    "smaller batches amortise the latency-bound kernels of a pass over fewer proofs: 4096 per context measured 3 %% lower)")
     ap.add_argument("--ell", type=int, default=252)
     ap.add_argument("--fused-verify", action="store_true", help="measure BASELINE config 5 instead: the batched verifier (one accumulated MSM over "
                     "all proofs of all GPUs, one all-gather of 144-byte partial sums); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0, help="host worker threads per engine context (0 = cores / (ranks x contexts), clamped to [2, 24])")
     ap.add_argument("--synth-cache", default="", help="pickle file for the synthetic batch (created if missing): keeps profiled runs free of setup kernels")
-    ap.add_argument("--ctxs", type=int, default=2, help="engine contexts (HIP streams, one host thread each) per GPU; the batch is split over them: the "
+    ap.add_argument("--ctxs", type=int, default=4, help="engine contexts (HIP streams, one host thread each) per GPU; the batch is split over them: the "
                     "protocol is device-resident, several contexts let one context's latency-bound kernels (reductions, finalisation, step "
-                    "kernels) and the tails of its launches run beside the others' MSM waves (one box, eight hardware queues: 2 x 8192 17.29 k, "
-                    "3 x 8192 +0.4 %%, 4 x 8192 +2.7 %% with 230 of the 288 GB of HBM in use — not the default —, 2 x 16384 +1.0 %%; 6 x 8192 do not fit)")
+                    "kernels) and the tails of its launches run beside the others' MSM waves.  4 x 8192 since round 6 (one box, processes alternating: "
+                    "2 x 8192 16.44 k, 4 x 8192 16.84 k proofs/s, +2.4 %% in both pairs, profiles/r06_ctxs_2_vs_4.txt; 233 of the 288 GB of HBM; round 5 "
+                    "kept 2 x 8192 for the footprint).  --ab-lib doubles the contexts: run it with --ctxs 2 --batch 16384")
     ap.add_argument("--no-extra-shapes", action="store_true", help="skip the extra keys: throughput at BASELINE's literal batch shapes (128 / 1024 proofs per "
                     "GPU), ell=1020 throughput and the all-cores CPU baseline")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option for every context (cpx_ctx_set_option), e.g. "
@@ -692,7 +708,7 @@ def main():
             ctx.set_crs(ell, data["crs"])
             data["setup_s"] = dict(data["setup_s"], from_cache=True)
     if data is None:
-        data = synth_batch(ctx, ell, B, seed=1234 + rank)
+        data = synth_batch(ctx, ell, B, seed=1234 + rank, helpers=ctxs[1:])
         data["ell"], data["B"] = ell, B
         if cache:
             import pickle

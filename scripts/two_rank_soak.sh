@@ -7,10 +7,10 @@ export CPX_BENCH_BACKEND=gloo CPX_BENCH_DEVICE=0 GLOO_SOCKET_IFNAME=lo
 unset WORLD_SIZE RANK LOCAL_RANK
 ok=0; bad=0
 {
-  echo "# two_rank_soak: $N x python bench.py --gpus 2 --ell 28 --batch 128 --steps 2 --warmup 1 --no-extra-shapes --no-traffic $* (commit ${COMMIT:-unknown})"
+  echo "# two_rank_soak: $N x python bench.py --gpus 2 --ell 28 --batch 128 --ctxs 2 --steps 2 --warmup 1 --no-extra-shapes --no-traffic $* (commit ${COMMIT:-unknown})"
   for i in $(seq 1 $N); do
     t0=$(date +%s%N)
-    python bench.py --gpus 2 --ell 28 --batch 128 --steps 2 --warmup 1 --no-extra-shapes --no-traffic "$@" > /tmp/soak_$i.out 2> /tmp/soak_$i.err
+    python bench.py --gpus 2 --ell 28 --batch 128 --ctxs 2 --steps 2 --warmup 1 --no-extra-shapes --no-traffic "$@" > /tmp/soak_$i.out 2> /tmp/soak_$i.err
     rc=$?
     t1=$(date +%s%N)
     v=$(grep -o '"value": [0-9.]*' /tmp/soak_$i.out | head -1)

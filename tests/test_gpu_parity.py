@@ -1001,16 +1001,22 @@ def test_headline_shape_1024_proofs_ell252_every_proof_matches_oracle(orc):
 _INSTANCE_LISTS = {}
 
 
+_DISTINCT = {252: 1024, 1020: 128}   # distinct oracle instances per proof size the large shapes draw from (the rest of a batch repeats them)
+
+
 def _instance_list(orc, ell, count, crs):
-    """instances 0 .. count-1 of BASELINE configs[3]'s recipe (instance i from StdRng(i)), computed once per session on all host cores (the
-    oracle is a C library behind ctypes: the GIL is released) and shared by the tests of the large shapes"""
+    """`count` instances of BASELINE configs[3]'s recipe (instance i from StdRng(i mod D)), computed once per session on all host cores (the
+    oracle is a C library behind ctypes: the GIL is released) and shared by the tests of the large shapes.  D distinct instances (1024 at
+    ell = 252 — BASELINE configs[3]'s own count —, 128 at ell = 1020), repeated beyond that: the oracle needs 0.9 / 3.2 s per instance and
+    core, and the GPU suite has to stay well inside the driver's time limit (round 5: 2048 + 512 distinct ones were 250 s of a 634-s suite)."""
     from concurrent.futures import ThreadPoolExecutor
     have = _INSTANCE_LISTS.setdefault(ell, [])
-    if len(have) < count:
+    want = min(count, _DISTINCT.get(ell, count))
+    if len(have) < want:
         ncpu = min(len(os.sched_getaffinity(0)), os.cpu_count() or 8, 64)
         with ThreadPoolExecutor(ncpu) as ex:
-            have.extend(ex.map(lambda s: orc._make_instance(ell, s, crs), range(len(have), count)))
-    return have[:count]
+            have.extend(ex.map(lambda s: orc._make_instance(ell, s, crs), range(len(have), want)))
+    return [have[i % want] for i in range(count)]
 
 
 def _three_wrong(good):
@@ -1457,7 +1463,7 @@ def test_bench_two_ranks_on_one_gpu(fused):
     env.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the ranks meet on the loopback interface whatever the box's hostname resolves to
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ell", "28", "--batch", "128", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ell", "28", "--batch", "128", "--ctxs", "2", "--steps", "2", "--warmup", "1",
            "--no-extra-shapes", "--no-traffic"] + (["--fused-verify"] if fused else [])
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:   # no second go (round 5 retried once): the whole output of a failed launch is kept for the reader and the test fails
@@ -1555,7 +1561,7 @@ def test_bench_interleaved_ab_of_an_option_and_of_two_library_builds(tmp_path):
 def test_bench_measures_hbm_traffic_in_the_run_and_reports_the_upload_inclusive_rate():
     """The bench line's roofline.traffic comes from rocprofv3 --pmc child passes of the run itself (FETCH_SIZE and WRITE_SIZE apart, counters only), the
     whole-pass product fraction and the rate with the public instances uploaded inside the timed region sit beside the headline."""
-    d = _run_bench(["--ell", "28", "--batch", "256", "--steps", "2", "--warmup", "1", "--no-extra-shapes", "--no-cpu-baseline"])
+    d = _run_bench(["--ell", "28", "--batch", "256", "--ctxs", "2", "--steps", "2", "--warmup", "1", "--no-extra-shapes", "--no-cpu-baseline"])
     r = d["roofline"]
     assert r["traffic"] is not None and r["traffic"] > 0, r["traffic_source"]
     assert r["traffic_source"]["FETCH_SIZE"]["dispatches"] > 0 and r["traffic_source"]["WRITE_SIZE"]["dispatches"] > 0

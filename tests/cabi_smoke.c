@@ -109,6 +109,12 @@ int main(int argc, char** argv) {
   CHECK(!memcmp(proof, want_proof.p, want_proof.n), "proof bytes differ from the oracle's");
   int verdict = CPX_ERR_INTERNAL;
   CHECK(cpx_batch_verify(ctx, proof, vrand.p, &verdict) == CPX_OK && verdict == CPX_OK, "cpx_batch_verify must accept the proof");
+  /* the same instance staged as the NEXT batch (cpx_batch_load_begin / _end): the loaded batch keeps proving in between, the staged one after */
+  CHECK(cpx_batch_load_end(ctx) == CPX_ERR_STATE, "cpx_batch_load_end without _begin must be a state error");
+  CHECK(cpx_batch_load_begin(ctx, 1, R.p, S.p, T.p, U.p, M.p) == CPX_OK, "cpx_batch_load_begin");
+  CHECK(cpx_batch_prove(ctx, (const uint32_t*)perm.p, k.p, mbl.p, prand.p, proof) == CPX_OK && !memcmp(proof, want_proof.p, want_proof.n), "prove beside a staged upload");
+  CHECK(cpx_batch_load_end(ctx) == CPX_OK && cpx_batch_size(ctx) == 1, "cpx_batch_load_end");
+  CHECK(cpx_batch_prove(ctx, (const uint32_t*)perm.p, k.p, mbl.p, prand.p, proof) == CPX_OK && !memcmp(proof, want_proof.p, want_proof.n), "prove on the staged batch");
   uint8_t tmp[48];   /* swap A and cm_T.T_1: still valid encodings, a wrong proof */
   memcpy(tmp, proof, 48);
   memcpy(proof, proof + 48, 48);

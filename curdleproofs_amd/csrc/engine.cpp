@@ -605,7 +605,7 @@ void Engine::msm(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t
   CPX_HIP(hipMemcpyAsync(dt.p, &t, sizeof t, hipMemcpyHostToDevice, stream_));
   DevBuf<TAff>& conv = t0_.conv;
   conv.ensure(2 * std::max<size_t>(n, 1));
-  if (n >= 64) {   // endomorphism split + radix-256 bucket lists (the verifier's kernel): 32 additions per point
+  if ((long)n >= opt_.msm_endo_min && n) {   // endomorphism split + radix-256 bucket lists (the verifier's kernel): 32 additions per point
     DevBuf<TblTask>& tt = t0_.ttask;
     DevBuf<TJac>& part = t0_.part;
     DevBuf<uint32_t>& dig = t0_.dig;

@@ -60,6 +60,7 @@ struct Options {
                                    // 12; 0: separate waves; -1 = by the batch (combined from 86 proofs on: 12 waves per proof no longer find a SIMD each)
   long smul_quad_max = 1024;       // the prover's T_2 scalar multiplications of a batch of up to this many elements (4 per proof) run with a quad per element (k_smul_quad)
   long strict_infinity = 0;        // point encodings with the infinity flag set: 0 = the identity whatever the other 382 bits say (ark-bls12-381 ^0.4 `read_g1_compressed`, as recalled: include/cpx.h), 1 = only 0xc0 || 0^47 (the zcash specification's wording; ark-bls12-381 0.5)
+  long msm_endo_min = 1;           // cpx_g1_msm / cpx_g1_msm_jac: from this many points on the endomorphism bucket-list path (k_to_table_endo + k_msm_tblw<2, true>), below it the plain windowed accumulation (k_msm_accw: three dependent launches with doubling chains, 1.35 - 1.5 ms per call at 1 - 63 points against 0.72 - 0.77 on the bucket-list path; the default was 64 until round 6)
   long scale_any_point = 0;        // 1: cpx_g1_scale / cpx_g1_fold take ANY point of E(Fp) (plain 257-step double-and-add, SMUL_PLAIN); 0: points of the order-r subgroup (endomorphism split, 129 steps)
 };
 const Options& default_options();                               // built-in defaults overridden by CPX_<NAME> environment variables

@@ -1343,7 +1343,7 @@ const OptField kOptFields[] = {
     {"p1_split", &Options::p1_split, 0, 1},                      {"transcript_lane_min_batch", &Options::transcript_lane_min_batch, 1, 1L << 30},
     {"late_rounds", &Options::late_rounds, 0, 4},                {"late_min_batch", &Options::late_min_batch, 1, 1L << 30},
     {"late_slices", &Options::late_slices, 1, 8},                {"rs_pairs", &Options::rs_pairs, 0, 1},                         {"late_m", &Options::late_m, 0, 64},
-    {"table_chunks", &Options::table_chunks, 0, 64},
+    {"table_chunks", &Options::table_chunks, 0, 64},                {"msm_endo_min", &Options::msm_endo_min, 1, 1L << 30},
     {"transcript_excl_max", &Options::transcript_excl_max, 0, 1L << 30}, {"table_stream_max", &Options::table_stream_max, 0, 1L << 30},
     {"scale_any_point", &Options::scale_any_point, 0, 1},         {"strict_infinity", &Options::strict_infinity, 0, 1},
     {"fused_rounds_max", &Options::fused_rounds_max, 0, 1L << 30}, {"fused_smsm_max", &Options::fused_smsm_max, 0, 1L << 30}, {"fused_fix_wpw", &Options::fused_fix_wpw, 0, 16},

@@ -1514,6 +1514,30 @@ def test_bench_two_ranks_on_one_gpu(fused):
             assert by_kernel[d["roofline"]["kernel"]]["frac"] == pytest.approx(d["roofline"]["valu"]["isolated"]["frac"], rel=1e-9)
 
 
+def test_bench_eight_ranks_on_one_gpu():
+    """The driver's scaling run ends at N = 8 and is one shot: the same launch with EIGHT real ranks (each with an engine context on GPU 0, gloo instead of
+    RCCL, a small shape), not a dry run — eight process-group members, every rank proves and verifies its own batch, the max over ranks, rank 0's
+    extras (CPU baseline, roofline) while seven ranks wait at the final barrier, ONE line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPX_BENCH_BACKEND="gloo", CPX_BENCH_DEVICE="0")
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--ell", "28", "--batch", "64", "--ctxs", "1", "--steps", "2", "--warmup", "1",
+           "--no-extra-shapes", "--no-traffic"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-6000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert "errors" not in d, d["errors"]
+    assert d["n_gpus"] == 8 and d["all_verified"] is True and d["config"]["global_batch"] == 512 and d["config"]["batch_per_gpu"] == 64
+    assert d["cpu_baseline"]["gpu_proof_bit_exact"] is True and d["roofline"]["frac"] > 0
+
+
 @pytest.mark.parametrize("copies", [1, 97], ids=["host_driven", "device_resident"])
 def test_instances_with_identity_points_and_repeated_points(ctx, orc, copies):
     """Edge instances the reference accepts as inputs: a ciphertext whose components are the point at infinity (R_i = S_i = O, hence an

@@ -690,40 +690,15 @@ def main():
     ell, B, K = args.ell, args.batch, max(1, args.ctxs)
     assert B % K == 0, "--batch must be a multiple of --ctxs"
     engine_opts = _parse_opts(args.opt)
-    ctxs = [cpx.Context(local_rank, options=engine_opts) for _ in range(K)]          # raises without a GPU: no CPU fallback
-    # host worker threads per context: the cores of the node divided over ranks x contexts (all ranks share one node)
-    host_threads = args.host_threads or max(2, min(24, effective_cores() // (world * K)))
-    for c in ctxs:
-        c.set_host_threads(host_threads)
-    ctx = ctxs[0]
-    data = None
-    cache = args.synth_cache and ("%s.r%d" % (args.synth_cache, rank))
-    if cache and os.path.exists(cache):
-        import pickle
-        with open(cache, "rb") as f:
-            data = pickle.load(f)
-        if data.get("ell") != ell or data.get("B") != B or "setup_s" not in data:
-            data = None
-        else:
-            ctx.set_crs(ell, data["crs"])
-            data["setup_s"] = dict(data["setup_s"], from_cache=True)
-    if data is None:
-        data = synth_batch(ctx, ell, B, seed=1234 + rank, helpers=ctxs[1:])
-        data["ell"], data["B"] = ell, B
-        if cache:
-            import pickle
-            with open(cache, "wb") as f:
-                pickle.dump(data, f)
-    # split the batch over the contexts; every context holds the CRS and its share of instances in HBM
-    Bk = B // K
     n_ = ell + 4
-    def part(buf, unit, k):
-        return buf[k * Bk * unit:(k + 1) * Bk * unit]
 
-    def make_shares(cs):
+    def make_shares(cs, data, Bk, first):
+        """every context of `cs` gets the CRS and its share of the batch (instances resident in HBM, witnesses in page-locked host memory)"""
+        def part(buf, unit, k):
+            return buf[k * Bk * unit:(k + 1) * Bk * unit]
         shs = []
         for k, c in enumerate(cs):
-            if c is not ctx:
+            if c is not first:
                 c.set_crs(ell, data["crs"])
             sh = dict(vec_R=part(data["vec_R"], ell * cpx.AFF, k), vec_S=part(data["vec_S"], ell * cpx.AFF, k),
                       vec_T=part(data["vec_T"], ell * cpx.AFF, k), vec_U=part(data["vec_U"], ell * cpx.AFF, k), M=part(data["M"], cpx.JAC, k),
@@ -736,7 +711,87 @@ def main():
             c.load_batch(sh["vec_R"], sh["vec_S"], sh["vec_T"], sh["vec_U"], sh["M"])   # inputs now resident in HBM
             shs.append(sh)
         return shs
-    shares = make_shares(ctxs)
+
+    def setup(K_, B_):
+        """K_ engine contexts holding B_ synthetic instances between them, and ONE prove + verify pass on all of them at once: every buffer of the
+        timed region exists when this returns (the engine allocates its scratch at the first pass of a shape)"""
+        cs = []
+        try:
+            if K_ > int(os.environ.get("CPX_BENCH_FAIL_SETUP_ABOVE", "1000000")):   # test hook: rehearses the fallback without exhausting HBM
+                raise cpx.CpxError(cpx.CPX_ERR_HIP, "CPX_BENCH_FAIL_SETUP_ABOVE: set-up with %d contexts refused" % K_)
+            cs = [cpx.Context(local_rank, options=engine_opts) for _ in range(K_)]          # raises without a GPU: no CPU fallback
+            # host worker threads per context: the cores of the node divided over ranks x contexts (all ranks share one node)
+            ht = args.host_threads or max(2, min(24, effective_cores() // (world * K_)))
+            for c in cs:
+                c.set_host_threads(ht)
+            data_ = None
+            cache = args.synth_cache and ("%s.r%d" % (args.synth_cache, rank))
+            if cache and os.path.exists(cache):
+                import pickle
+                with open(cache, "rb") as f:
+                    data_ = pickle.load(f)
+                if data_.get("ell") != ell or data_.get("B") != B_ or "setup_s" not in data_:
+                    data_ = None
+                else:
+                    cs[0].set_crs(ell, data_["crs"])
+                    data_["setup_s"] = dict(data_["setup_s"], from_cache=True)
+            if data_ is None:
+                data_ = synth_batch(cs[0], ell, B_, seed=1234 + rank, helpers=cs[1:])
+                data_["ell"], data_["B"] = ell, B_
+                if cache:
+                    import pickle
+                    with open(cache, "wb") as f:
+                        pickle.dump(data_, f)
+            shs = make_shares(cs, data_, B_ // K_, cs[0])
+            errs = []
+
+            def probe(k):
+                try:
+                    pr_ = cs[k].prove_batch(shs[k]["perms"], shs[k]["k"], shs[k]["mbl"], shs[k]["prand"], raw=True)
+                    cs[k].verify_batch(pr_, shs[k]["vrand"])
+                except Exception as e:
+                    errs.append(e)
+            th = [threading.Thread(target=probe, args=(k,)) for k in range(K_)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+            return cs, ht, data_, shs
+        except Exception:
+            for c in cs:
+                try:
+                    c.close()
+                except Exception:
+                    pass
+            raise
+
+    # Four contexts x 8192 proofs hold 233 of the 288 GB of HBM.  Should that not fit (something else on the device), every rank falls back to half
+    # the contexts and half the batch — together: `value` counts world x B proofs per step — and the line says so (config.fallback).
+    fallback = None
+    while True:
+        err = None
+        try:
+            ctxs, host_threads, data, shares = setup(K, B)
+        except cpx.CpxError as e:
+            err = e
+        ok = 0 if err else 1
+        if dist is not None:
+            t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if ok:
+            break
+        if K <= 2 or B % 2 or (B // 2) % (K // 2):
+            raise err if err else RuntimeError("another rank could not set up its contexts")
+        if not err:
+            for c in ctxs:
+                c.close()
+        fallback = dict(from_contexts=K, from_batch=B, reason=repr(err) if err else "another rank's set-up failed")
+        K, B = K // 2, B // 2
+    ctx = ctxs[0]
+    Bk = B // K
 
     def barrier():
         torch.cuda.synchronize()
@@ -753,7 +808,7 @@ def main():
             ctxs_b = [cpx.Context(local_rank, options=engine_opts, lib=args.ab_lib) for _ in range(K)]
             for c in ctxs_b:
                 c.set_host_threads(host_threads)
-            shares_b = make_shares(ctxs_b)
+            shares_b = make_shares(ctxs_b, data, Bk, None)
             base = variants or [("", ctxs, shares, {})]
             variants = [((lbl + " " if lbl else "") + "libcpx.so", c_, s_, o_) for lbl, c_, s_, o_ in base] + \
                        [((lbl + " " if lbl else "") + os.path.basename(args.ab_lib), ctxs_b, shares_b, o_) for lbl, _, _, o_ in base]
@@ -970,7 +1025,7 @@ def main():
                                         "(CurdleproofsProof::new) then verified; BASELINE configs[1] instance shape, per-GPU share "
                                         "of configs[3]" % (ell, n, L, B),
                                ell=ell, batch_per_gpu=B, global_batch=B * world, engine_contexts_per_gpu=K, host_threads_per_context=host_threads,
-                               fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"), hbm_used_gb=hbm_used_gb, parallelism="proofs sharded over %d GPU(s), no collective" % world),
+                               fix_bits=ctxs[0].get_option("fix_bits"), fix_bits_effective=ctxs[0].get_option("fix_bits_effective"), gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"), hbm_used_gb=hbm_used_gb, fallback=fallback, parallelism="proofs sharded over %d GPU(s), no collective" % world),
                    all_verified=all_ok and nbad_up == 0,
                    # the same metric with the 97 KB public instance of every proof uploaded (cpx_batch_load) inside the timed region on every pass
                    value_incl_instance_upload=world * B * up_steps / dt_up,

@@ -1571,12 +1571,12 @@ def test_instances_with_identity_points_and_repeated_points(ctx, orc, copies):
     assert ctx.verify_batch(proofs, base["verifier_rand"] * copies) == [cpx.CPX_ERR_VERIFY] * copies
 
 
-def _run_bench(extra, timeout=900):
+def _run_bench(extra, timeout=900, env_extra=None):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
+    env = dict(os.environ, **(env_extra or {}))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
@@ -1663,3 +1663,16 @@ def test_staged_instance_upload_keeps_the_loaded_batch_and_then_replaces_it(orc)
             c.load_batch_end()
         assert e.value.code == cpx.CPX_ERR_STATE
         c.close()
+
+
+def test_bench_falls_back_to_fewer_contexts_when_the_default_shape_does_not_fit():
+    """bench.py's default is four engine contexts x 8192 proofs (233 of the 288 GB of HBM).  If their set-up or first pass fails (HIP out of memory),
+    all ranks together fall back to half the contexts and half the batch and the line says so — rehearsed with the test hook that refuses more than
+    two contexts."""
+    d = _run_bench(["--ell", "28", "--batch", "256", "--ctxs", "4", "--steps", "2", "--warmup", "1", "--no-extra-shapes", "--no-cpu-baseline", "--no-traffic"],
+                   env_extra={"CPX_BENCH_FAIL_SETUP_ABOVE": "2"})
+    assert d["config"]["engine_contexts_per_gpu"] == 2 and d["config"]["batch_per_gpu"] == 128 and d["all_verified"] is True
+    assert d["config"]["fallback"]["from_contexts"] == 4 and d["config"]["fallback"]["from_batch"] == 256
+    assert abs(d["value"] - 128 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    d = _run_bench(["--ell", "28", "--batch", "256", "--ctxs", "4", "--steps", "2", "--warmup", "1", "--no-extra-shapes", "--no-cpu-baseline", "--no-traffic"])
+    assert d["config"]["engine_contexts_per_gpu"] == 4 and d["config"]["fallback"] is None
